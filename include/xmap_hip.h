@@ -1,0 +1,188 @@
+/*
+ * xmap_hip.h -- C ABI of libxmap_hip.so, the MI355X (gfx950) engine behind X-MAP's hot path.
+ *
+ * The reference (LPD-EPFL-ML/X-MAP) is pure Python on Spark and has no FFI; the interface this
+ * library replaces is the set of L2 "tool" methods that the three pipeline functions of
+ * code/xmap/utils/assist.py call.  Each entry point below cites the
+ * reference method(s) whose work it performs.  The host-side mirror of the Python API
+ * (xmap.utils.assist / xmap.core.*) binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer argument is a DEVICE pointer into HBM unless its name starts with h_;
+ *     buffers are allocated by the caller (the Python host uses torch tensors as containers);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - items are int32 indices in lexicographic order of the reference's id strings, users are
+ *     int32 indices in trainRDD order; string predicates arrive as small per-item arrays
+ *     (prefix_cls = class of iid[:2], suffix_cls = class of iid[-2:], contains_mask bit c =
+ *     class-c suffix string occurs in iid, flags bit0 = "S:" in iid, bit1 = "T:" in iid);
+ *   - return value 0 = ok, negative = error (xmap_last_error() gives the thread-local text);
+ *     functions that hand a count back to the host synchronise `stream` before returning.
+ */
+#ifndef XMAP_HIP_H
+#define XMAP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMAP_OK 0
+#define XMAP_ERR_HIP -1       /* a HIP runtime call or kernel launch failed */
+#define XMAP_ERR_ARG -2       /* bad argument */
+#define XMAP_ERR_OVERFLOW -3  /* an on-chip accumulator table overflowed; retry with a smaller slot target */
+#define XMAP_ERR_CAPACITY -4  /* caller-provided output buffer too small; needed size is reported */
+
+#define XMAP_COSINE 0         /* BaselinerSim.method == "cosine"        (core/baselinerSim.py:213) */
+#define XMAP_ADJUST_COSINE 1  /* BaselinerSim.method == "adjust_cosine" (core/baselinerSim.py:215) */
+
+#define XMAP_TOPC 10          /* candidates kept per start item: generator.py:85 keeps 10, :109 keeps 4 */
+
+/* Ratings resident in HBM: CSR by user (trainRDD order, profile order kept) + CSC by item
+ * (raters in ascending user index = the order reduceByKey concatenates co-raters in). */
+typedef struct xmap_ratings {
+    int64_t n_users;
+    int32_t n_items;
+    int64_t nnz;
+    const int64_t *user_ptr;    /* [n_users+1] */
+    const int32_t *user_item;   /* [nnz] */
+    const float *user_rating;   /* [nnz] */
+    const int64_t *user_time;   /* [nnz] unix seconds (stage C only) */
+    const int64_t *item_ptr;    /* [n_items+1] */
+    const int32_t *item_user;   /* [nnz] */
+    const float *item_rating;   /* [nnz] */
+    const int32_t *prefix_cls;  /* [n_items] */
+    const int32_t *suffix_cls;  /* [n_items] */
+    const uint32_t *contains_mask; /* [n_items] */
+    const uint8_t *flags;       /* [n_items] */
+} xmap_ratings;
+
+const char *xmap_last_error(void);
+int xmap_version(void);
+
+/* exclusive prefix sum of n int64 values; out[n] receives the total; *h_total (may be NULL) too (syncs). */
+int xmap_exclusive_scan_i64(void *stream, const int64_t *in, int64_t *out, int64_t n, int64_t *h_total);
+int xmap_exclusive_scan_i32_to_i64(void *stream, const int32_t *in, int64_t *out, int64_t n, int64_t *h_total);
+
+/* ---- stage A: baseliner_calculate_sim_pipeline (utils/assist.py:66-77) ------------------- */
+
+/* BaselinerSim.get_universal_user_info (core/baselinerSim.py:17-38): avg[u], norm2[u] (fp64). */
+int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *u_norm2);
+
+/* BaselinerSim.get_universal_item_info (core/baselinerSim.py:40-82): info[i] = (avg, norm2, adjnorm2, n).
+ * Also emits the stage-A private copies of the index arrays with bit 31 = (rating >= item avg), which is
+ * all retrieve_path_info (core/baselinerSim.py:97-113) needs per co-rating:
+ *   ua_item[e] = user_item[e] | ge<<31,  ia_user[p] = item_user[p] | ge<<31. */
+int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info /*[I][4]*/,
+                    int32_t *ua_item /*[nnz]*/, int32_t *ia_user /*[nnz]*/);
+
+/* Work decomposition for the pair kernel: unit = (item i, hash partition q of its partner space),
+ * Q[i] = ceil(min(W_i, I-1) / slot_target), W_i = sum over raters of (profile length - 1).
+ * Writes Q[I], unit_ptr[I+1] (exclusive scan of Q); *h_n_units, *h_contrib (= sum W_i = P). Syncs. */
+int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *unit_ptr,
+                  int64_t *h_n_units, int64_t *h_contrib);
+int xmap_sim_units(void *stream, int32_t n_items, const int32_t *Q, const int64_t *unit_ptr,
+                   int32_t *unit_item /*[n_units]*/, int32_t *unit_q /*[n_units]*/);
+
+/* BaselinerSim.calculate_item2item_sim (core/baselinerSim.py:176-216) restricted to the units
+ * [unit_lo, unit_hi) (item shards for multi-GPU): produce_pairwise_items + reduceByKey + cosine /
+ * adjusted-cosine + significance weighting + mutuality + zero filter.
+ * Pass 1 (count): unit_cnt[u] = kept pairs of unit u; h_counters[0] += kept, [1] += evaluated (D),
+ *                 [2] = overflow flag.  Pass 2 (fill) writes the kept pairs of unit u at
+ *                 unit_off[u] + [0, unit_cnt[u]) as (col, sim fp64, mutu, n_ij).
+ * sim, mutu are symmetric bit for bit; frac_mutu = mutu / (n_i + n_j - n_ij) is derived by consumers. */
+int xmap_sim_count(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg,
+                   const double *info, const int32_t *ua_item, const int32_t *ia_user, const int32_t *Q,
+                   const int32_t *unit_item, const int32_t *unit_q, int64_t unit_lo, int64_t unit_hi,
+                   int32_t *unit_cnt /*[n_units]*/, int64_t *d_counters /*[4] device*/, int64_t *h_counters /*[4]*/);
+int xmap_sim_fill(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg,
+                  const double *info, const int32_t *ua_item, const int32_t *ia_user, const int32_t *Q,
+                  const int32_t *unit_item, const int32_t *unit_q, int64_t unit_lo, int64_t unit_hi,
+                  const int64_t *unit_off /*[n_units+1]*/, int32_t *col, double *sim, int32_t *mutu, int32_t *nij);
+
+/* row_ptr[i] = unit_off[unit_ptr[i]], i in [0, I]: CSR row pointers of the kept pairs (units of one
+ * item are contiguous, so its partitions concatenate into its row). */
+int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, const int64_t *unit_off /*[n_units+1]*/,
+                     int64_t *row_ptr /*[I+1]*/);
+
+/* ---- stage B: extender_pipeline (utils/assist.py:80-133) ---------------------------------- */
+
+/* Similarity matrix of stage A, CSR by first item (get_item_sim, core/baselinerSim.py:218-233). */
+typedef struct xmap_sim {
+    int32_t n_items;
+    const int64_t *row_ptr; /* [I+1] */
+    const int32_t *col;
+    const double *sim;
+    const int32_t *mutu;
+    const int32_t *nij;
+    const double *info;     /* [I][4] item info of stage A (n_i is info[i][3]) */
+} xmap_sim;
+
+/* build_sim_DF + "SELECT DISTINCT id1 ... WHERE label = 1" (core/baselinerSim.py:235-244,
+ * utils/assist.py:82-87): bb[i] = 1 iff item i has a kept pair whose 2-char prefixes differ. */
+int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls, uint8_t *bb);
+
+/* ExtendSim.find_knn_items (core/extender.py:16-44) + extract_siminfo (utils/assist.py:105-133):
+ * per item the two top-k lists by (|sim| desc, col asc): list 0 = BB_BB | NB_BB, list 1 = BB_NB | NB_NN.
+ * cls[i] = 0 none, 1 bridge record, 2 non-bridge record. kval = (sim, mutu, frac_mutu) fp64. */
+int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const int32_t *suffix_cls,
+                      const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt /*[I][2]*/,
+                      int32_t *kcol /*[I][2][k]*/, double *kval /*[I][2][k][3]*/);
+
+/* Reverse adjacencies of the knn tables, built deterministically in row order:
+ *   mode 0 ATTACH: attach(b) = [x : x non-bridge record, b in NB_BB(x)]   (core/extender.py:48-59,171-173)
+ *   mode 1 SRC   : src(t)    = [s : s bridge, "S:" in s, attach(s) != [], t in keys(knn_BB[s])], "T:" in t
+ *                               (core/extender.py:61-70,174,176); rflag bit0 = (t,s) also joins TGT (:72-81,175-178)
+ *   mode 2 RNN   : rnn(y)    = [x : x non-bridge record, y in NB_NN(x)]    (core/extender.py:142-169 longest_path)
+ * count pass: rcnt[I]; fill pass: ridx / rval (sim, mutu, frac) / rflag at rptr[a] + ... */
+int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
+                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
+                       int32_t *rcnt /*[I]*/);
+int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
+                      const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                      const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
+                      const int64_t *rptr /*[I+1]*/, int32_t *ridx, double *rval /*[n][3]*/, uint8_t *rflag);
+
+/* ExtendSim.sim_extend + get_final_extension (core/extender.py:46-217), start-sharded and streamed:
+ * every path of final_nonjoint_extend / final_joint_extend is enumerated in registers with its
+ * s_p, c_p (calculate_path_confidence, :83-89) and accumulated into (sum s_p c_p, sum c_p) per
+ * (start, end); xsim = ratio (:198-201).  For every start in [start_lo, start_hi):
+ *   n_cand[start] = number of distinct ends, top_end/top_val[start][XMAP_TOPC] = the candidates a
+ *   Generator reads (stable sort by -|xsim|, generator.py:85,109; ties by ascending end index).
+ * If xs_cap > 0 the full candidate lists are also written: xs_off[start], entries (xs_end, xs_val);
+ * needs xs_cap >= total (reported in h_counters[0]; XMAP_ERR_CAPACITY otherwise).  h_counters[1] = paths.
+ * The per-(start,end) sums are kept as double-double (error-free two-sum), so they do not depend on the
+ * enumeration order.  scratch: acc[n_slots][n_items][4] doubles (zero-filled by the caller, left zero),
+ * touched[n_slots][n_items] int32. */
+int xmap_extend_paths(void *stream, int32_t n_items, int top_k, int32_t start_lo, int32_t start_hi,
+                      const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
+                      const uint8_t *flags,
+                      const int64_t *att_ptr, const int32_t *att_idx, const double *att_val,
+                      const int64_t *src_ptr, const int32_t *src_idx, const double *src_val, const uint8_t *src_flag,
+                      const int64_t *rnn_ptr, const int32_t *rnn_idx, const double *rnn_val,
+                      int32_t n_slots, double *acc, int32_t *touched,
+                      int32_t *n_cand, int32_t *top_end, double *top_val,
+                      int64_t xs_cap, int64_t *xs_off, int32_t *xs_end, double *xs_val,
+                      int64_t *d_counters /*[4] device*/, int64_t *h_counters /*[4]*/);
+
+/* ---- stage C: generator_pipeline (utils/assist.py:136-150) ---------------------------------- */
+
+/* Generator.cross_private_mapping / cross_nonprivate_mapping (core/generator.py:27-111) + map_to_dict
+ * (utils/assist.py:210-215).  private: choice = candidate 0 (arg-max |xsim|).  non-private: choice =
+ * top4[picks[start]], picks drawn on the host with np.random.randint in ascending start order.
+ * n_top[start] = min(private ? 10 : 4, n_cand); map_src2tgt[choice] = largest start choosing it, else -1. */
+int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32_t *n_cand, const int32_t *top_end,
+                    const int32_t *picks /* may be NULL */, int32_t *n_top, int32_t *choice, int32_t *map_src2tgt);
+
+/* Generator.build_alterEgo (core/generator.py:113-157).  count pass: cnt_t[u] pass-through rows
+ * ("T:" in iid), cnt_m[u] AlterEgo rows (distinct mapped targets, first-seen order).  fill pass writes
+ * rows [off_t[u]..) and [n_t_total + off_m[u]..): (user, item, rating = mean fp32, time of first row). */
+int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m);
+int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, const int64_t *off_t,
+                       const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item,
+                       float *out_rating, int64_t *out_time);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

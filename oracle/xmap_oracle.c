@@ -313,13 +313,29 @@ static int cmp_u64(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 /* (start,end) -> (sum s_p*c_p, sum c_p) open-addressing map */
-typedef struct { uint64_t *key; double *sc; double *c; uint64_t cap, n; } PMap;
+/* The per-(start,end) sums are accumulated error-free (double-double, Knuth two-sum), i.e. to
+ * ~2^-104: the reference's own result (np.dot through BLAS, np.sum pairwise; extender.py:198-201)
+ * depends on an unknowable summation order at the 1e-16 level, so the canonical value adopted by
+ * oracle and HIP path alike is the correctly rounded exact sum -- order-independent, and items with
+ * identical path multisets tie exactly (tie-break: ascending end index). */
+typedef struct { uint64_t *key; double *sc; double *scl; double *c; double *cl; uint64_t cap, n; } PMap;
+static void dd_add(double *hi, double *lo, double x) {
+    double s = *hi + x;
+    double bb = s - *hi;
+    double e = (*hi - (s - bb)) + (x - bb);
+    e += *lo;
+    double h2 = s + e;
+    *lo = e - (h2 - s);
+    *hi = h2;
+}
 static void pmap_init(PMap *m, uint64_t cap) {
     m->cap = cap; m->n = 0;
     m->key = (uint64_t *)malloc(cap * sizeof(uint64_t));
     memset(m->key, 0xff, cap * sizeof(uint64_t));
     m->sc = (double *)calloc(cap, sizeof(double));
+    m->scl = (double *)calloc(cap, sizeof(double));
     m->c = (double *)calloc(cap, sizeof(double));
+    m->cl = (double *)calloc(cap, sizeof(double));
 }
 static uint64_t pmap_hash(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k; }
 static void pmap_add(PMap *m, uint64_t k, double sc, double c);
@@ -328,16 +344,17 @@ static void pmap_grow(PMap *m) {
     for (uint64_t i = 0; i < m->cap; i++) if (m->key[i] != UINT64_MAX) {
         uint64_t h = pmap_hash(m->key[i]) & (n.cap - 1);
         while (n.key[h] != UINT64_MAX) h = (h + 1) & (n.cap - 1);
-        n.key[h] = m->key[i]; n.sc[h] = m->sc[i]; n.c[h] = m->c[i]; n.n++;
+        n.key[h] = m->key[i]; n.sc[h] = m->sc[i]; n.scl[h] = m->scl[i]; n.c[h] = m->c[i]; n.cl[h] = m->cl[i]; n.n++;
     }
-    free(m->key); free(m->sc); free(m->c); *m = n;
+    free(m->key); free(m->sc); free(m->scl); free(m->c); free(m->cl); *m = n;
 }
 static void pmap_add(PMap *m, uint64_t k, double sc, double c) {
     if (m->n * 2 >= m->cap) pmap_grow(m);
     uint64_t h = pmap_hash(k) & (m->cap - 1);
     while (m->key[h] != UINT64_MAX && m->key[h] != k) h = (h + 1) & (m->cap - 1);
     if (m->key[h] == UINT64_MAX) { m->key[h] = k; m->n++; }
-    m->sc[h] += sc; m->c[h] += c;
+    dd_add(&m->sc[h], &m->scl[h], sc);
+    dd_add(&m->c[h], &m->cl[h], c);
 }
 
 /* edge lookup with the reference's 4-way fallback   core/extender.py:100-113 */
@@ -511,7 +528,7 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
         X->xs_val[q] = 1.0 * M.sc[h] / M.c[h];
     }
     for (int32_t i = 0; i < I; i++) X->xs_ptr[i + 1] += X->xs_ptr[i];
-    free(keys); free(M.key); free(M.sc); free(M.c); free(aptr); free(ax);
+    free(keys); free(M.key); free(M.sc); free(M.scl); free(M.c); free(M.cl); free(aptr); free(ax);
     return X;
 }
 void xo_ext_free(XoExt *X) {

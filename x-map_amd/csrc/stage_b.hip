@@ -1,0 +1,656 @@
+// stage_b.hip -- cross-domain top-k similarity extension (extender_pipeline, reference
+// utils/assist.py:80-133; core/extender.py).
+//
+// Kernels (DESIGN.md section "Stage B"):
+//   k_bridge_flags  : bb[i] = any kept pair of row i whose 2-char prefixes differ        (HBM-bound, one pass over D')
+//   k_knn_classify  : per row, chunked bitonic sort in LDS by (|sim| desc, col asc) and the two
+//                     filtered top-k lists of find_knn_items                              (HBM-bound, one pass over D')
+//   k_reverse       : reverse adjacencies (attach / src / rnn) built in row order with an O(1)
+//                     membership test against the k-th entry of the neighbour's list       (HBM-bound, one pass over D')
+//   k_paths         : streamed path enumeration, one wave per start item, fp64 (s_p, c_p) in
+//                     registers, per-start accumulators, fused top-10                      (ALU / latency bound)
+#include "common.h"
+
+namespace xmap {
+
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_bridge_flags(int I, const long long *row_ptr, const int *col,
+                                                      const int *prefix_cls, uint8_t *bb) {
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= I) return;
+    int lane = lane_id();
+    long long lo = row_ptr[i], hi = row_ptr[i + 1];
+    int pi = prefix_cls[i];
+    int found = 0;
+    for (long long b = lo; b < hi && !found; b += 64) {
+        long long p = b + lane;
+        int f = (p < hi) && (prefix_cls[col[p]] != pi);
+        found = __ballot(f) != 0ull;
+    }
+    if (lane == 0) bb[i] = (uint8_t)found;
+}
+
+// =============================================================================================
+constexpr int K_THREADS = 256;
+constexpr int K_CH = 2048;  // entries sorted per chunk (32 KB of LDS)
+
+__device__ __forceinline__ bool before(unsigned long long ka, int ca, unsigned long long kb, int cb) {
+    return (ka > kb) || (ka == kb && ca < cb);
+}
+
+// exclusive scan of one long long per thread across the block (256 threads)
+__device__ __forceinline__ long long block_scan_ll(long long v, long long *total, long long *smem) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < K_THREADS / 64; k++) {
+        long long s = smem[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+struct KnnArgs {
+    int I, k;
+    const long long *row_ptr;
+    const int *col;
+    const double *sim;
+    const int *mutu;
+    const int *nij;
+    const double *info;
+    const uint8_t *bb;
+    const int *suffix_cls;
+    const uint32_t *contains_mask;
+    uint8_t *cls;
+    int *kcnt;
+    int *kcol;
+    double *kval;
+};
+
+__global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
+    __shared__ unsigned long long skey[K_CH];
+    __shared__ int scol[K_CH];
+    __shared__ int spos[K_CH];
+    __shared__ long long sscan[4];
+
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const long long lo = A.row_ptr[i];
+    const int n = (int)(A.row_ptr[i + 1] - lo);
+    const int k = A.k;
+    if (n == 0) {
+        if (tid == 0) {
+            A.cls[i] = 0;
+            A.kcnt[(size_t)i * 2] = 0;
+            A.kcnt[(size_t)i * 2 + 1] = 0;
+        }
+        return;
+    }
+    const bool isbb = A.bb[i] != 0;
+    const int sc = A.suffix_cls[i];
+    int nc = 0, consumed = 0;
+    for (;;) {
+        const int take = (K_CH - nc) < (n - consumed) ? (K_CH - nc) : (n - consumed);
+        for (int t = tid; t < take; t += K_THREADS) {
+            int p = consumed + t;
+            double s = A.sim[lo + p];
+            skey[nc + t] = (unsigned long long)__double_as_longlong(fabs(s));
+            scol[nc + t] = A.col[lo + p];
+            spos[nc + t] = p;
+        }
+        const int total = nc + take;
+        int N = 2;
+        while (N < total) N <<= 1;
+        for (int t = total + tid; t < N; t += K_THREADS) {
+            skey[t] = 0ull;
+            scol[t] = 0x7fffffff;
+            spos[t] = -1;
+        }
+        __syncthreads();
+        // bitonic sort by (|sim| desc, col asc); pads (|sim| = 0) end up last
+        for (int k2 = 2; k2 <= N; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (N >> 1); t += K_THREADS) {
+                    int a = 2 * t - (t & (j - 1));
+                    int b = a + j;
+                    bool up = (a & k2) == 0;
+                    unsigned long long ka = skey[a], kb = skey[b];
+                    int ca = scol[a], cb = scol[b];
+                    bool sw = up ? before(kb, cb, ka, ca) : before(ka, ca, kb, cb);
+                    if (sw) {
+                        skey[a] = kb; skey[b] = ka;
+                        scol[a] = cb; scol[b] = ca;
+                        int pa = spos[a], pb = spos[b];
+                        spos[a] = pb; spos[b] = pa;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // class predicates, ranks in sorted order
+        const int per = (N + K_THREADS - 1) / K_THREADS;
+        const int s0 = tid * per;
+        int cA = 0, cB = 0;
+        for (int t = s0; t < s0 + per && t < total; t++) {
+            int c = scol[t];
+            bool pa, pb;
+            if (isbb) {
+                bool has = (A.contains_mask[c] >> sc) & 1u;  // domain_label in pair[0]
+                pa = !has; pb = has;
+            } else {
+                pa = A.bb[c] != 0; pb = true;                 // NB_NN keeps every neighbour
+            }
+            cA += pa; cB += pb;
+        }
+        long long tot;
+        long long ex = block_scan_ll(((long long)cB << 32) | (unsigned)cA, &tot, sscan);
+        int rA = (int)(ex & 0xffffffffll), rB = (int)(ex >> 32);
+        const int totA = (int)(tot & 0xffffffffll), totB = (int)(tot >> 32);
+        consumed += take;
+        const bool last = consumed >= n;
+        if (last) {
+            for (int t = s0; t < s0 + per && t < total; t++) {
+                int c = scol[t];
+                bool pa, pb;
+                if (isbb) {
+                    bool has = (A.contains_mask[c] >> sc) & 1u;
+                    pa = !has; pb = has;
+                } else {
+                    pa = A.bb[c] != 0; pb = true;
+                }
+                long long p = lo + spos[t];
+                if ((pa && rA < k) || (pb && rB < k)) {
+                    double sv = A.sim[p];
+                    double mu = (double)A.mutu[p];
+                    double fr = 1.0 * mu / (A.info[(size_t)i * 4 + 3] + A.info[(size_t)c * 4 + 3] - (double)A.nij[p]);
+                    if (pa && rA < k) {
+                        size_t o = ((size_t)i * 2 + 0) * k + rA;
+                        A.kcol[o] = c; A.kval[o * 3] = sv; A.kval[o * 3 + 1] = mu; A.kval[o * 3 + 2] = fr;
+                    }
+                    if (pb && rB < k) {
+                        size_t o = ((size_t)i * 2 + 1) * k + rB;
+                        A.kcol[o] = c; A.kval[o * 3] = sv; A.kval[o * 3 + 1] = mu; A.kval[o * 3 + 2] = fr;
+                    }
+                }
+                rA += pa; rB += pb;
+            }
+            if (tid == 0) {
+                int nA = totA < k ? totA : k, nB = totB < k ? totB : k;
+                uint8_t c = isbb ? 1 : (nA > 0 ? 2 : 0);  // no bridge neighbour -> dropped (extender.py:39)
+                A.cls[i] = c;
+                A.kcnt[(size_t)i * 2] = c ? nA : 0;
+                A.kcnt[(size_t)i * 2 + 1] = c ? nB : 0;
+            }
+            return;
+        }
+        // carry the selected <= 2k entries to the front (sorted order kept), then take the next chunk
+        unsigned long long rk[K_CH / K_THREADS];
+        int rc[K_CH / K_THREADS], rp[K_CH / K_THREADS];
+        int nk = 0;
+        for (int t = s0; t < s0 + per && t < total; t++) {
+            int c = scol[t];
+            bool pa, pb;
+            if (isbb) {
+                bool has = (A.contains_mask[c] >> sc) & 1u;
+                pa = !has; pb = has;
+            } else {
+                pa = A.bb[c] != 0; pb = true;
+            }
+            if ((pa && rA < k) || (pb && rB < k)) { rk[nk] = skey[t]; rc[nk] = c; rp[nk] = spos[t]; nk++; }
+            rA += pa; rB += pb;
+        }
+        long long tk;
+        long long ek = block_scan_ll((long long)nk, &tk, sscan);
+        for (int q = 0; q < nk; q++) {
+            skey[ek + q] = rk[q]; scol[ek + q] = rc[q]; spos[ek + q] = rp[q];
+        }
+        nc = (int)tk;
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// membership of item a in list l of neighbour b, given |sim(a,b)| (bit-symmetric by construction):
+// a is in the list iff it passes the list's class predicate and sorts at or before the list's
+// last entry in the order (|sim| desc, col asc) -- or the list is not full.
+struct RevArgs {
+    int I, k, mode;
+    const long long *row_ptr;
+    const int *col;
+    const double *sim;
+    const int *mutu;
+    const int *nij;
+    const double *info;
+    const uint8_t *bb;
+    const uint8_t *cls;
+    const int *kcnt;
+    const int *kcol;
+    const double *kval;
+    const int *suffix_cls;
+    const uint32_t *contains_mask;
+    const uint8_t *flags;
+    const long long *attach_ptr;
+    int *rcnt;
+    const long long *rptr;
+    int *ridx;
+    double *rval;
+    uint8_t *rflag;
+};
+
+__device__ __forceinline__ bool in_list(const RevArgs &A, int b, int l, int a, double abs_sim) {
+    int c = A.kcnt[(size_t)b * 2 + l];
+    if (c == 0) return false;
+    bool pred;
+    if (A.cls[b] == 1) {
+        bool has = (A.contains_mask[a] >> A.suffix_cls[b]) & 1u;
+        pred = (l == 0) ? !has : has;
+    } else {
+        pred = (l == 0) ? (A.bb[a] != 0) : true;
+    }
+    if (!pred) return false;
+    if (c < A.k) return true;
+    size_t o = ((size_t)b * 2 + l) * A.k + (c - 1);
+    double la = fabs(A.kval[o * 3]);
+    return (abs_sim > la) || (abs_sim == la && a <= A.kcol[o]);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
+    int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= A.I) return;
+    int lane = lane_id();
+    long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
+    bool row_ok = true;
+    if (A.mode == 1) row_ok = (A.flags[a] & 2) != 0;  // "T:" in t
+    long long out = FILL ? A.rptr[a] : 0;
+    int total = 0;
+    if (row_ok)
+        for (long long base = lo; base < hi; base += 64) {
+            long long p = base + lane;
+            bool ok = false;
+            int b = 0;
+            double sv = 0.0;
+            uint8_t fl = 0;
+            if (p < hi) {
+                b = A.col[p];
+                sv = A.sim[p];
+                double ab = fabs(sv);
+                int cb = A.cls[b];
+                if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
+                    ok = (cb == 2) && in_list(A, b, 0, a, ab);
+                } else if (A.mode == 1) {    // src(t = a): s = b
+                    ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
+                         (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
+                    if (ok) {
+                        bool joint = (A.cls[a] == 1) && (A.attach_ptr[a + 1] > A.attach_ptr[a]) &&
+                                     (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
+                        fl = joint ? 1 : 0;
+                    }
+                } else {                     // rnn(y = a): x = b non-bridge record with a in NB_NN(x)
+                    ok = (cb == 2) && in_list(A, b, 1, a, ab);
+                }
+            }
+            unsigned long long m = __ballot(ok);
+            if (FILL && ok) {
+                long long o = out + __popcll(m & lanemask_lt());
+                double mu = (double)A.mutu[p];
+                A.ridx[o] = b;
+                A.rval[o * 3] = sv;
+                A.rval[o * 3 + 1] = mu;
+                A.rval[o * 3 + 2] = 1.0 * mu / (A.info[(size_t)a * 4 + 3] + A.info[(size_t)b * 4 + 3] - (double)A.nij[p]);
+                if (A.rflag) A.rflag[o] = fl;
+            }
+            int c = __popcll(m);
+            out += c;
+            total += c;
+        }
+    if (!FILL && lane == 0) A.rcnt[a] = total;
+}
+
+// =============================================================================================
+struct PathArgs {
+    int I, k;
+    int start_lo, start_hi;
+    const uint8_t *cls;
+    const int *kcnt;
+    const int *kcol;
+    const double *kval;
+    const uint8_t *flags;
+    const long long *att_ptr; const int *att_idx; const double *att_val;
+    const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
+    const long long *rnn_ptr; const int *rnn_idx; const double *rnn_val;
+    int n_slots;
+    double *acc; int *touched;   // acc: [n_slots][I][4] = double-double (sum s_p c_p), double-double (sum c_p)
+    int *n_cand; int *top_end; double *top_val;
+    long long xs_cap; long long *xs_off; int *xs_end; double *xs_val;
+    unsigned long long *counters;  // [0] total candidates, [1] paths, [2] work cursor, [3] xs cursor
+};
+
+struct Carry { double sm, mu, c; };  // sum sim*mutu, sum mutu, prod frac_mutu along the path so far
+
+__device__ __forceinline__ Carry first_edge(double sim, double mutu, double frac) {
+    Carry r; r.sm = sim * mutu; r.mu = mutu; r.c = frac; return r;   // python sum(): 0 + x == x
+}
+__device__ __forceinline__ Carry add_edge(Carry a, double sim, double mutu, double frac) {
+    Carry r; r.sm = a.sm + sim * mutu; r.mu = a.mu + mutu; r.c = a.c * frac; return r;
+}
+
+// Error-free accumulation (Knuth two-sum, double-double running sums): the per-(start,end) sums become
+// independent of the order in which paths are enumerated (to ~2^-104), so items with identical
+// path multisets tie exactly and the tie-break (ascending end index) is well defined.
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double x) {
+    double s = hi + x;
+    double bb = s - hi;
+    double e = (hi - (s - bb)) + (x - bb);
+    e += lo;
+    double h2 = s + e;
+    lo = e - (h2 - s);
+    hi = h2;
+}
+
+struct WaveAcc {
+    double *acc; int *touched; int nt; unsigned long long paths;
+    __device__ __forceinline__ void add(bool active, int end, Carry p) {
+        bool first = false;
+        if (active) {
+            double sp = (p.mu != 0.0) ? 1.0 * p.sm / p.mu : 0.0;   // calculate_path_confidence (extender.py:83-89)
+            double *a = acc + (size_t)end * 4;
+            double s_hi = a[0], s_lo = a[1], c_hi = a[2], c_lo = a[3];
+            first = (c_hi == 0.0);
+            dd_add(s_hi, s_lo, sp * p.c);
+            dd_add(c_hi, c_lo, p.c);
+            a[0] = s_hi; a[1] = s_lo; a[2] = c_hi; a[3] = c_lo;
+        }
+        unsigned long long m = __ballot(first);
+        if (first) touched[nt + __popcll(m & lanemask_lt())] = end;
+        nt += __popcll(m);
+        paths += __popcll(__ballot(active));
+    }
+};
+
+// tails of one (t,s) after edge (t,s): end s is accumulated by the caller (vector step over s);
+// here: for x in attach(s): end x, then end y for y in NN(x)         (extender.py:134-138 / :154-158)
+__device__ __forceinline__ void tails(const PathArgs &A, WaveAcc &W, int s, Carry c_ts) {
+    const int lane = lane_id();
+    const int k = A.k;
+    long long a0 = A.att_ptr[s], a1 = A.att_ptr[s + 1];
+    for (long long ap = a0; ap < a1; ap++) {
+        const int x = A.att_idx[ap];
+        const Carry c_sx = add_edge(c_ts, A.att_val[ap * 3], A.att_val[ap * 3 + 1], A.att_val[ap * 3 + 2]);
+        const int nn = A.kcnt[(size_t)x * 2 + 1];
+        for (int b = 0; b < nn + 1; b += 64) {
+            int idx = b + lane;
+            bool act = idx < nn + 1;
+            int end = x;
+            Carry c = c_sx;
+            if (act && idx > 0) {
+                size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
+                end = A.kcol[o];
+                c = add_edge(c_sx, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+            }
+            W.add(act, end, c);
+        }
+    }
+}
+
+// all (t,s) of src(t) behind a given head carry (head_len = number of edges in front of (t,s))
+__device__ __forceinline__ void through_t(const PathArgs &A, WaveAcc &W, int t, bool has_head, Carry head) {
+    const int lane = lane_id();
+    long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
+    for (long long base = s0; base < s1; base += 64) {
+        long long p = base + lane;
+        bool act = p < s1;
+        int s = 0;
+        Carry c; c.sm = 0; c.mu = 0; c.c = 0;
+        if (act) {
+            if (has_head && !(A.src_flag[p] & 1)) act = false;  // joint paths need (t,s) in TGT as well
+        }
+        if (act) {
+            s = A.src_idx[p];
+            double sv = A.src_val[p * 3], mu = A.src_val[p * 3 + 1], fr = A.src_val[p * 3 + 2];
+            c = has_head ? add_edge(head, sv, mu, fr) : first_edge(sv, mu, fr);
+        }
+        W.add(act, s, c);  // path ... -> t -> s
+        unsigned long long m = __ballot(act);
+        while (m) {
+            int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int sb = rl32(s, l);
+            Carry cb;
+            cb.sm = rld(c.sm, l); cb.mu = rld(c.mu, l); cb.c = rld(c.c, l);
+            tails(A, W, sb, cb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_paths(PathArgs A) {
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.n_slots) return;
+    const int lane = lane_id();
+    const int k = A.k;
+    WaveAcc W;
+    W.acc = A.acc + (size_t)slot * A.I * 4;
+    W.touched = A.touched + (size_t)slot * A.I;
+    W.paths = 0;
+    unsigned long long cand_total = 0;
+    for (;;) {
+        int s_ = 0;
+        if (lane == 0) s_ = (int)atomicAdd(&A.counters[2], 1ull);
+        const int start = A.start_lo + uniform(s_);
+        if (start >= A.start_hi) break;  // every wave reaches this exit: the cursor only grows
+        W.nt = 0;
+        // role T: start = t (final_nonjoint_extend on every SRC record, extender.py:124-140,:180)
+        if (A.flags[start] & 2) {
+            Carry none; none.sm = 0; none.mu = 0; none.c = 0;
+            through_t(A, W, start, false, none);
+        }
+        // role X': start = x' in attach(t) (target_path, extender.py:160-163)
+        if (A.cls[start] == 2) {
+            int nb = A.kcnt[(size_t)start * 2];
+            for (int q = 0; q < nb; q++) {
+                size_t o = ((size_t)start * 2) * k + q;
+                int t = A.kcol[o];
+                if (!(A.flags[t] & 2)) continue;  // BB_other_intra_target keeps "T:" bridges only (:175)
+                Carry h = first_edge(A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+                through_t(A, W, t, true, h);
+            }
+        }
+        // role Y': start = y' in NN(x'), x' in attach(t) (longest_path, extender.py:164-167)
+        {
+            long long r0 = A.rnn_ptr[start], r1 = A.rnn_ptr[start + 1];
+            for (long long rp = r0; rp < r1; rp++) {
+                int xp = A.rnn_idx[rp];
+                Carry h0 = first_edge(A.rnn_val[rp * 3], A.rnn_val[rp * 3 + 1], A.rnn_val[rp * 3 + 2]);
+                int nb = A.kcnt[(size_t)xp * 2];
+                for (int q = 0; q < nb; q++) {
+                    size_t o = ((size_t)xp * 2) * k + q;
+                    int t = A.kcol[o];
+                    if (!(A.flags[t] & 2)) continue;
+                    Carry h = add_edge(h0, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+                    through_t(A, W, t, true, h);
+                }
+            }
+        }
+        // finalise: xsim = sum(s_p c_p) / sum(c_p) (get_sim, extender.py:198-201), kept in sc[]
+        const int nt = W.nt;
+        for (int b = lane; b < nt; b += 64) {
+            int e = W.touched[b];
+            W.acc[(size_t)e * 4] = 1.0 * W.acc[(size_t)e * 4] / W.acc[(size_t)e * 4 + 2];
+        }
+        // fused top-XMAP_TOPC by (|xsim| desc, end asc): all a Generator reads (generator.py:85,109)
+        unsigned long long pk = 0xFFFFFFFFFFFFFFFFull;  // previous best key; first round accepts all
+        int pe = -1;
+        int nsel = nt < XMAP_TOPC ? nt : XMAP_TOPC;
+        for (int r = 0; r < nsel; r++) {
+            unsigned long long bk = 0;
+            int be = 0x7fffffff;
+            bool have = false;
+            for (int b = lane; b < nt; b += 64) {
+                int e = W.touched[b];
+                unsigned long long key = (unsigned long long)__double_as_longlong(fabs(W.acc[(size_t)e * 4]));
+                bool after_prev = (r == 0) || (key < pk) || (key == pk && e > pe);
+                if (after_prev && (!have || key > bk || (key == bk && e < be))) { bk = key; be = e; have = true; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                unsigned long long ok = __shfl_xor(bk, m, 64);
+                int oe = __shfl_xor(be, m, 64);
+                int oh = __shfl_xor((int)have, m, 64);
+                if (oh && (!have || ok > bk || (ok == bk && oe < be))) { bk = ok; be = oe; have = true; }
+            }
+            pk = bk; pe = be;
+            if (lane == 0) {
+                A.top_end[(size_t)start * XMAP_TOPC + r] = be;
+                A.top_val[(size_t)start * XMAP_TOPC + r] = W.acc[(size_t)be * 4];
+            }
+        }
+        if (lane == 0) A.n_cand[start] = nt;
+        cand_total += nt;
+        // optional full candidate lists (extender_pipeline's RDD) via a cursor in the caller's buffer
+        if (A.xs_cap > 0 && nt > 0) {
+            unsigned long long off = 0;
+            if (lane == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
+            off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
+            if ((long long)(off + nt) <= A.xs_cap) {
+                for (int b = lane; b < nt; b += 64) {
+                    int e = W.touched[b];
+                    A.xs_end[off + b] = e;
+                    A.xs_val[off + b] = W.acc[(size_t)e * 4];
+                }
+                if (lane == 0) A.xs_off[start] = (long long)off;
+            } else if (lane == 0) {
+                A.xs_off[start] = -1;
+            }
+        }
+        for (int b = lane; b < nt; b += 64) {
+            int e = W.touched[b];
+            double *a = W.acc + (size_t)e * 4;
+            a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], cand_total);
+        atomicAdd(&A.counters[1], W.paths);
+    }
+}
+
+}  // namespace xmap
+
+using namespace xmap;
+
+extern "C" {
+
+int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls, uint8_t *bb) {
+    XM_ARG(S && prefix_cls && bb);
+    if (S->n_items == 0) return XMAP_OK;
+    k_bridge_flags<<<dim3((unsigned)((S->n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        S->n_items, (const long long *)S->row_ptr, S->col, prefix_cls, bb);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const int32_t *suffix_cls,
+                      const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt, int32_t *kcol, double *kval) {
+    XM_ARG(S && bb && suffix_cls && contains_mask && cls && kcnt && kcol && kval);
+    XM_ARG(top_k >= 1 && 2 * top_k <= K_CH / 2);
+    if (S->n_items == 0) return XMAP_OK;
+    KnnArgs A;
+    A.I = S->n_items; A.k = top_k;
+    A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
+    A.info = S->info; A.bb = bb; A.suffix_cls = suffix_cls; A.contains_mask = contains_mask;
+    A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
+    k_knn_classify<<<dim3((unsigned)S->n_items), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, int top_k, const uint8_t *bb,
+                          const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
+                          const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
+                          const int64_t *attach_ptr, int32_t *rcnt, const int64_t *rptr, int32_t *ridx, double *rval,
+                          uint8_t *rflag) {
+    XM_ARG(S && bb && cls && kcnt && kcol && kval && suffix_cls && contains_mask && flags);
+    XM_ARG(mode >= 0 && mode <= 2);
+    XM_ARG(mode != 1 || attach_ptr);
+    if (S->n_items == 0) return XMAP_OK;
+    RevArgs A;
+    A.I = S->n_items; A.k = top_k; A.mode = mode;
+    A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
+    A.info = S->info; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
+    A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
+    A.attach_ptr = (const long long *)attach_ptr;
+    A.rcnt = rcnt; A.rptr = (const long long *)rptr; A.ridx = ridx; A.rval = rval; A.rflag = rflag;
+    dim3 grid((unsigned)((S->n_items + 3) / 4)), block(256);
+    if (fill) k_reverse<true><<<grid, block, 0, (hipStream_t)stream>>>(A);
+    else k_reverse<false><<<grid, block, 0, (hipStream_t)stream>>>(A);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
+                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, int32_t *rcnt) {
+    XM_ARG(rcnt);
+    return reverse_common(stream, false, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
+                          attach_ptr, rcnt, nullptr, nullptr, nullptr, nullptr);
+}
+
+int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
+                      const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                      const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
+                      const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag) {
+    XM_ARG(rptr && ridx && rval);
+    return reverse_common(stream, true, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
+                          attach_ptr, nullptr, rptr, ridx, rval, rflag);
+}
+
+int xmap_extend_paths(void *stream, int32_t n_items, int top_k, int32_t start_lo, int32_t start_hi, const uint8_t *cls,
+                      const int32_t *kcnt, const int32_t *kcol, const double *kval, const uint8_t *flags,
+                      const int64_t *att_ptr, const int32_t *att_idx, const double *att_val, const int64_t *src_ptr,
+                      const int32_t *src_idx, const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr,
+                      const int32_t *rnn_idx, const double *rnn_val, int32_t n_slots, double *acc,
+                      int32_t *touched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && rnn_ptr);
+    XM_ARG(acc && touched && n_cand && top_end && top_val && d_counters);
+    XM_ARG(n_slots > 0 && start_lo >= 0 && start_hi <= n_items);
+    XM_ARG(xs_cap == 0 || (xs_off && xs_end && xs_val));
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+    if (start_hi > start_lo) {
+        PathArgs A;
+        A.I = n_items; A.k = top_k; A.start_lo = start_lo; A.start_hi = start_hi;
+        A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval; A.flags = flags;
+        A.att_ptr = (const long long *)att_ptr; A.att_idx = att_idx; A.att_val = att_val;
+        A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
+        A.rnn_ptr = (const long long *)rnn_ptr; A.rnn_idx = rnn_idx; A.rnn_val = rnn_val;
+        A.n_slots = n_slots; A.acc = acc; A.touched = touched;
+        A.n_cand = n_cand; A.top_end = top_end; A.top_val = top_val;
+        A.xs_cap = xs_cap; A.xs_off = (long long *)xs_off; A.xs_end = xs_end; A.xs_val = xs_val;
+        A.counters = (unsigned long long *)d_counters;
+        k_paths<<<dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st>>>(A);
+        XM_LAUNCH_CHECK();
+    }
+    if (h_counters) {
+        XM_HIP(hipMemcpyAsync(h_counters, d_counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        XM_HIP(hipStreamSynchronize(st));
+        if (xs_cap > 0 && h_counters[0] > xs_cap) {
+            set_error("candidate buffer too small: need %lld entries, have %lld", (long long)h_counters[0],
+                      (long long)xs_cap);
+            return XMAP_ERR_CAPACITY;
+        }
+    }
+    return XMAP_OK;
+}
+}

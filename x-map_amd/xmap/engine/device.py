@@ -1,0 +1,321 @@
+"""Device engine: drives the three stages of the hot path through the C ABI (include/xmap_hip.h).
+
+torch is used only as the container for HBM buffers and for the current HIP stream; every
+computation on the path is a kernel of libxmap_hip.so.  All results stay resident in HBM as
+torch tensors until a caller asks for host copies.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hipabi as abi
+
+lib = abi.lib
+vp, i32, i64, check = abi.vp, abi.i32, abi.i64, abi.check
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class DeviceRatings(object):
+    """trainRDD in index space, resident in HBM: CSR by user (trainRDD / profile order) and CSC by
+    item (raters ascending).  The CSC is laid out once on the host at upload time (stable sort), like
+    the id dictionary; neither is part of a timed pass."""
+
+    def __init__(self, user_ptr, item, rating, time, n_items, attrs, device="cuda:0"):
+        self.device = torch.device(device)
+        user_ptr = np.ascontiguousarray(user_ptr, np.int64)
+        item = np.ascontiguousarray(item, np.int32)
+        rating = np.ascontiguousarray(rating, np.float32)
+        time = np.ascontiguousarray(time, np.int64)
+        self.n_users = len(user_ptr) - 1
+        self.n_items = int(n_items)
+        self.nnz = int(user_ptr[-1])
+        if self.nnz >= 2 ** 31 - 1:
+            raise ValueError("nnz must fit int32")
+        if self.nnz and (item.min() < 0 or item.max() >= self.n_items):
+            raise ValueError("item index out of range")
+        users = np.repeat(np.arange(self.n_users, dtype=np.int32), np.diff(user_ptr))
+        order = np.argsort(item, kind="stable")
+        item_ptr = np.zeros(self.n_items + 1, np.int64)
+        np.cumsum(np.bincount(item, minlength=self.n_items), out=item_ptr[1:])
+        prefix_cls, suffix_cls, contains_mask, flags = attrs
+        d = self.device
+        t = torch.from_numpy
+        self.user_ptr = t(user_ptr).to(d)
+        self.user_item = t(item).to(d)
+        self.user_rating = t(rating).to(d)
+        self.user_time = t(time).to(d)
+        self.item_ptr = t(item_ptr).to(d)
+        self.item_user = t(np.ascontiguousarray(users[order])).to(d)
+        self.item_rating = t(np.ascontiguousarray(rating[order])).to(d)
+        self.prefix_cls = t(np.ascontiguousarray(prefix_cls, np.int32)).to(d)
+        self.suffix_cls = t(np.ascontiguousarray(suffix_cls, np.int32)).to(d)
+        self.contains_mask = t(np.ascontiguousarray(contains_mask, np.uint32).view(np.int32)).to(d)
+        self.flags = t(np.ascontiguousarray(flags, np.uint8)).to(d)
+        self.c = abi.Ratings(self.n_users, self.n_items, self.nnz,
+                             self.user_ptr.data_ptr(), self.user_item.data_ptr(), self.user_rating.data_ptr(),
+                             self.user_time.data_ptr(), self.item_ptr.data_ptr(), self.item_user.data_ptr(),
+                             self.item_rating.data_ptr(), self.prefix_cls.data_ptr(), self.suffix_cls.data_ptr(),
+                             self.contains_mask.data_ptr(), self.flags.data_ptr())
+
+    def bytes_resident(self):
+        return sum(x.numel() * x.element_size() for x in (
+            self.user_ptr, self.user_item, self.user_rating, self.user_time, self.item_ptr,
+            self.item_user, self.item_rating))
+
+
+class SimResult(object):
+    """Stage-A output in HBM: CSR (row_ptr, col, sim fp64, mutu, nij) + item/user info."""
+    pass
+
+
+class ExtResult(object):
+    pass
+
+
+class GenResult(object):
+    pass
+
+
+class Engine(object):
+    def __init__(self, ratings):
+        self.R = ratings
+        self.dev = ratings.device
+
+    def _empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.dev)
+
+    def _zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.dev)
+
+    # ------------------------------------------------------------------ stage A
+    def stats(self):
+        """A2 + A3: user info, item info and the flag-packed index copies."""
+        R = self.R
+        st = _stream(self.dev)
+        u_avg = self._empty(max(R.n_users, 1), torch.float64)
+        u_norm = self._empty(max(R.n_users, 1), torch.float64)
+        check(lib.xmap_user_stats(st, C.byref(R.c), vp(u_avg), vp(u_norm)))
+        info = self._zeros((max(R.n_items, 1), 4), torch.float64)
+        ua_item = self._empty(max(R.nnz, 1), torch.int32)
+        ia_user = self._empty(max(R.nnz, 1), torch.int32)
+        check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(ua_item), vp(ia_user)))
+        return u_avg, u_norm, info, ua_item, ia_user
+
+    def item_sim(self, method, cap, slot_target=640, item_range=None):
+        """baseliner_calculate_sim_pipeline for the rows in item_range (default: all)."""
+        R = self.R
+        st = _stream(self.dev)
+        m = abi.METHODS[method] if isinstance(method, str) else int(method)
+        u_avg, u_norm, info, ua_item, ia_user = self.stats()
+        I = R.n_items
+        while True:
+            Q = self._zeros(max(I, 1), torch.int32)
+            unit_ptr = self._zeros(I + 1, torch.int64)
+            n_units, contrib = C.c_int64(0), C.c_int64(0)
+            check(lib.xmap_sim_plan(st, C.byref(R.c), i32(slot_target), vp(Q), vp(unit_ptr),
+                                    C.byref(n_units), C.byref(contrib)))
+            nu = int(n_units.value)
+            unit_item = self._empty(max(nu, 1), torch.int32)
+            unit_q = self._empty(max(nu, 1), torch.int32)
+            check(lib.xmap_sim_units(st, i32(I), vp(Q), vp(unit_ptr), vp(unit_item), vp(unit_q)))
+            if item_range is None:
+                lo, hi = 0, nu
+            else:
+                ends = unit_ptr[[int(item_range[0]), int(item_range[1])]].tolist()
+                lo, hi = int(ends[0]), int(ends[1])
+            unit_cnt = self._zeros(max(nu, 1), torch.int32)
+            d_cnt = self._zeros(4, torch.int64)
+            h_cnt = (C.c_int64 * 4)()
+            rc = lib.xmap_sim_count(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
+                                    vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi), vp(unit_cnt), vp(d_cnt), h_cnt)
+            if rc == abi.ERR_OVERFLOW and slot_target > 32:
+                slot_target //= 2
+                continue
+            check(rc)
+            break
+        kept, evaluated = int(h_cnt[0]), int(h_cnt[1])
+        unit_off = self._zeros(nu + 1, torch.int64)
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(unit_cnt), vp(unit_off), i64(nu), None))
+        row_ptr = self._empty(I + 1, torch.int64)
+        check(lib.xmap_sim_row_ptr(st, i32(I), vp(unit_ptr), vp(unit_off), vp(row_ptr)))
+        col = self._empty(max(kept, 1), torch.int32)
+        sim = self._empty(max(kept, 1), torch.float64)
+        mutu = self._empty(max(kept, 1), torch.int32)
+        nij = self._empty(max(kept, 1), torch.int32)
+        check(lib.xmap_sim_fill(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
+                                vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi), vp(unit_off),
+                                vp(col), vp(sim), vp(mutu), vp(nij)))
+        S = SimResult()
+        S.method, S.cap, S.n_items = m, int(cap), I
+        S.u_avg, S.u_norm, S.info = u_avg, u_norm, info
+        S.row_ptr, S.col, S.sim, S.mutu, S.nij = row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept]
+        S.n_kept, S.n_eval, S.n_contrib, S.n_units = kept, evaluated, int(contrib.value), hi - lo
+        S.slot_target = slot_target
+        S.c = abi.Sim(I, row_ptr.data_ptr(), col.data_ptr(), sim.data_ptr(), mutu.data_ptr(), nij.data_ptr(),
+                      info.data_ptr())
+        S._keep = (col, sim, mutu, nij)
+        return S
+
+    def sim_from_host(self, row_ptr, col, sim, mutu, nij, info):
+        """Wrap a host-side stage-A result (e.g. a canonically re-fed RDD) as a device SimResult."""
+        d = self.dev
+        S = SimResult()
+        S.n_items = self.R.n_items
+        S.row_ptr = torch.from_numpy(np.ascontiguousarray(row_ptr, np.int64)).to(d)
+        n = int(row_ptr[-1])
+        pad = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a if n else np.zeros(1), dt)).to(d)
+        col_, sim_, mutu_, nij_ = pad(col, np.int32), pad(sim, np.float64), pad(mutu, np.int32), pad(nij, np.int32)
+        S.col, S.sim, S.mutu, S.nij = col_[:n], sim_[:n], mutu_[:n], nij_[:n]
+        S.info = torch.from_numpy(np.ascontiguousarray(info, np.float64)).to(d)
+        S.n_kept = n
+        S.c = abi.Sim(S.n_items, S.row_ptr.data_ptr(), col_.data_ptr(), sim_.data_ptr(), mutu_.data_ptr(),
+                      nij_.data_ptr(), S.info.data_ptr())
+        S._keep = (col_, sim_, mutu_, nij_)
+        return S
+
+    # ------------------------------------------------------------------ stage B
+    def knn(self, S, top_k):
+        """B1-B4: bridge flags + classified top-k lists."""
+        R = self.R
+        st = _stream(self.dev)
+        I, k = R.n_items, int(top_k)
+        E = ExtResult()
+        E.k = k
+        E.bb = self._zeros(max(I, 1), torch.uint8)
+        check(lib.xmap_bridge_flags(st, C.byref(S.c), vp(R.prefix_cls), vp(E.bb)))
+        E.cls = self._zeros(max(I, 1), torch.uint8)
+        E.kcnt = self._zeros((max(I, 1), 2), torch.int32)
+        E.kcol = self._zeros((max(I, 1), 2, k), torch.int32)
+        E.kval = self._zeros((max(I, 1), 2, k, 3), torch.float64)
+        check(lib.xmap_knn_classify(st, C.byref(S.c), k, vp(E.bb), vp(R.suffix_cls), vp(R.contains_mask),
+                                    vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval)))
+        return E
+
+    def _reverse(self, S, E, mode, attach_ptr):
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        rcnt = self._zeros(max(I, 1), torch.int32)
+        args = (C.byref(S.c), mode, E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval),
+                vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(attach_ptr))
+        check(lib.xmap_reverse_count(st, *args, vp(rcnt)))
+        rptr = self._zeros(I + 1, torch.int64)
+        tot = C.c_int64(0)
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rcnt), vp(rptr), i64(I), C.byref(tot)))
+        n = int(tot.value)
+        ridx = self._empty(max(n, 1), torch.int32)
+        rval = self._empty((max(n, 1), 3), torch.float64)
+        rflag = self._zeros(max(n, 1), torch.uint8)
+        check(lib.xmap_reverse_fill(st, *args, vp(rptr), vp(ridx), vp(rval), vp(rflag)))
+        return rptr, ridx, rval, rflag, n
+
+    def extend(self, S, top_k, full=False, start_range=None, n_slots=None, xs_cap=None):
+        """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
+        R = self.R
+        I = R.n_items
+        E = self.knn(S, top_k)
+        st = _stream(self.dev)
+        E.att = self._reverse(S, E, 0, None)
+        E.src = self._reverse(S, E, 1, E.att[0])
+        E.rnn = self._reverse(S, E, 2, None)
+        if n_slots is None:
+            n_slots = 2048
+            budget = 32 << 30  # bytes of per-start accumulator rows (36 B per item per slot)
+            n_slots = int(max(64, min(n_slots, budget // max(36 * I, 1))))
+        lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
+        n_slots = max(4, min(n_slots, ((hi - lo + 3) // 4) * 4 if hi > lo else 4))
+        acc = self._zeros(n_slots * max(I, 1) * 4, torch.float64)
+        touched = self._empty(n_slots * max(I, 1), torch.int32)
+        E.n_cand = self._zeros(max(I, 1), torch.int32)
+        E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=self.dev)
+        E.top_val = self._zeros((max(I, 1), abi.TOPC), torch.float64)
+        d_cnt = self._zeros(4, torch.int64)
+        h_cnt = (C.c_int64 * 4)()
+        cap = 0
+        if full:
+            cap = int(xs_cap) if xs_cap else 1 << 22
+        while True:
+            xs_off = self._zeros(max(I, 1), torch.int64) if cap else None
+            xs_end = self._empty(max(cap, 1), torch.int32) if cap else None
+            xs_val = self._empty(max(cap, 1), torch.float64) if cap else None
+            rc = lib.xmap_extend_paths(
+                st, i32(I), E.k, i32(lo), i32(hi), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags),
+                vp(E.att[0]), vp(E.att[1]), vp(E.att[2]),
+                vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]),
+                vp(E.rnn[0]), vp(E.rnn[1]), vp(E.rnn[2]),
+                i32(n_slots), vp(acc), vp(touched), vp(E.n_cand), vp(E.top_end), vp(E.top_val),
+                i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
+            if rc == abi.ERR_CAPACITY:
+                cap = int(h_cnt[0])
+                continue
+            check(rc)
+            break
+        E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])
+        E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val
+        E.start_range = (lo, hi)
+        return E
+
+    # ------------------------------------------------------------------ stage C
+    def select(self, E, private, picks=None):
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        n_top = self._zeros(max(I, 1), torch.int32)
+        choice = self._zeros(max(I, 1), torch.int32)
+        mp = self._zeros(max(I, 1), torch.int32)
+        pk = None
+        if picks is not None:
+            pk = torch.from_numpy(np.ascontiguousarray(picks, np.int32)).to(self.dev)
+        check(lib.xmap_select_map(st, i32(I), 1 if private else 0, vp(E.n_cand), vp(E.top_end), vp(pk),
+                                  vp(n_top), vp(choice), vp(mp)))
+        return n_top, choice, mp
+
+    def alterego(self, mp):
+        R = self.R
+        st = _stream(self.dev)
+        U = R.n_users
+        cnt_t = self._zeros(max(U, 1), torch.int32)
+        cnt_m = self._zeros(max(U, 1), torch.int32)
+        check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m)))
+        off_t = self._zeros(U + 1, torch.int64)
+        off_m = self._zeros(U + 1, torch.int64)
+        nt, nm = C.c_int64(0), C.c_int64(0)
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_t), vp(off_t), i64(U), C.byref(nt)))
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_m), vp(off_m), i64(U), C.byref(nm)))
+        n = int(nt.value) + int(nm.value)
+        G = GenResult()
+        G.user = self._empty(max(n, 1), torch.int32)
+        G.item = self._empty(max(n, 1), torch.int32)
+        G.rating = self._empty(max(n, 1), torch.float32)
+        G.time = self._empty(max(n, 1), torch.int64)
+        check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt.value),
+                                     vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))
+        G.n_rows, G.n_target_rows = n, int(nt.value)
+        G.cnt_t, G.cnt_m = cnt_t, cnt_m
+        G.user, G.item, G.rating, G.time = G.user[:n], G.item[:n], G.rating[:n], G.time[:n]
+        return G
+
+    def n_profiles(self, G):
+        """distinct users present in the AlterEgo output (profiles/s numerator)."""
+        U = self.R.n_users
+        return int(((G.cnt_t[:U] + G.cnt_m[:U]) > 0).sum().item())
+
+
+def draw_picks(n_top):
+    """cross_nonprivate_mapping's draw (core/generator.py:110): one np.random.randint(0, len(top)-1)
+    per start item in ascending start order from the GLOBAL NumPy RNG (the vectorised call consumes
+    the stream exactly like the reference's sequential scalar calls).  Singleton candidate lists raise
+    ValueError like the reference."""
+    n_top = np.asarray(n_top)
+    starts = np.nonzero(n_top)[0]
+    picks = np.zeros(len(n_top), np.int32)
+    if len(starts):
+        high = n_top[starts].astype(np.int64) - 1
+        if (high <= 0).any():
+            raise ValueError("low >= high")
+        picks[starts] = np.random.randint(0, high)
+    return picks

@@ -1,0 +1,70 @@
+"""ctypes binding of libxmap_hip.so (C ABI declared in include/xmap_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, import of this
+module raises (build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C x-map_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(HERE, "..", "..", "libxmap_hip.so"))
+
+COSINE, ADJUST_COSINE = 0, 1
+METHODS = {"cosine": COSINE, "adjust_cosine": ADJUST_COSINE}
+TOPC = 10
+ERR_OVERFLOW, ERR_CAPACITY = -3, -4
+
+
+class XmapError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libxmap_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Ratings(C.Structure):
+    _fields_ = [("n_users", C.c_int64), ("n_items", C.c_int32), ("nnz", C.c_int64),
+                ("user_ptr", C.c_void_p), ("user_item", C.c_void_p), ("user_rating", C.c_void_p),
+                ("user_time", C.c_void_p), ("item_ptr", C.c_void_p), ("item_user", C.c_void_p),
+                ("item_rating", C.c_void_p), ("prefix_cls", C.c_void_p), ("suffix_cls", C.c_void_p),
+                ("contains_mask", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class Sim(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("sim", C.c_void_p),
+                ("mutu", C.c_void_p), ("nij", C.c_void_p), ("info", C.c_void_p)]
+
+
+EXPORTS = [
+    "xmap_last_error", "xmap_version", "xmap_exclusive_scan_i64", "xmap_exclusive_scan_i32_to_i64",
+    "xmap_user_stats", "xmap_item_stats", "xmap_sim_plan", "xmap_sim_units", "xmap_sim_count",
+    "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_bridge_flags", "xmap_knn_classify", "xmap_reverse_count",
+    "xmap_reverse_fill", "xmap_extend_paths", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
+]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("libxmap_hip.so not built (%s); the MI355X engine has no CPU fallback" % LIB_PATH)
+lib = C.CDLL(LIB_PATH)
+lib.xmap_last_error.restype = C.c_char_p
+for _n in EXPORTS:
+    getattr(lib, _n)  # every symbol the header declares must be exported
+
+
+def check(rc):
+    if rc != 0:
+        raise XmapError(rc, (lib.xmap_last_error() or b"").decode())
+
+
+def vp(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def i64(v):
+    return C.c_int64(int(v))
+
+
+def i32(v):
+    return C.c_int32(int(v))
