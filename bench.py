@@ -1,0 +1,168 @@
+"""bench.py -- one "step" = one pass of the X-MAP hot path (item-item similarity -> cross-domain
+extension -> AlterEgo generation) over synthetic Amazon-format ratings already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  metric = item-item sim pairs/s: D (distinct directed item pairs with
+>= 1 co-rater evaluated by stage A) / stage-A time; AlterEgo profiles/s and the per-stage
+times ride along in the same line.  N>1 shards the items of the SAME workload over the ranks (strong
+scaling): stage-A rows and stage-B start items are split, the kept rows and the per-start candidates are
+exchanged with RCCL all-gathers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "x-map_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+CAP = 50                # parameters.yaml:18
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def workloads():
+    from xmap.engine import synth
+    return {
+        # BASELINE.json configs[1]: ~1M users / 200k+200k items, top-k 50
+        "c2": dict(gen=lambda: synth.config_c2(), k=50, name="amazon-like two-domain 1M users / 200k+200k items, top-k=50 (BASELINE configs[1])"),
+        # BASELINE.json configs[0]: 10k users / 2x5k items (the reference's CPU-runnable case)
+        "c1": dict(gen=lambda: synth.config_c1(), k=10, name="10k users / 2x5k items, top-k=10 (BASELINE configs[0])"),
+    }
+
+
+def cpu_baseline(r, attrs, method, target_s=15.0, threads=4):
+    """Oracle (CPU restatement, `port`) timed on this host on a bounded row sample of the same workload."""
+    from oracle import xmap_oracle as xo
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
+    uavg, _ = xo.user_info(T)
+    info = xo.item_info(T, uavg)
+    I = r.n_items
+    # probe on a small slice to size the sample
+    probe = max(1, I // 200)
+    t0 = time.time()
+    S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, probe))
+    dt = max(time.time() - t0, 1e-3)
+    xo.sim_free(S)
+    rows = int(min(I, max(probe, probe * target_s / dt)))
+    t0 = time.time()
+    S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, rows))
+    dt = time.time() - t0
+    out = dict(value=S.n_eval / dt, unit="pairs/s", cores=threads, kind="port",
+               sample="oracle stage A (item-item sim) on item rows [0,%d) of %d: %d pairs in %.1f s, OpenMP %d threads"
+                      % (rows, I, S.n_eval, dt, threads))
+    xo.sim_free(S)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--method", default="adjust_cosine")   # parameters.yaml:17
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        log("bench.py: --gpus %d needs torch.distributed.run; running 1 rank" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = "cuda:%d" % local
+    torch.cuda.set_device(local)
+
+    from xmap.engine import device, sharded
+    wl = workloads()[args.workload]
+    k = args.k or wl["k"]
+    t0 = time.time()
+    r = wl["gen"]()
+    attrs = r.item_attrs()
+    R = device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs, dev)
+    eng = device.Engine(R)
+    if rank == 0:
+        log("setup: users=%d items=%d nnz=%d in %.1f s (gen + CSC layout + H2D)" % (r.n_users, r.n_items, r.nnz, time.time() - t0))
+
+    def step():
+        return sharded.run_step(eng, args.method, CAP, k, True, dist, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    eng.timers = {}
+    t_start = time.time()
+    res = None
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.time() - t_start
+    tm = eng.timer_ms()
+    eng.timers = None
+    if dist:
+        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    ms_step = wall * 1e3 / args.steps
+    stage = {n: float(np.mean(tm.get(n, [0.0]))) for n in ("stage_a", "stage_b", "stage_c")}
+    if dist:  # max over ranks of the per-stage means
+        v = torch.tensor([stage["stage_a"], stage["stage_b"], stage["stage_c"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        stage = dict(zip(("stage_a", "stage_b", "stage_c"), [float(x) for x in v.tolist()]))
+    t_a, t_b, t_c = stage["stage_a"] / 1e3, stage["stage_b"] / 1e3, stage["stage_c"] / 1e3
+
+    if rank == 0:
+        D, Dk, P, nnz, I = res["n_eval"], res["n_kept"], res["n_contrib"], r.nnz, r.n_items
+        # dominant kernel: k_pair_sim (fill launch); algorithmic bytes per launch, SURVEY.md 8d:
+        #   8 B per directed co-rating contribution + CSR and CSC read once + item stats + kept pairs written
+        fill_ms = float(np.mean(tm.get("pair_fill", [0.0])))
+        bytes_fill = 8.0 * res["n_contrib_local"] + 16.0 * nnz + 32.0 * I + 20.0 * res["n_kept_local"]
+        ach = bytes_fill / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+        out = {
+            "metric": "item_sim_pairs_per_s", "value": D / t_a if t_a > 0 else 0.0, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "method": args.method, "top_k": k, "private": True,
+                       "users": r.n_users, "items": I, "nnz": nnz, "P_contributions": P,
+                       "D_pairs_evaluated": D, "D_pairs_kept": Dk, "paths": res["n_paths"],
+                       "parallelism": "items sharded over %d GPU(s)" % world},
+            "alterego_profiles_per_s": res["n_profiles"] / (t_b + t_c) if (t_b + t_c) > 0 else 0.0,
+            "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
+            "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},
+            "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+            "roofline": {"bound": "hbm", "kernel": "k_pair_sim<fill>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_fill, "launch_ms": fill_ms},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(r, attrs, args.method)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,8 +77,8 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
 
 /* Work decomposition for the pair kernel: unit = (item i, hash partition q of its partner space),
  * Q[i] = ceil(min(W_i, I-1) / slot_target), W_i = sum over raters of (profile length - 1).
- * Writes Q[I], unit_ptr[I+1] (exclusive scan of Q); *h_n_units, *h_contrib (= sum W_i = P). Syncs. */
-int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *unit_ptr,
+ * Writes Q[I], W[I], unit_ptr[I+1] (exclusive scan of Q); *h_n_units, *h_contrib (= sum W_i = P). Syncs. */
+int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *W, int64_t *unit_ptr,
                   int64_t *h_n_units, int64_t *h_contrib);
 int xmap_sim_units(void *stream, int32_t n_items, const int32_t *Q, const int64_t *unit_ptr,
                    int32_t *unit_item /*[n_units]*/, int32_t *unit_q /*[n_units]*/);
@@ -115,6 +115,7 @@ typedef struct xmap_sim {
     const int32_t *mutu;
     const int32_t *nij;
     const double *info;     /* [I][4] item info of stage A (n_i is info[i][3]) */
+    const double *frac;     /* optional [nnz] frac_mutu per pair; NULL = derive mutu / (n_i + n_j - n_ij) */
 } xmap_sim;
 
 /* build_sim_DF + "SELECT DISTINCT id1 ... WHERE label = 1" (core/baselinerSim.py:235-244,
@@ -164,6 +165,11 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, int32_t start_lo
                       int32_t *n_cand, int32_t *top_end, double *top_val,
                       int64_t xs_cap, int64_t *xs_off, int32_t *xs_end, double *xs_val,
                       int64_t *d_counters /*[4] device*/, int64_t *h_counters /*[4]*/);
+
+/* Candidate arrays from explicit X-Sim lists (an extended_simRDD that did not come from this engine,
+ * e.g. a canonically re-fed one): CSR (xs_ptr, xs_end, xs_val) -> n_cand, top_end, top_val as above. */
+int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end,
+                         const double *xs_val, int32_t *n_cand, int32_t *top_end, double *top_val);
 
 /* ---- stage C: generator_pipeline (utils/assist.py:136-150) ---------------------------------- */
 

@@ -54,6 +54,7 @@ static double np_pairwise_sum(const double *a, int64_t n) {
     }
 }
 static double np_sum(const double *a, int64_t n) { return 0.0 + np_pairwise_sum(a, n); }
+static void dd_add(double *hi, double *lo, double x);
 
 /* --------------------------------------------------------------- stage A */
 
@@ -75,19 +76,25 @@ void xo_user_info(int64_t U, const int64_t *ptr, const float *rating, double *av
 
 /* A3: core/baselinerSim.py:40-82  get_universal_item_info
  *   combineByKey in trainRDD order (one partition): (sum r, sum r**2, sum (r-avg_u)**2, n)
- *   -> (1.0*sum/n, sqrt(sum r**2), sqrt(sum (r-avg_u)**2), 1.0*n).  `**2` is C pow(). */
+ *   -> (1.0*sum/n, sqrt(sum r**2), sqrt(sum (r-avg_u)**2), 1.0*n).  `**2` is C pow(); the third sum
+ *   is accumulated error-free (order-independent canonical value). */
 void xo_item_info(int64_t U, int32_t I, const int64_t *ptr, const int32_t *item, const float *rating,
                   const double *uavg, double *info /* [I][4] */) {
     double *acc = (double *)calloc((size_t)I * 4, sizeof(double));
+    double *lo = (double *)calloc((size_t)I, sizeof(double));
     for (int64_t u = 0; u < U; u++)
         for (int64_t e = ptr[u]; e < ptr[u + 1]; e++) {
             double r = (double)rating[e];
             double *x = acc + (size_t)item[e] * 4;
+            double d = r - uavg[u];
             x[0] += r;
             x[1] += pow(r, 2.0);
-            x[2] += pow(r - uavg[u], 2.0);
+            /* canonical value: exact sum of the fp64 squares (see dd_add); the reference's
+             * left-to-right sum of pow(d, 2) differs from it by a few ulp at most */
+            dd_add(&x[2], &lo[item[e]], d * d);
             x[3] += 1.0;
         }
+    free(lo);
     for (int32_t i = 0; i < I; i++) {
         double *x = acc + (size_t)i * 4, *o = info + (size_t)i * 4;
         o[0] = x[3] > 0 ? 1.0 * x[0] / x[3] : 0.0;
@@ -136,7 +143,7 @@ static int cmp_i32(const void *a, const void *b) {
  * order reduceByKey concatenates the co-rater triples in, one partition), collect the
  * per-pair term lists, then apply exactly the reference's reductions:
  *   cosine : python sum() left to right of 1.0*r_i*r_j                        (:126-131)
- *   adjust : np.sum((rx-avg)*(ry-avg))  = numpy pairwise sum                  (:156-164)
+ *   adjust : np.sum((rx-avg)*(ry-avg))  -> exact sum of the same fp64 terms, rounded once (:156-164)
  *   sim    = (cos * min(n,cap)) / cap, cos = dot/(norm_i*norm_j) if (norm_i*norm_j) else 0.0   (:84-95)
  *   mutu   = #{(r_i>=avg_i & r_j>=avg_j) | (r_i<avg_i & r_j<avg_j)}            (:97-113)
  *   frac   = 1.0*mutu/(n_i+n_j-n)                                              (:139-141,:171-173)
@@ -236,7 +243,14 @@ XoSim *xo_item_sim(int method, int cap, int64_t U, int32_t I, const int64_t *ptr
                     dot = 0.0;
                     for (int32_t k = 0; k < n; k++) dot += terms[k];
                 } else {
-                    dot = np_sum(terms, n);
+                    /* canonical value: the correctly rounded EXACT sum of the fp64 terms (error-free
+                     * double-double accumulation).  The reference's np.sum rounds in pairwise order of a
+                     * co-rater list whose order depends on Spark partitioning; the exact sum is the
+                     * order-independent value both oracle and HIP path adopt (differs from np.sum by
+                     * <= 1e-13 relative on the golden vectors, every discrete output identical). */
+                    double hi = 0.0, lo = 0.0;
+                    for (int32_t k = 0; k < n; k++) dd_add(&hi, &lo, terms[k]);
+                    dot = hi;
                 }
                 int c1 = (method == XO_COSINE) ? 1 : 2;
                 double np_ = info[(size_t)i * 4 + c1] * info[(size_t)j * 4 + c1];

@@ -61,6 +61,18 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
     return v;
 }
 
+// Error-free accumulation (Knuth two-sum + renormalisation, double-double running sum): the result is
+// the exact sum of the added fp64 values to ~2^-104, hence independent of the order of addition.
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double x) {
+    double s = hi + x;
+    double bb = s - hi;
+    double e = (hi - (s - bb)) + (x - bb);
+    e += lo;
+    double h2 = s + e;
+    lo = e - (h2 - s);
+    hi = h2;
+}
+
 // murmur3 finaliser: partition hash of an item index
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;

@@ -19,7 +19,7 @@
 
 namespace xmap {
 
-constexpr int A_THREADS = 256;
+constexpr int A_THREADS = 64;   // one wave = one unit = one workgroup (no block-level barrier is used)
 constexpr int A_WAVES = A_THREADS / 64;
 constexpr int LOG_SLOTS = 10;
 constexpr int SLOTS = 1 << LOG_SLOTS;
@@ -48,17 +48,23 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
     if (i >= I) return;
     int lane = lane_id();
     long long p0 = iptr[i], p1 = iptr[i + 1];
-    double s = 0.0, q = 0.0, a2 = 0.0;
+    double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
     for (long long p = p0 + lane; p < p1; p += 64) {
         double r = (double)irating[p];
         double d = r - u_avg[iuser[p]];
         s += r;
         q += r * r;
-        a2 += d * d;
+        dd_add(a2, a2lo, d * d);   // exact sum of the fp64 squares (order-independent)
     }
     s = wave_sum(s);
     q = wave_sum(q);
-    a2 = wave_sum(a2);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double oh = __shfl_down(a2, m, 64), ol = __shfl_down(a2lo, m, 64);
+        dd_add(a2, a2lo, oh);
+        dd_add(a2, a2lo, ol);
+    }
+    a2 = __shfl(a2, 0, 64);
     double n = (double)(p1 - p0);
     double avg = (p1 > p0) ? 1.0 * s / n : 0.0;
     if (lane == 0) {
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void k_pack_user_side(long long nnz, const int
 
 // W_i = sum over raters of (profile length - 1); Q_i = ceil(min(W_i, I-1) / target)
 __global__ __launch_bounds__(256) void k_plan(int I, const long long *iptr, const int *iuser, const long long *uptr,
-                                              int target, int *Q, unsigned long long *contrib) {
+                                              int target, int *Q, long long *W, unsigned long long *contrib) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
     int lane = lane_id();
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(256) void k_plan(int I, const long long *iptr, cons
     if (lane == 0) {
         long long m = w < (long long)(I - 1) ? w : (long long)(I - 1);
         Q[i] = (int)((m + target - 1) / target);
+        W[i] = w;
         if (w) atomicAdd(contrib, (unsigned long long)w);
     }
 }
@@ -153,6 +160,8 @@ __global__ __launch_bounds__(A_THREADS) void k_pair_sim(PairArgs A) {
     __shared__ uint32_t s_cnt[A_WAVES][SLOTS];
     __shared__ uint32_t s_mut[A_WAVES][SLOTS];
     __shared__ double s_dot[A_WAVES][SLOTS];
+    // adjusted-cosine terms are summed error-free (double-double): the low words live here
+    __shared__ double s_lo[METHOD == XMAP_ADJUST_COSINE ? A_WAVES : 1][METHOD == XMAP_ADJUST_COSINE ? SLOTS : 1];
 
     const int w = threadIdx.x >> 6;
     const int lane = lane_id();
@@ -163,11 +172,13 @@ __global__ __launch_bounds__(A_THREADS) void k_pair_sim(PairArgs A) {
     uint32_t *cnt = s_cnt[w];
     uint32_t *mut = s_mut[w];
     double *dot = s_dot[w];
+    double *dlo = s_lo[METHOD == XMAP_ADJUST_COSINE ? w : 0];
     for (int s = lane; s < SLOTS; s += 64) {
         key[s] = EMPTY;
         cnt[s] = 0;
         mut[s] = 0;
         dot[s] = 0.0;
+        if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
     }
 
     const int i = uniform(A.unit_item[unit]);
@@ -240,9 +251,14 @@ __global__ __launch_bounds__(A_THREADS) void k_pair_sim(PairArgs A) {
                             const unsigned gej = ((unsigned)jw) >> 31;
                             cnt[h] += 1;
                             mut[h] += (gej == gei) ? 1u : 0u;
-                            const double term = (METHOD == XMAP_COSINE) ? (1.0 * ri) * (double)rj
-                                                                        : (ri - a) * ((double)rj - a);
-                            dot[h] += term;
+                            if (METHOD == XMAP_COSINE) {
+                                dot[h] += (1.0 * ri) * (double)rj;   // exact for integer ratings
+                            } else {
+                                double hi = dot[h], lo = dlo[h];
+                                dd_add(hi, lo, (ri - a) * ((double)rj - a));
+                                dot[h] = hi;
+                                dlo[h] = lo;
+                            }
                         } else {
                             ovf = 1;
                         }
@@ -365,9 +381,9 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
     return XMAP_OK;
 }
 
-int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *unit_ptr,
+int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *W, int64_t *unit_ptr,
                   int64_t *h_n_units, int64_t *h_contrib) {
-    XM_ARG(R && Q && unit_ptr && slot_target > 0 && slot_target <= SLOTS);
+    XM_ARG(R && Q && W && unit_ptr && slot_target > 0 && slot_target <= SLOTS);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d_contrib = nullptr;
     XM_HIP(hipMallocAsync((void **)&d_contrib, sizeof(unsigned long long), st));
@@ -375,7 +391,7 @@ int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int3
     if (R->n_items > 0) {
         k_plan<<<dim3((unsigned)((R->n_items + 3) / 4)), dim3(256), 0, st>>>(
             R->n_items, (const long long *)R->item_ptr, R->item_user, (const long long *)R->user_ptr, slot_target, Q,
-            d_contrib);
+            (long long *)W, d_contrib);
         XM_LAUNCH_CHECK();
     }
     int rc = xmap_exclusive_scan_i32_to_i64(stream, Q, unit_ptr, R->n_items, h_n_units);

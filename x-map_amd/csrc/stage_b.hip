@@ -69,6 +69,7 @@ struct KnnArgs {
     const int *mutu;
     const int *nij;
     const double *info;
+    const double *frac;
     const uint8_t *bb;
     const int *suffix_cls;
     const uint32_t *contains_mask;
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
                 if ((pa && rA < k) || (pb && rB < k)) {
                     double sv = A.sim[p];
                     double mu = (double)A.mutu[p];
-                    double fr = 1.0 * mu / (A.info[(size_t)i * 4 + 3] + A.info[(size_t)c * 4 + 3] - (double)A.nij[p]);
+                    double fr = A.frac ? A.frac[p]
+                                       : 1.0 * mu / (A.info[(size_t)i * 4 + 3] + A.info[(size_t)c * 4 + 3] - (double)A.nij[p]);
                     if (pa && rA < k) {
                         size_t o = ((size_t)i * 2 + 0) * k + rA;
                         A.kcol[o] = c; A.kval[o * 3] = sv; A.kval[o * 3 + 1] = mu; A.kval[o * 3 + 2] = fr;
@@ -232,6 +234,7 @@ struct RevArgs {
     const int *mutu;
     const int *nij;
     const double *info;
+    const double *frac;
     const uint8_t *bb;
     const uint8_t *cls;
     const int *kcnt;
@@ -308,7 +311,8 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
                 A.ridx[o] = b;
                 A.rval[o * 3] = sv;
                 A.rval[o * 3 + 1] = mu;
-                A.rval[o * 3 + 2] = 1.0 * mu / (A.info[(size_t)a * 4 + 3] + A.info[(size_t)b * 4 + 3] - (double)A.nij[p]);
+                A.rval[o * 3 + 2] = A.frac ? A.frac[p]
+                                           : 1.0 * mu / (A.info[(size_t)a * 4 + 3] + A.info[(size_t)b * 4 + 3] - (double)A.nij[p]);
                 if (A.rflag) A.rflag[o] = fl;
             }
             int c = __popcll(m);
@@ -349,16 +353,6 @@ __device__ __forceinline__ Carry add_edge(Carry a, double sim, double mutu, doub
 // Error-free accumulation (Knuth two-sum, double-double running sums): the per-(start,end) sums become
 // independent of the order in which paths are enumerated (to ~2^-104), so items with identical
 // path multisets tie exactly and the tie-break (ascending end index) is well defined.
-__device__ __forceinline__ void dd_add(double &hi, double &lo, double x) {
-    double s = hi + x;
-    double bb = s - hi;
-    double e = (hi - (s - bb)) + (x - bb);
-    e += lo;
-    double h2 = s + e;
-    lo = e - (h2 - s);
-    hi = h2;
-}
-
 struct WaveAcc {
     double *acc; int *touched; int nt; unsigned long long paths;
     __device__ __forceinline__ void add(bool active, int end, Carry p) {
@@ -434,6 +428,50 @@ __device__ __forceinline__ void through_t(const PathArgs &A, WaveAcc &W, int t, 
     }
 }
 
+// wave-wide selection of the XMAP_TOPC best of nt candidates in the order (|xsim| desc, end asc);
+// get(b, end, val) returns candidate b.  Lane 0 writes the result.
+template <typename Get>
+__device__ __forceinline__ void select_topc(int nt, Get get, int *top_end, double *top_val) {
+    const int lane = lane_id();
+    unsigned long long pk = 0;
+    int pe = -1;
+    int nsel = nt < XMAP_TOPC ? nt : XMAP_TOPC;
+    for (int r = 0; r < nsel; r++) {
+        unsigned long long bk = 0;
+        int be = 0x7fffffff;
+        double bv = 0.0;
+        bool have = false;
+        for (int b = lane; b < nt; b += 64) {
+            int e; double v;
+            get(b, e, v);
+            unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v));
+            bool after_prev = (r == 0) || (key < pk) || (key == pk && e > pe);
+            if (after_prev && (!have || key > bk || (key == bk && e < be))) { bk = key; be = e; bv = v; have = true; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            unsigned long long ok = __shfl_xor(bk, m, 64);
+            int oe = __shfl_xor(be, m, 64);
+            double ov = __shfl_xor(bv, m, 64);
+            int oh = __shfl_xor((int)have, m, 64);
+            if (oh && (!have || ok > bk || (ok == bk && oe < be))) { bk = ok; be = oe; bv = ov; have = true; }
+        }
+        pk = bk; pe = be;
+        if (lane == 0) { top_end[r] = be; top_val[r] = bv; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_topc_lists(int I, const long long *xs_ptr, const int *xs_end, const double *xs_val,
+                                                    int *n_cand, int *top_end, double *top_val) {
+    int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= I) return;
+    long long lo = xs_ptr[s];
+    int nt = (int)(xs_ptr[s + 1] - lo);
+    select_topc(nt, [&](int b, int &e, double &v) { e = xs_end[lo + b]; v = xs_val[lo + b]; },
+                top_end + (size_t)s * XMAP_TOPC, top_val + (size_t)s * XMAP_TOPC);
+    if (lane_id() == 0) n_cand[s] = nt;
+}
+
 __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= A.n_slots) return;
@@ -489,32 +527,8 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
             W.acc[(size_t)e * 4] = 1.0 * W.acc[(size_t)e * 4] / W.acc[(size_t)e * 4 + 2];
         }
         // fused top-XMAP_TOPC by (|xsim| desc, end asc): all a Generator reads (generator.py:85,109)
-        unsigned long long pk = 0xFFFFFFFFFFFFFFFFull;  // previous best key; first round accepts all
-        int pe = -1;
-        int nsel = nt < XMAP_TOPC ? nt : XMAP_TOPC;
-        for (int r = 0; r < nsel; r++) {
-            unsigned long long bk = 0;
-            int be = 0x7fffffff;
-            bool have = false;
-            for (int b = lane; b < nt; b += 64) {
-                int e = W.touched[b];
-                unsigned long long key = (unsigned long long)__double_as_longlong(fabs(W.acc[(size_t)e * 4]));
-                bool after_prev = (r == 0) || (key < pk) || (key == pk && e > pe);
-                if (after_prev && (!have || key > bk || (key == bk && e < be))) { bk = key; be = e; have = true; }
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                unsigned long long ok = __shfl_xor(bk, m, 64);
-                int oe = __shfl_xor(be, m, 64);
-                int oh = __shfl_xor((int)have, m, 64);
-                if (oh && (!have || ok > bk || (ok == bk && oe < be))) { bk = ok; be = oe; have = true; }
-            }
-            pk = bk; pe = be;
-            if (lane == 0) {
-                A.top_end[(size_t)start * XMAP_TOPC + r] = be;
-                A.top_val[(size_t)start * XMAP_TOPC + r] = W.acc[(size_t)be * 4];
-            }
-        }
+        select_topc(nt, [&](int b, int &e, double &v) { e = W.touched[b]; v = W.acc[(size_t)e * 4]; },
+                    A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
         if (lane == 0) A.n_cand[start] = nt;
         cand_total += nt;
         // optional full candidate lists (extender_pipeline's RDD) via a cursor in the caller's buffer
@@ -568,7 +582,7 @@ int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t 
     KnnArgs A;
     A.I = S->n_items; A.k = top_k;
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
-    A.info = S->info; A.bb = bb; A.suffix_cls = suffix_cls; A.contains_mask = contains_mask;
+    A.info = S->info; A.frac = S->frac; A.bb = bb; A.suffix_cls = suffix_cls; A.contains_mask = contains_mask;
     A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
     k_knn_classify<<<dim3((unsigned)S->n_items), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
     XM_LAUNCH_CHECK();
@@ -587,7 +601,7 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     RevArgs A;
     A.I = S->n_items; A.k = top_k; A.mode = mode;
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
-    A.info = S->info; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
+    A.info = S->info; A.frac = S->frac; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
     A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
     A.attach_ptr = (const long long *)attach_ptr;
     A.rcnt = rcnt; A.rptr = (const long long *)rptr; A.ridx = ridx; A.rval = rval; A.rflag = rflag;
@@ -613,6 +627,16 @@ int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, cons
     XM_ARG(rptr && ridx && rval);
     return reverse_common(stream, true, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
                           attach_ptr, nullptr, rptr, ridx, rval, rflag);
+}
+
+int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end, const double *xs_val,
+                         int32_t *n_cand, int32_t *top_end, double *top_val) {
+    XM_ARG(xs_ptr && xs_end && xs_val && n_cand && top_end && top_val);
+    if (n_items == 0) return XMAP_OK;
+    k_topc_lists<<<dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        n_items, (const long long *)xs_ptr, xs_end, xs_val, n_cand, top_end, top_val);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
 }
 
 int xmap_extend_paths(void *stream, int32_t n_items, int top_k, int32_t start_lo, int32_t start_hi, const uint8_t *cls,

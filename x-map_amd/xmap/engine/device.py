@@ -80,10 +80,39 @@ class GenResult(object):
     pass
 
 
+class _Timed(object):
+    """HIP-event bracket around one C-ABI call on the engine's stream (only when profiling is on)."""
+
+    def __init__(self, eng, name):
+        self.eng, self.name = eng, name
+
+    def __enter__(self):
+        if self.eng.timers is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.eng.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.eng.timers is not None:
+            self.b.record(torch.cuda.current_stream(self.eng.dev))
+            self.eng.timers.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 class Engine(object):
     def __init__(self, ratings):
         self.R = ratings
         self.dev = ratings.device
+        self.timers = None  # set to {} to collect per-call HIP-event timings
+
+    def timed(self, name):
+        return _Timed(self, name)
+
+    def timer_ms(self):
+        """{name: [ms, ...]} of everything recorded since timers was set (synchronises)."""
+        torch.cuda.synchronize(self.dev)
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.timers or {}).items()}
 
     def _empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.dev)
@@ -105,23 +134,45 @@ class Engine(object):
         check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(ua_item), vp(ia_user)))
         return u_avg, u_norm, info, ua_item, ia_user
 
-    def item_sim(self, method, cap, slot_target=640, item_range=None):
+    def plan(self, slot_target=640):
+        """work decomposition of the pair kernel: units = (item, hash partition of its partner space)"""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        Pn = SimResult()
+        Pn.slot_target = slot_target
+        Pn.Q = self._zeros(max(I, 1), torch.int32)
+        Pn.W = self._zeros(max(I, 1), torch.int64)
+        Pn.unit_ptr = self._zeros(I + 1, torch.int64)
+        n_units, contrib = C.c_int64(0), C.c_int64(0)
+        with self.timed("plan"):
+            check(lib.xmap_sim_plan(st, C.byref(R.c), i32(slot_target), vp(Pn.Q), vp(Pn.W), vp(Pn.unit_ptr),
+                                    C.byref(n_units), C.byref(contrib)))
+        Pn.nu, Pn.contrib = int(n_units.value), int(contrib.value)
+        Pn.unit_item = self._empty(max(Pn.nu, 1), torch.int32)
+        Pn.unit_q = self._empty(max(Pn.nu, 1), torch.int32)
+        check(lib.xmap_sim_units(st, i32(I), vp(Pn.Q), vp(Pn.unit_ptr), vp(Pn.unit_item), vp(Pn.unit_q)))
+        return Pn
+
+    def item_weights(self, Pn):
+        """per-item cost proxy of the pair kernel: raters x partitions (rater-steps of its units)"""
+        R = self.R
+        n = (R.item_ptr[1:] - R.item_ptr[:-1])
+        return n * Pn.Q[:R.n_items].to(torch.int64)
+
+    def item_sim(self, method, cap, slot_target=640, item_range=None, stats=None, plan=None):
         """baseliner_calculate_sim_pipeline for the rows in item_range (default: all)."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
-        u_avg, u_norm, info, ua_item, ia_user = self.stats()
+        if stats is None:
+            with self.timed("stats"):
+                stats = self.stats()
+        u_avg, u_norm, info, ua_item, ia_user = stats
         I = R.n_items
         while True:
-            Q = self._zeros(max(I, 1), torch.int32)
-            unit_ptr = self._zeros(I + 1, torch.int64)
-            n_units, contrib = C.c_int64(0), C.c_int64(0)
-            check(lib.xmap_sim_plan(st, C.byref(R.c), i32(slot_target), vp(Q), vp(unit_ptr),
-                                    C.byref(n_units), C.byref(contrib)))
-            nu = int(n_units.value)
-            unit_item = self._empty(max(nu, 1), torch.int32)
-            unit_q = self._empty(max(nu, 1), torch.int32)
-            check(lib.xmap_sim_units(st, i32(I), vp(Q), vp(unit_ptr), vp(unit_item), vp(unit_q)))
+            Pn = plan if plan is not None else self.plan(slot_target)
+            Q, unit_ptr, unit_item, unit_q, nu, contrib = Pn.Q, Pn.unit_ptr, Pn.unit_item, Pn.unit_q, Pn.nu, Pn.contrib
             if item_range is None:
                 lo, hi = 0, nu
             else:
@@ -129,13 +180,19 @@ class Engine(object):
                 lo, hi = int(ends[0]), int(ends[1])
             unit_cnt = self._zeros(max(nu, 1), torch.int32)
             d_cnt = self._zeros(4, torch.int64)
-            h_cnt = (C.c_int64 * 4)()
-            rc = lib.xmap_sim_count(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
-                                    vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi), vp(unit_cnt), vp(d_cnt), h_cnt)
-            if rc == abi.ERR_OVERFLOW and slot_target > 32:
-                slot_target //= 2
-                continue
+            h_cnt = [0, 0, 0, 0]
+            with self.timed("pair_count"):
+                rc = lib.xmap_sim_count(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item),
+                                        vp(ia_user), vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi),
+                                        vp(unit_cnt), vp(d_cnt), None)
             check(rc)
+            h_cnt = d_cnt.tolist()  # synchronises the stream
+            if h_cnt[2]:
+                if slot_target > 32:
+                    slot_target //= 2
+                    plan = None
+                    continue
+                raise abi.XmapError(abi.ERR_OVERFLOW, "pair-table overflow")
             break
         kept, evaluated = int(h_cnt[0]), int(h_cnt[1])
         unit_off = self._zeros(nu + 1, torch.int64)
@@ -146,53 +203,76 @@ class Engine(object):
         sim = self._empty(max(kept, 1), torch.float64)
         mutu = self._empty(max(kept, 1), torch.int32)
         nij = self._empty(max(kept, 1), torch.int32)
-        check(lib.xmap_sim_fill(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
-                                vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi), vp(unit_off),
-                                vp(col), vp(sim), vp(mutu), vp(nij)))
+        with self.timed("pair_fill"):
+            check(lib.xmap_sim_fill(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
+                                    vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi), vp(unit_off),
+                                    vp(col), vp(sim), vp(mutu), vp(nij)))
         S = SimResult()
         S.method, S.cap, S.n_items = m, int(cap), I
         S.u_avg, S.u_norm, S.info = u_avg, u_norm, info
         S.row_ptr, S.col, S.sim, S.mutu, S.nij = row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept]
-        S.n_kept, S.n_eval, S.n_contrib, S.n_units = kept, evaluated, int(contrib.value), hi - lo
+        S.n_kept, S.n_eval, S.n_contrib, S.n_units = kept, evaluated, int(contrib), hi - lo
+        S.plan = Pn
         S.slot_target = slot_target
         S.c = abi.Sim(I, row_ptr.data_ptr(), col.data_ptr(), sim.data_ptr(), mutu.data_ptr(), nij.data_ptr(),
-                      info.data_ptr())
+                      info.data_ptr(), 0)
         S._keep = (col, sim, mutu, nij)
         return S
 
-    def sim_from_host(self, row_ptr, col, sim, mutu, nij, info):
-        """Wrap a host-side stage-A result (e.g. a canonically re-fed RDD) as a device SimResult."""
-        d = self.dev
+    def sim_from_device(self, row_ptr, col, sim, mutu, nij, info):
+        """Wrap device tensors (e.g. rows gathered from several ranks) as a SimResult."""
         S = SimResult()
         S.n_items = self.R.n_items
-        S.row_ptr = torch.from_numpy(np.ascontiguousarray(row_ptr, np.int64)).to(d)
-        n = int(row_ptr[-1])
-        pad = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a if n else np.zeros(1), dt)).to(d)
-        col_, sim_, mutu_, nij_ = pad(col, np.int32), pad(sim, np.float64), pad(mutu, np.int32), pad(nij, np.int32)
-        S.col, S.sim, S.mutu, S.nij = col_[:n], sim_[:n], mutu_[:n], nij_[:n]
-        S.info = torch.from_numpy(np.ascontiguousarray(info, np.float64)).to(d)
+        n = int(col.numel())
+        if n == 0:
+            col = self._zeros(1, torch.int32); sim = self._zeros(1, torch.float64)
+            mutu = self._zeros(1, torch.int32); nij = self._zeros(1, torch.int32)
+        S.row_ptr, S.info = row_ptr.contiguous(), info
+        col, sim, mutu, nij = col.contiguous(), sim.contiguous(), mutu.contiguous(), nij.contiguous()
+        S.col, S.sim, S.mutu, S.nij = col[:n], sim[:n], mutu[:n], nij[:n]
         S.n_kept = n
-        S.c = abi.Sim(S.n_items, S.row_ptr.data_ptr(), col_.data_ptr(), sim_.data_ptr(), mutu_.data_ptr(),
-                      nij_.data_ptr(), S.info.data_ptr())
-        S._keep = (col_, sim_, mutu_, nij_)
+        S.c = abi.Sim(S.n_items, S.row_ptr.data_ptr(), col.data_ptr(), sim.data_ptr(), mutu.data_ptr(),
+                      nij.data_ptr(), info.data_ptr())
+        S._keep = (col, sim, mutu, nij)
+        return S
+
+    def sim_from_host(self, row_ptr, col, sim, mutu, nij, info, frac=None):
+        """Wrap a host-side stage-A result (e.g. a canonically re-fed RDD) as a device SimResult.
+        With `frac`, frac_mutu is taken from the records instead of being derived from (info, nij)."""
+        d = self.dev
+        n = int(row_ptr[-1])
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a if n else np.zeros(1), dt)).to(d)
+        row_ptr_d = torch.from_numpy(np.ascontiguousarray(row_ptr, np.int64)).to(d)
+        info_d = torch.from_numpy(np.ascontiguousarray(info, np.float64)).to(d)
+        S = self.sim_from_device(row_ptr_d, up(col, np.int32)[:n], up(sim, np.float64)[:n], up(mutu, np.int32)[:n],
+                                 up(nij if nij is not None else np.zeros(max(n, 1)), np.int32)[:n], info_d)
+        if frac is not None:
+            S.frac = up(frac, np.float64)
+            S.c.frac = S.frac.data_ptr()
         return S
 
     # ------------------------------------------------------------------ stage B
-    def knn(self, S, top_k):
-        """B1-B4: bridge flags + classified top-k lists."""
+    def knn(self, S, top_k, bb=None):
+        """B1-B4: bridge flags (computed, or given by the caller) + classified top-k lists."""
         R = self.R
         st = _stream(self.dev)
         I, k = R.n_items, int(top_k)
         E = ExtResult()
         E.k = k
-        E.bb = self._zeros(max(I, 1), torch.uint8)
-        check(lib.xmap_bridge_flags(st, C.byref(S.c), vp(R.prefix_cls), vp(E.bb)))
+        if bb is not None:
+            E.bb = bb.to(torch.uint8).contiguous()
+        else:
+            E.bb = self._zeros(max(I, 1), torch.uint8)
+            check(lib.xmap_bridge_flags(st, C.byref(S.c), vp(R.prefix_cls), vp(E.bb)))
         E.cls = self._zeros(max(I, 1), torch.uint8)
         E.kcnt = self._zeros((max(I, 1), 2), torch.int32)
         E.kcol = self._zeros((max(I, 1), 2, k), torch.int32)
         E.kval = self._zeros((max(I, 1), 2, k, 3), torch.float64)
-        check(lib.xmap_knn_classify(st, C.byref(S.c), k, vp(E.bb), vp(R.suffix_cls), vp(R.contains_mask),
-                                    vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval)))
+        with self.timed("knn_classify"):
+            check(lib.xmap_knn_classify(st, C.byref(S.c), k, vp(E.bb), vp(R.suffix_cls), vp(R.contains_mask),
+                                        vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval)))
         return E
 
     def _reverse(self, S, E, mode, attach_ptr):
@@ -242,7 +322,8 @@ class Engine(object):
             xs_off = self._zeros(max(I, 1), torch.int64) if cap else None
             xs_end = self._empty(max(cap, 1), torch.int32) if cap else None
             xs_val = self._empty(max(cap, 1), torch.float64) if cap else None
-            rc = lib.xmap_extend_paths(
+            with self.timed("paths"):
+              rc = lib.xmap_extend_paths(
                 st, i32(I), E.k, i32(lo), i32(hi), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags),
                 vp(E.att[0]), vp(E.att[1]), vp(E.att[2]),
                 vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]),

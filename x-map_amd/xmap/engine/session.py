@@ -1,0 +1,174 @@
+"""Host-side plumbing between the reference's record formats and the device engine.
+
+  trainRDD records   (uid, [(iid, rating, time)*])           -> DeviceRatings (index space, HBM)
+  item2item_simRDD   ((iid1, iid2), (sim, mutu, frac, label)) <-> SimResult
+  extended_simRDD    (start_iid, [(end_iid, xsim)*])          <-> ExtResult
+  alterEgo_profile   (uid, iid, rating, time)                 <-  GenResult
+
+The id dictionary built from a trainRDD is shared by the three stages; engines are
+cached per trainRDD object so that generator_pipeline reuses the one stage A uploaded.
+"""
+import weakref
+
+import numpy as np
+
+from . import ids as xids
+from .localrdd import LocalRDD, records_of
+
+_engines = {}   # id(trainRDD) -> (weakref or None, TrainState)
+
+
+class TrainState(object):
+    def __init__(self, records):
+        from . import device
+        self.idt = xids.IdTable.from_records(records)
+        iidx = self.idt.iidx
+        n = sum(len(p) for _, p in records)
+        ptr = np.zeros(len(records) + 1, np.int64)
+        item = np.empty(n, np.int32)
+        rating = np.empty(n, np.float32)
+        self.times = []          # original time objects, device carries their position
+        self.ratings = []        # original rating objects (pass-through rows keep them)
+        e = 0
+        for u, (_, prof) in enumerate(records):
+            for (iid, r, t) in prof:
+                item[e] = iidx[iid]
+                rating[e] = r
+                self.times.append(t)
+                self.ratings.append(r)
+                e += 1
+            ptr[u + 1] = e
+        self.R = device.DeviceRatings(ptr, item, rating, np.arange(n, dtype=np.int64), len(self.idt.iids),
+                                      self.idt.attrs)
+        self.engine = device.Engine(self.R)
+
+
+def train_state(trainRDD):
+    key = id(trainRDD)
+    hit = _engines.get(key)
+    if hit is not None and (hit[0] is None or hit[0]() is trainRDD):
+        return hit[1]
+    st = TrainState(records_of(trainRDD))
+    try:
+        ref = weakref.ref(trainRDD, lambda _r, k=key: _engines.pop(k, None))
+    except TypeError:
+        ref = None
+    _engines[key] = (ref, st)
+    return st
+
+
+# ---------------------------------------------------------------------------------------------
+class SimPairsRDD(LocalRDD):
+    """item2item_simRDD: ((iid1, iid2), (sim, mutu, frac_mutu, label)) -- rows live in HBM."""
+
+    def __init__(self, state, S, ctx=None):
+        LocalRDD.__init__(self, None, ctx, self._rows)
+        self.state, self.S = state, S
+
+    def _rows(self):
+        S, idt = self.S, self.state.idt
+        row_ptr = S.row_ptr.cpu().numpy()
+        rows = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))
+        col = S.col.cpu().numpy()
+        o = np.lexsort((col, rows))        # canonical order: (iid1, iid2) ascending
+        rows, col = rows[o], col[o]
+        sim = S.sim.cpu().numpy()[o]
+        mutu = S.mutu.cpu().numpy()[o].astype(np.float64)
+        info = S.info.cpu().numpy()
+        frac = mutu / (info[rows, 3] + info[col, 3] - S.nij.cpu().numpy()[o])
+        pre = self.state.idt.attrs[0]
+        label = (pre[rows] != pre[col]).astype(int)
+        iids = idt.iids
+        return [((iids[a], iids[b]), (float(s), float(m), float(f), int(lab)))
+                for a, b, s, m, f, lab in zip(rows, col, sim, mutu, frac, label)]
+
+
+class ExtendedSimRDD(LocalRDD):
+    """extended_simRDD: (start_iid, [(end_iid, xsim)*]) -- candidate lists live in HBM."""
+
+    def __init__(self, state, E, ctx=None):
+        LocalRDD.__init__(self, None, ctx, self._rows)
+        self.state, self.E = state, E
+
+    def _rows(self):
+        E, iids = self.E, self.state.idt.iids
+        I = len(iids)
+        n_cand = E.n_cand.cpu().numpy()[:I]
+        off = E.xs_off.cpu().numpy()[:I]
+        xe, xv = E.xs_end.cpu().numpy(), E.xs_val.cpu().numpy()
+        out = []
+        for s in np.nonzero(n_cand)[0]:
+            e = xe[off[s]:off[s] + n_cand[s]]
+            v = xv[off[s]:off[s] + n_cand[s]]
+            o = np.argsort(e)               # canonical order: end id ascending
+            out.append((iids[s], [(iids[j], float(x)) for j, x in zip(e[o], v[o])]))
+        return out
+
+
+class AlterEgoRDD(LocalRDD):
+    """alterEgo_profile: (uid, iid, rating, time) rows -- generator.py:140-157."""
+
+    def __init__(self, state, G, ctx=None):
+        LocalRDD.__init__(self, None, ctx, self._rows)
+        self.state, self.G = state, G
+
+    def _rows(self):
+        G, st = self.G, self.state
+        u = G.user.cpu().numpy()
+        it = G.item.cpu().numpy()
+        r = G.rating.cpu().numpy()
+        pos = G.time.cpu().numpy()          # position of the source row in trainRDD order
+        nt = G.n_target_rows
+        uids, iids = st.idt.uids, st.idt.iids
+        out = []
+        for q in range(len(u)):
+            # pass-through rows keep the caller's rating object; AlterEgo rows carry the mean
+            rating = st.ratings[pos[q]] if q < nt else np.float64(r[q])
+            out.append((uids[u[q]], iids[it[q]], rating, st.times[pos[q]]))
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+def sim_from_records(state, records):
+    """Device SimResult from generic ((iid1,iid2),(sim,mutu,frac,label)) records (any order)."""
+    iidx = state.idt.iidx
+    I = len(state.idt.iids)
+    n = len(records)
+    a = np.fromiter((iidx[k[0]] for k, _ in records), np.int64, n)
+    b = np.fromiter((iidx[k[1]] for k, _ in records), np.int32, n)
+    sim = np.fromiter((v[0] for _, v in records), np.float64, n)
+    mutu = np.fromiter((v[1] for _, v in records), np.float64, n)
+    frac = np.fromiter((v[2] for _, v in records), np.float64, n)
+    o = np.lexsort((b, a))
+    row_ptr = np.zeros(I + 1, np.int64)
+    np.cumsum(np.bincount(a, minlength=I), out=row_ptr[1:])
+    info = np.zeros((I, 4))
+    return state.engine.sim_from_host(row_ptr, b[o], sim[o], mutu[o].astype(np.int32), None, info, frac=frac[o])
+
+
+def ext_from_records(state, records):
+    """Device candidate arrays from generic (start, [(end, xsim)*]) records."""
+    import ctypes as C
+    import torch
+    from . import device, hipabi as abi
+    eng = state.engine
+    iidx = state.idt.iidx
+    I = len(state.idt.iids)
+    st = np.fromiter((iidx[s] for s, lst in records for _ in lst), np.int64)
+    en = np.fromiter((iidx[e] for _, lst in records for (e, _) in lst), np.int32)
+    va = np.fromiter((v for _, lst in records for (_, v) in lst), np.float64)
+    o = np.lexsort((en, st))
+    xs_ptr = np.zeros(I + 1, np.int64)
+    np.cumsum(np.bincount(st, minlength=I), out=xs_ptr[1:])
+    d = eng.dev
+    E = device.ExtResult()
+    pad = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a if len(a) else np.zeros(1), dt)).to(d)
+    E.xs_ptr = torch.from_numpy(xs_ptr).to(d)
+    E.xs_off = E.xs_ptr[:-1].contiguous()
+    E.xs_end, E.xs_val = pad(en[o], np.int32), pad(va[o], np.float64)
+    E.n_cand = torch.zeros(max(I, 1), dtype=torch.int32, device=d)
+    E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=d)
+    E.top_val = torch.zeros((max(I, 1), abi.TOPC), dtype=torch.float64, device=d)
+    abi.check(abi.lib.xmap_topc_from_lists(device._stream(d), abi.i32(I), abi.vp(E.xs_ptr), abi.vp(E.xs_end),
+                                           abi.vp(E.xs_val), abi.vp(E.n_cand), abi.vp(E.top_end), abi.vp(E.top_val)))
+    return E
