@@ -144,27 +144,39 @@ int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, cons
                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
                       const int64_t *rptr /*[I+1]*/, int32_t *ridx, double *rval /*[n][3]*/, uint8_t *rflag);
 
+/* Scheduling weights of the path enumeration: paths[start] = number of paths that start at `start`
+ * (exact; tails(s) summed over src(t), heads over NB_BB / rnn).  tmp: 4*n_items int64 of scratch. */
+int xmap_path_weights(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                      const int64_t *src_ptr, const int32_t *src_idx, const uint8_t *src_flag, const int64_t *rnn_ptr,
+                      const int32_t *rnn_idx, int64_t *tmp /*[4][I]*/, int64_t *paths /*[I]*/);
+
 /* ExtendSim.sim_extend + get_final_extension (core/extender.py:46-217), start-sharded and streamed:
  * every path of final_nonjoint_extend / final_joint_extend is enumerated in registers with its
  * s_p, c_p (calculate_path_confidence, :83-89) and accumulated into (sum s_p c_p, sum c_p) per
- * (start, end); xsim = ratio (:198-201).  For every start in [start_lo, start_hi):
- *   n_cand[start] = number of distinct ends, top_end/top_val[start][XMAP_TOPC] = the candidates a
- *   Generator reads (stable sort by -|xsim|, generator.py:85,109; ties by ascending end index).
+ * (start, end); xsim = ratio (:198-201).  The sums are kept as double-double (error-free two-sum), so
+ * they do not depend on the enumeration order.
+ * Work units (built by the caller from xmap_path_weights): unit u = (unit_start, chunk unit_c of unit_G).
+ *   unit_G == 1, unit_row == -1: one wave owns the start, uses its slot row and finalises it;
+ *   unit_G  > 1: the start's (head, t) entries are dealt round-robin to unit_G consecutive units with
+ *   dedicated rows unit_row .. unit_row+G-1 of hacc/htouched; heavy_unit0[h] = first unit of heavy start h;
+ *   the rows are merged and finalised after the enumeration.
+ * For every start that has a unit: n_cand[start] = number of distinct ends, top_end/top_val[start][XMAP_TOPC]
+ * = the candidates a Generator reads (stable sort by -|xsim|, generator.py:85,109; ties by ascending end).
  * If xs_cap > 0 the full candidate lists are also written: xs_off[start], entries (xs_end, xs_val);
  * needs xs_cap >= total (reported in h_counters[0]; XMAP_ERR_CAPACITY otherwise).  h_counters[1] = paths.
- * The per-(start,end) sums are kept as double-double (error-free two-sum), so they do not depend on the
- * enumeration order.  scratch: acc[n_slots][n_items][4] doubles (zero-filled by the caller, left zero),
- * touched[n_slots][n_items] int32. */
-int xmap_extend_paths(void *stream, int32_t n_items, int top_k, int32_t start_lo, int32_t start_hi,
-                      const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
-                      const uint8_t *flags,
-                      const int64_t *att_ptr, const int32_t *att_idx, const double *att_val,
-                      const int64_t *src_ptr, const int32_t *src_idx, const double *src_val, const uint8_t *src_flag,
-                      const int64_t *rnn_ptr, const int32_t *rnn_idx, const double *rnn_val,
-                      int32_t n_slots, double *acc, int32_t *touched,
-                      int32_t *n_cand, int32_t *top_end, double *top_val,
-                      int64_t xs_cap, int64_t *xs_off, int32_t *xs_end, double *xs_val,
-                      int64_t *d_counters /*[4] device*/, int64_t *h_counters /*[4]*/);
+ * scratch (zero-filled by the caller, left zero): acc[n_slots][I][4], hacc[n_rows][I][4] doubles;
+ * touched[n_slots][I], htouched[n_rows][I] int32. */
+int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters /*[4] device*/,
+                      int64_t *h_counters /*[4]*/);
 
 /* Candidate arrays from explicit X-Sim lists (an extended_simRDD that did not come from this engine,
  * e.g. a canonically re-fed one): CSR (xs_ptr, xs_end, xs_val) -> n_cand, top_end, top_val as above. */

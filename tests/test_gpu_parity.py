@@ -210,3 +210,14 @@ def test_determinism_and_partitions(dev):
     c = _sorted_sim(eng.item_sim("adjust_cosine", CAP, slot_target=48))  # many partitions per item
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, z)
+    # stage B: heavy starts split into chunks with dedicated rows + device merge == one wave per start
+    S = eng.item_sim("adjust_cosine", CAP)
+    E1 = eng.extend(S, 5, full=True, chunk=1 << 40)
+    E2 = eng.extend(S, 5, full=True, chunk=64, n_slots=64)
+    assert E1.units.n_heavy == 0 and E2.units.n_heavy > 10
+    assert E1.n_paths == E2.n_paths and E1.n_out == E2.n_out
+    for x, y in zip(_xsim_lists(E1, r.n_items), _xsim_lists(E2, r.n_items)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(E1.top_end.cpu().numpy(), E2.top_end.cpu().numpy())
+    assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
+    assert np.array_equal(E1.n_cand.cpu().numpy(), E2.n_cand.cpu().numpy())

@@ -325,7 +325,6 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
 // =============================================================================================
 struct PathArgs {
     int I, k;
-    int start_lo, start_hi;
     const uint8_t *cls;
     const int *kcnt;
     const int *kcol;
@@ -334,8 +333,14 @@ struct PathArgs {
     const long long *att_ptr; const int *att_idx; const double *att_val;
     const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
     const long long *rnn_ptr; const int *rnn_idx; const double *rnn_val;
+    // work units: (start, chunk c of G).  G == 1: the unit owns the start, accumulates in the wave's slot
+    // row and finalises it.  G > 1: the start's (head, t) entries are dealt round-robin to G units, each
+    // with a dedicated row (unit_row); k_merge adds the rows up and finalises.
+    int n_units;
+    const int *unit_start; const int *unit_c; const int *unit_G; const int *unit_row; int *unit_nt;
     int n_slots;
-    double *acc; int *touched;   // acc: [n_slots][I][4] = double-double (sum s_p c_p), double-double (sum c_p)
+    double *acc; int *touched;     // slot rows   [n_slots][I][4] / [n_slots][I]
+    double *hacc; int *htouched;   // heavy rows  [n_rows][I][4]  / [n_rows][I]
     int *n_cand; int *top_end; double *top_val;
     long long xs_cap; long long *xs_off; int *xs_end; double *xs_val;
     unsigned long long *counters;  // [0] total candidates, [1] paths, [2] work cursor, [3] xs cursor
@@ -472,26 +477,72 @@ __global__ __launch_bounds__(256) void k_topc_lists(int I, const long long *xs_p
     if (lane_id() == 0) n_cand[s] = nt;
 }
 
+// xsim = sum(s_p c_p) / sum(c_p) (get_sim, extender.py:198-201), fused top-XMAP_TOPC by (|xsim| desc,
+// end asc) -- all a Generator reads (generator.py:85,109) --, optional full lists, row reset.
+__device__ __forceinline__ int finalize_start(const PathArgs &A, double *acc, const int *touched, int nt, int start) {
+    const int lane = lane_id();
+    for (int b = lane; b < nt; b += 64) {
+        int e = touched[b];
+        acc[(size_t)e * 4] = 1.0 * acc[(size_t)e * 4] / acc[(size_t)e * 4 + 2];
+    }
+    select_topc(nt, [&](int b, int &e, double &v) { e = touched[b]; v = acc[(size_t)e * 4]; },
+                A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
+    if (lane == 0) A.n_cand[start] = nt;
+    if (A.xs_cap > 0 && nt > 0) {  // full candidate lists (extender_pipeline's RDD) via a cursor
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
+        off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
+        if ((long long)(off + nt) <= A.xs_cap) {
+            for (int b = lane; b < nt; b += 64) {
+                int e = touched[b];
+                A.xs_end[off + b] = e;
+                A.xs_val[off + b] = acc[(size_t)e * 4];
+            }
+            if (lane == 0) A.xs_off[start] = (long long)off;
+        } else if (lane == 0) {
+            A.xs_off[start] = -1;
+        }
+    }
+    for (int b = lane; b < nt; b += 64) {
+        double *a = acc + (size_t)touched[b] * 4;
+        a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
+    }
+    return nt;
+}
+
 __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= A.n_slots) return;
     const int lane = lane_id();
     const int k = A.k;
     WaveAcc W;
-    W.acc = A.acc + (size_t)slot * A.I * 4;
-    W.touched = A.touched + (size_t)slot * A.I;
     W.paths = 0;
     unsigned long long cand_total = 0;
     for (;;) {
-        int s_ = 0;
-        if (lane == 0) s_ = (int)atomicAdd(&A.counters[2], 1ull);
-        const int start = A.start_lo + uniform(s_);
-        if (start >= A.start_hi) break;  // every wave reaches this exit: the cursor only grows
+        int u_ = 0;
+        if (lane == 0) u_ = (int)atomicAdd(&A.counters[2], 1ull);
+        const int unit = uniform(u_);
+        if (unit >= A.n_units) break;  // every wave reaches this exit: the cursor only grows
+        const int start = uniform(A.unit_start[unit]);
+        const int c = uniform(A.unit_c[unit]);
+        const int G = uniform(A.unit_G[unit]);
+        const int row = uniform(A.unit_row[unit]);
+        if (row < 0) {
+            W.acc = A.acc + (size_t)slot * A.I * 4;
+            W.touched = A.touched + (size_t)slot * A.I;
+        } else {
+            W.acc = A.hacc + (size_t)row * A.I * 4;
+            W.touched = A.htouched + (size_t)row * A.I;
+        }
         W.nt = 0;
+        int ent = 0;  // running index of the start's (head, t) entries; unit c takes ent % G == c
         // role T: start = t (final_nonjoint_extend on every SRC record, extender.py:124-140,:180)
         if (A.flags[start] & 2) {
-            Carry none; none.sm = 0; none.mu = 0; none.c = 0;
-            through_t(A, W, start, false, none);
+            if (G == 1 || ent % G == c) {
+                Carry none; none.sm = 0; none.mu = 0; none.c = 0;
+                through_t(A, W, start, false, none);
+            }
+            ent++;
         }
         // role X': start = x' in attach(t) (target_path, extender.py:160-163)
         if (A.cls[start] == 2) {
@@ -500,8 +551,11 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
                 size_t o = ((size_t)start * 2) * k + q;
                 int t = A.kcol[o];
                 if (!(A.flags[t] & 2)) continue;  // BB_other_intra_target keeps "T:" bridges only (:175)
-                Carry h = first_edge(A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
-                through_t(A, W, t, true, h);
+                if (G == 1 || ent % G == c) {
+                    Carry h = first_edge(A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+                    through_t(A, W, t, true, h);
+                }
+                ent++;
             }
         }
         // role Y': start = y' in NN(x'), x' in attach(t) (longest_path, extender.py:164-167)
@@ -515,48 +569,105 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
                     size_t o = ((size_t)xp * 2) * k + q;
                     int t = A.kcol[o];
                     if (!(A.flags[t] & 2)) continue;
-                    Carry h = add_edge(h0, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
-                    through_t(A, W, t, true, h);
+                    if (G == 1 || ent % G == c) {
+                        Carry h = add_edge(h0, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+                        through_t(A, W, t, true, h);
+                    }
+                    ent++;
                 }
             }
         }
-        // finalise: xsim = sum(s_p c_p) / sum(c_p) (get_sim, extender.py:198-201), kept in sc[]
-        const int nt = W.nt;
-        for (int b = lane; b < nt; b += 64) {
-            int e = W.touched[b];
-            W.acc[(size_t)e * 4] = 1.0 * W.acc[(size_t)e * 4] / W.acc[(size_t)e * 4 + 2];
-        }
-        // fused top-XMAP_TOPC by (|xsim| desc, end asc): all a Generator reads (generator.py:85,109)
-        select_topc(nt, [&](int b, int &e, double &v) { e = W.touched[b]; v = W.acc[(size_t)e * 4]; },
-                    A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
-        if (lane == 0) A.n_cand[start] = nt;
-        cand_total += nt;
-        // optional full candidate lists (extender_pipeline's RDD) via a cursor in the caller's buffer
-        if (A.xs_cap > 0 && nt > 0) {
-            unsigned long long off = 0;
-            if (lane == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
-            off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
-            if ((long long)(off + nt) <= A.xs_cap) {
-                for (int b = lane; b < nt; b += 64) {
-                    int e = W.touched[b];
-                    A.xs_end[off + b] = e;
-                    A.xs_val[off + b] = W.acc[(size_t)e * 4];
-                }
-                if (lane == 0) A.xs_off[start] = (long long)off;
-            } else if (lane == 0) {
-                A.xs_off[start] = -1;
-            }
-        }
-        for (int b = lane; b < nt; b += 64) {
-            int e = W.touched[b];
-            double *a = W.acc + (size_t)e * 4;
-            a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
-        }
+        if (row < 0) cand_total += finalize_start(A, W.acc, W.touched, W.nt, start);
+        else if (lane == 0) A.unit_nt[unit] = W.nt;
     }
     if (lane == 0) {
         atomicAdd(&A.counters[0], cand_total);
         atomicAdd(&A.counters[1], W.paths);
     }
+}
+
+// heavy starts: add the G partial rows into the first one (double-double merge), then finalise
+__global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n_heavy) return;
+    const int lane = lane_id();
+    const int u0 = heavy_unit0[h];
+    const int start = A.unit_start[u0], G = A.unit_G[u0], r0 = A.unit_row[u0];
+    double *acc0 = A.hacc + (size_t)r0 * A.I * 4;
+    int *touched0 = A.htouched + (size_t)r0 * A.I;
+    int nt = A.unit_nt[u0];
+    for (int c = 1; c < G; c++) {
+        double *accc = A.hacc + (size_t)(r0 + c) * A.I * 4;
+        const int *tc = A.htouched + (size_t)(r0 + c) * A.I;
+        const int ntc = A.unit_nt[u0 + c];
+        for (int b0 = 0; b0 < ntc; b0 += 64) {
+            const int b = b0 + lane;
+            bool first = false;
+            int e = 0;
+            if (b < ntc) {
+                e = tc[b];
+                double *s = accc + (size_t)e * 4, *d = acc0 + (size_t)e * 4;
+                double s_hi = d[0], s_lo = d[1], c_hi = d[2], c_lo = d[3];
+                first = (c_hi == 0.0);
+                dd_add(s_hi, s_lo, s[0]); dd_add(s_hi, s_lo, s[1]);
+                dd_add(c_hi, c_lo, s[2]); dd_add(c_hi, c_lo, s[3]);
+                d[0] = s_hi; d[1] = s_lo; d[2] = c_hi; d[3] = c_lo;
+                s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+            }
+            unsigned long long m = __ballot(first);
+            if (first) touched0[nt + __popcll(m & lanemask_lt())] = e;
+            nt += __popcll(m);
+        }
+    }
+    int n = finalize_start(A, acc0, touched0, nt, start);
+    if (lane == 0) atomicAdd(&A.counters[0], (unsigned long long)n);
+}
+
+// ---- per-start path counts (scheduling weights): T(s) tails of s, sums over src(t), heads of x' -------------
+__global__ __launch_bounds__(256) void k_w_tails(int I, const long long *att_ptr, const int *att_idx, const int *kcnt,
+                                                 long long *T) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= I) return;
+    long long a0 = att_ptr[s], a1 = att_ptr[s + 1], t = 0;
+    for (long long ap = a0; ap < a1; ap++) t += 1 + kcnt[(size_t)att_idx[ap] * 2 + 1];
+    T[s] = (a1 > a0) ? t + 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_w_src(int I, const long long *src_ptr, const int *src_idx, const uint8_t *src_flag,
+                                               const long long *T, long long *ST_all, long long *ST_j) {
+    int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= I) return;
+    int lane = lane_id();
+    long long a = 0, j = 0;
+    for (long long p = src_ptr[t] + lane; p < src_ptr[t + 1]; p += 64) {
+        long long v = T[src_idx[p]];
+        a += v;
+        if (src_flag[p] & 1) j += v;
+    }
+    a = wave_sum_ll(a);
+    j = wave_sum_ll(j);
+    if (lane == 0) { ST_all[t] = a; ST_j[t] = j; }
+}
+__global__ __launch_bounds__(256) void k_w_heads(int I, int k, const uint8_t *cls, const int *kcnt, const int *kcol,
+                                                 const uint8_t *flags, const long long *ST_j, long long *HX) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= I) return;
+    long long h = 0;
+    if (cls[x] == 2) {
+        int nb = kcnt[(size_t)x * 2];
+        for (int q = 0; q < nb; q++) {
+            int t = kcol[((size_t)x * 2) * k + q];
+            if (flags[t] & 2) h += ST_j[t];
+        }
+    }
+    HX[x] = h;
+}
+__global__ __launch_bounds__(256) void k_w_starts(int I, const uint8_t *flags, const long long *rnn_ptr, const int *rnn_idx,
+                                                  const long long *ST_all, const long long *HX, long long *P) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= I) return;
+    long long p = ((flags[s] & 2) ? ST_all[s] : 0) + HX[s];
+    for (long long rp = rnn_ptr[s]; rp < rnn_ptr[s + 1]; rp++) p += HX[rnn_idx[rp]];
+    P[s] = p;
 }
 
 }  // namespace xmap
@@ -639,32 +750,65 @@ int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, c
     return XMAP_OK;
 }
 
-int xmap_extend_paths(void *stream, int32_t n_items, int top_k, int32_t start_lo, int32_t start_hi, const uint8_t *cls,
-                      const int32_t *kcnt, const int32_t *kcol, const double *kval, const uint8_t *flags,
-                      const int64_t *att_ptr, const int32_t *att_idx, const double *att_val, const int64_t *src_ptr,
-                      const int32_t *src_idx, const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr,
-                      const int32_t *rnn_idx, const double *rnn_val, int32_t n_slots, double *acc,
-                      int32_t *touched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+int xmap_path_weights(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                      const int64_t *src_ptr, const int32_t *src_idx, const uint8_t *src_flag, const int64_t *rnn_ptr,
+                      const int32_t *rnn_idx, int64_t *tmp /*[4][I]*/, int64_t *paths /*[I]*/) {
+    XM_ARG(cls && kcnt && kcol && flags && att_ptr && src_ptr && rnn_ptr && tmp && paths);
+    if (n_items == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    long long *T = (long long *)tmp, *STa = T + n_items, *STj = STa + n_items, *HX = STj + n_items;
+    unsigned g1 = (unsigned)((n_items + 255) / 256), g4 = (unsigned)((n_items + 3) / 4);
+    k_w_tails<<<dim3(g1), dim3(256), 0, st>>>(n_items, (const long long *)att_ptr, att_idx, kcnt, T);
+    XM_LAUNCH_CHECK();
+    k_w_src<<<dim3(g4), dim3(256), 0, st>>>(n_items, (const long long *)src_ptr, src_idx, src_flag, T, STa, STj);
+    XM_LAUNCH_CHECK();
+    k_w_heads<<<dim3(g1), dim3(256), 0, st>>>(n_items, top_k, cls, kcnt, kcol, flags, STj, HX);
+    XM_LAUNCH_CHECK();
+    k_w_starts<<<dim3(g1), dim3(256), 0, st>>>(n_items, flags, (const long long *)rnn_ptr, rnn_idx, STa, HX,
+                                                (long long *)paths);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
                       int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters) {
     XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && rnn_ptr);
     XM_ARG(acc && touched && n_cand && top_end && top_val && d_counters);
-    XM_ARG(n_slots > 0 && start_lo >= 0 && start_hi <= n_items);
+    XM_ARG(n_slots > 0 && n_units >= 0 && n_heavy >= 0);
+    XM_ARG(n_units == 0 || (unit_start && unit_c && unit_G && unit_row && unit_nt));
+    XM_ARG(n_heavy == 0 || (heavy_unit0 && hacc && htouched));
     XM_ARG(xs_cap == 0 || (xs_off && xs_end && xs_val));
     hipStream_t st = (hipStream_t)stream;
     XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
-    if (start_hi > start_lo) {
+    if (n_units > 0) {
         PathArgs A;
-        A.I = n_items; A.k = top_k; A.start_lo = start_lo; A.start_hi = start_hi;
+        A.I = n_items; A.k = top_k;
         A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval; A.flags = flags;
         A.att_ptr = (const long long *)att_ptr; A.att_idx = att_idx; A.att_val = att_val;
         A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
         A.rnn_ptr = (const long long *)rnn_ptr; A.rnn_idx = rnn_idx; A.rnn_val = rnn_val;
-        A.n_slots = n_slots; A.acc = acc; A.touched = touched;
+        A.n_units = n_units; A.unit_start = unit_start; A.unit_c = unit_c; A.unit_G = unit_G; A.unit_row = unit_row;
+        A.unit_nt = unit_nt;
+        A.n_slots = n_slots; A.acc = acc; A.touched = touched; A.hacc = hacc; A.htouched = htouched;
         A.n_cand = n_cand; A.top_end = top_end; A.top_val = top_val;
         A.xs_cap = xs_cap; A.xs_off = (long long *)xs_off; A.xs_end = xs_end; A.xs_val = xs_val;
         A.counters = (unsigned long long *)d_counters;
-        k_paths<<<dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st>>>(A);
+        int slots = n_slots < n_units ? n_slots : n_units;
+        A.n_slots = slots;
+        k_paths<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(A);
         XM_LAUNCH_CHECK();
+        if (n_heavy > 0) {
+            k_merge<<<dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, st>>>(A, n_heavy, heavy_unit0);
+            XM_LAUNCH_CHECK();
+        }
     }
     if (h_counters) {
         XM_HIP(hipMemcpyAsync(h_counters, d_counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -293,23 +293,72 @@ class Engine(object):
         check(lib.xmap_reverse_fill(st, *args, vp(rptr), vp(ridx), vp(rval), vp(rflag)))
         return rptr, ridx, rval, rflag, n
 
-    def extend(self, S, top_k, full=False, start_range=None, n_slots=None, xs_cap=None):
+    def path_units(self, E, start_range=None, chunk=None, row_budget=48 << 30):
+        """Work units of the path enumeration from the exact per-start path counts: starts with more than
+        `chunk` paths are split into G round-robin chunks with dedicated accumulator rows (merged on the
+        device afterwards); units are ordered heaviest first."""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        tmp = self._zeros(4 * max(I, 1), torch.int64)
+        P = self._zeros(max(I, 1), torch.int64)
+        with self.timed("path_weights"):
+            check(lib.xmap_path_weights(st, i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(R.flags),
+                                        vp(E.att[0]), vp(E.att[1]), vp(E.src[0]), vp(E.src[1]), vp(E.src[3]),
+                                        vp(E.rnn[0]), vp(E.rnn[1]), vp(tmp), vp(P)))
+        p = P.cpu().numpy()[:I].copy()
+        lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
+        p[:lo] = 0
+        p[hi:] = 0
+        total = int(p.sum())
+        if chunk is None:
+            chunk = max(1 << 22, total // 8192)
+        row_bytes = 36 * max(I, 1)
+        while True:
+            G = np.where(p > chunk, -(-p // chunk), 1).astype(np.int64)
+            G[p == 0] = 0
+            n_rows = int(G[G > 1].sum())
+            if n_rows * row_bytes <= row_budget or chunk > total:
+                break
+            chunk *= 2
+        starts = np.nonzero(G > 0)[0]
+        cost = p[starts] / np.maximum(G[starts], 1)
+        order = starts[np.argsort(-cost, kind="stable")]
+        g = G[order]
+        unit_start = np.repeat(order, g).astype(np.int32)
+        first = np.cumsum(g) - g
+        unit_c = (np.arange(len(unit_start)) - np.repeat(first, g)).astype(np.int32)
+        unit_G = np.repeat(g, g).astype(np.int32)
+        heavy = g > 1
+        row0 = np.cumsum(np.where(heavy, g, 0)) - np.where(heavy, g, 0)
+        unit_row = np.where(np.repeat(heavy, g), np.repeat(row0, g) + unit_c, -1).astype(np.int32)
+        heavy_unit0 = first[heavy].astype(np.int32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a if len(a) else np.zeros(1, a.dtype))).to(self.dev)
+        U = ExtResult()
+        U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = len(unit_start), int(heavy.sum()), n_rows, total, int(chunk)
+        U.unit_start, U.unit_c, U.unit_G, U.unit_row = t(unit_start), t(unit_c), t(unit_G), t(unit_row)
+        U.heavy_unit0 = t(heavy_unit0)
+        U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
+        return U
+
+    def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
         I = R.n_items
         E = self.knn(S, top_k)
         st = _stream(self.dev)
-        E.att = self._reverse(S, E, 0, None)
-        E.src = self._reverse(S, E, 1, E.att[0])
-        E.rnn = self._reverse(S, E, 2, None)
-        if n_slots is None:
-            n_slots = 2048
-            budget = 32 << 30  # bytes of per-start accumulator rows (36 B per item per slot)
-            n_slots = int(max(64, min(n_slots, budget // max(36 * I, 1))))
-        lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
-        n_slots = max(4, min(n_slots, ((hi - lo + 3) // 4) * 4 if hi > lo else 4))
+        with self.timed("reverse"):
+            E.att = self._reverse(S, E, 0, None)
+            E.src = self._reverse(S, E, 1, E.att[0])
+            E.rnn = self._reverse(S, E, 2, None)
+        U = self.path_units(E, start_range, chunk)
+        E.units = U
+        slot_budget = 48 << 30
+        n_slots = int(max(4, min(n_slots, slot_budget // (36 * max(I, 1)), max(U.n_units, 4))))
         acc = self._zeros(n_slots * max(I, 1) * 4, torch.float64)
         touched = self._empty(n_slots * max(I, 1), torch.int32)
+        hacc = self._zeros(max(U.n_rows, 1) * max(I, 1) * 4, torch.float64) if U.n_rows else None
+        htouched = self._empty(max(U.n_rows, 1) * max(I, 1), torch.int32) if U.n_rows else None
         E.n_cand = self._zeros(max(I, 1), torch.int32)
         E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=self.dev)
         E.top_val = self._zeros((max(I, 1), abi.TOPC), torch.float64)
@@ -323,13 +372,16 @@ class Engine(object):
             xs_end = self._empty(max(cap, 1), torch.int32) if cap else None
             xs_val = self._empty(max(cap, 1), torch.float64) if cap else None
             with self.timed("paths"):
-              rc = lib.xmap_extend_paths(
-                st, i32(I), E.k, i32(lo), i32(hi), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags),
-                vp(E.att[0]), vp(E.att[1]), vp(E.att[2]),
-                vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]),
-                vp(E.rnn[0]), vp(E.rnn[1]), vp(E.rnn[2]),
-                i32(n_slots), vp(acc), vp(touched), vp(E.n_cand), vp(E.top_end), vp(E.top_val),
-                i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
+                rc = lib.xmap_extend_paths(
+                    st, i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags),
+                    vp(E.att[0]), vp(E.att[1]), vp(E.att[2]),
+                    vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]),
+                    vp(E.rnn[0]), vp(E.rnn[1]), vp(E.rnn[2]),
+                    i32(U.n_units), vp(U.unit_start), vp(U.unit_c), vp(U.unit_G), vp(U.unit_row), vp(U.unit_nt),
+                    i32(U.n_heavy), vp(U.heavy_unit0),
+                    i32(n_slots), vp(acc), vp(touched), vp(hacc), vp(htouched),
+                    vp(E.n_cand), vp(E.top_end), vp(E.top_val),
+                    i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
             if rc == abi.ERR_CAPACITY:
                 cap = int(h_cnt[0])
                 continue
@@ -337,7 +389,7 @@ class Engine(object):
             break
         E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])
         E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val
-        E.start_range = (lo, hi)
+        E.start_range = (0, I) if start_range is None else tuple(start_range)
         return E
 
     # ------------------------------------------------------------------ stage C
