@@ -208,8 +208,18 @@ def test_determinism_and_partitions(dev):
     a = _sorted_sim(eng.item_sim("adjust_cosine", CAP))
     b = _sorted_sim(eng.item_sim("adjust_cosine", CAP))
     c = _sorted_sim(eng.item_sim("adjust_cosine", CAP, slot_target=48))  # many partitions per item
-    for x, y, z in zip(a, b, c):
-        assert np.array_equal(x, y) and np.array_equal(x, z)
+    d = _sorted_sim(eng.item_sim("adjust_cosine", CAP, algo="rows"))     # first formulation: complete rows
+    e = _sorted_sim(eng.item_sim("adjust_cosine", CAP, algo="rows", slot_target=48))
+    f = _sorted_sim(eng.item_sim_tri("adjust_cosine", CAP, ch_min=64))   # forces heavy rows + rater chunks
+    for x, y, z, w, v, t in zip(a, b, c, d, e, f):
+        assert np.array_equal(x, y) and np.array_equal(x, z) and np.array_equal(x, w) and np.array_equal(x, v)
+        assert np.array_equal(x, t)
+    for m in ("cosine",):
+        g = _sorted_sim(eng.item_sim(m, CAP))
+        h = _sorted_sim(eng.item_sim(m, CAP, algo="rows"))
+        k2 = _sorted_sim(eng.item_sim_tri(m, CAP, ch_min=64))
+        for x, y, z in zip(g, h, k2):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
     # stage B: heavy starts split into chunks with dedicated rows + device merge == one wave per start
     S = eng.item_sim("adjust_cosine", CAP)
     E1 = eng.extend(S, 5, full=True, chunk=1 << 40)

@@ -1,0 +1,556 @@
+// stage_a2.hip -- stage A, second formulation: every unordered item pair is computed ONCE, in the row of
+// its lighter item, and mirrored into the CSR afterwards (baseliner_calculate_sim_pipeline, reference
+// utils/assist.py:66-77; core/baselinerSim.py:176-216).  sim, mutu and n_ij are symmetric in the reference
+// bit for bit, and both directions are emitted by produce_pairwise_items (:182-183), so
+// computing the pair once and writing it twice is the same result.
+//
+// "Weight" of an item = (number of raters, index); the per-user private copy of each profile is sorted
+// heaviest first, so the partners a rater contributes to item i are exactly the PREFIX of its sorted
+// profile in front of i: no filtering in the inner loop, half the reads, and the heavier an item is the
+// fewer partners its row has (the heaviest rows, which dominate the first formulation's cost, become tiny).
+//
+//   k_hist / k_threshold / k_mark_heavy : rater-count histogram -> #items at least as heavy (bound on a row's
+//                                         distinct partners) and the set H of at most HMAX items with more
+//                                         than CH raters (dense ids)
+//   k_sort_profiles : per-user sort by weight, emits the rater records of every item (atomic cursors) and
+//                     W+_i = number of contributions of row i
+//   k_plan2 / k_fill_units2 : light units (item, hash partition), heavy units (item in H, chunk of CH raters)
+//   k_pair_tri      : light rows; wave-private LDS hash table as in stage_a.hip, rater records instead of a
+//                     dependent row_ptr hop, prefix-only profile reads; appends kept pairs to a half-COO
+//   k_pair_heavy    : rows of H, raters in chunks, DENSE LDS table over H, partial tables to HBM
+//   k_heavy_merge   : double-double merge of the chunk partials, finalise, append
+//   k_scatter       : mirror the half-COO into the CSR rows (atomic cursors)
+// Sums are exact (double-double, or integer-exact in cosine mode), so neither the order of raters nor the
+// chunking changes a bit of the result.
+#include "common.h"
+
+namespace xmap {
+
+constexpr int T_LOG_SLOTS = 10;
+constexpr int T_SLOTS = 1 << T_LOG_SLOTS;
+constexpr int HMAX = 1024;              // |H| <= HMAX: dense LDS table of the heavy kernel
+constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned long long wkey(int n, int item) {
+    return ((unsigned long long)(unsigned)n << 32) | (unsigned)item;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hist(int I, const long long *iptr, int HB, int *hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    long long n = iptr[i + 1] - iptr[i];
+    atomicAdd(&hist[n < HB - 1 ? (int)n : HB - 1], 1);
+}
+
+// pre[v] = #{items with n < v}.  CH = smallest v >= ch_min with #{n > v} <= HMAX.
+__global__ __launch_bounds__(256) void k_threshold(int I, int HB, const long long *pre, int ch_min, int *CH) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= HB - 1 || v < ch_min) return;
+    long long gt_v = I - pre[v + 1];
+    long long gt_prev = (v == ch_min) ? (long long)HMAX + 1 : I - pre[v];
+    if (gt_v <= HMAX && (v == ch_min || gt_prev > HMAX)) atomicMin(CH, v);
+}
+
+__global__ __launch_bounds__(256) void k_mark_heavy(int I, const long long *iptr, const int *CH, int *hid, int *hlist,
+                                                    int *n_heavy) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    long long n = iptr[i + 1] - iptr[i];
+    int h = -1;
+    if (n > *CH) {
+        h = atomicAdd(n_heavy, 1);
+        if (h < HMAX) hlist[h] = i;
+    }
+    hid[i] = h;
+}
+
+// one thread per user: private copy of the profile sorted heaviest first; rater records per item.
+__global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long long *uptr, const int *uitem,
+                                                       const float *urating, const long long *iptr, const double *info,
+                                                       unsigned long long *ub_key, int *ub_item, float *ub_rating,
+                                                       int *cur, int *rc_e0, int *rc_pos, float *rc_rating, int *rc_user,
+                                                       unsigned long long *Wp) {
+    long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const long long a = uptr[u], b = uptr[u + 1];
+    const int d = (int)(b - a);
+    // insertion sort by descending weight key into the private copy
+    for (int p = 0; p < d; p++) {
+        int it = uitem[a + p];
+        float r = urating[a + p];
+        unsigned long long key = wkey((int)(iptr[it + 1] - iptr[it]), it);
+        int q = p;
+        while (q > 0 && ub_key[a + q - 1] < key) {
+            ub_key[a + q] = ub_key[a + q - 1];
+            ub_item[a + q] = ub_item[a + q - 1];
+            ub_rating[a + q] = ub_rating[a + q - 1];
+            q--;
+        }
+        unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;   // rating >= item average
+        ub_key[a + q] = key;
+        ub_item[a + q] = (int)((unsigned)it | ge);
+        ub_rating[a + q] = r;
+    }
+    if (d < 2) return;  // users with >= 2 ratings only (baselinerSim.py:184-185)
+    for (int p = 0; p < d; p++) {
+        int iw = ub_item[a + p];
+        int it = iw & 0x7fffffff;
+        int slot = (int)iptr[it] + atomicAdd(&cur[it], 1);
+        rc_e0[slot] = (int)a;
+        rc_pos[slot] = (int)((unsigned)p | ((unsigned)iw & 0x80000000u));
+        rc_rating[slot] = ub_rating[a + p];
+        rc_user[slot] = (int)u;
+        if (p) atomicAdd(&Wp[it], (unsigned long long)p);
+    }
+}
+
+// light rows: Q partitions; heavy rows (in H): chunks of CH raters
+__global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const int *cur, const unsigned long long *Wp,
+                                               const long long *pre, int HB, const int *hid, const int *CH, int target,
+                                               int *Q, int *C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    long long n = iptr[i + 1] - iptr[i];
+    long long w = (long long)Wp[i];
+    long long ge = I - pre[n < HB - 1 ? n : HB - 1];   // #{items with at least as many raters}
+    long long bound = w < ge - 1 ? w : ge - 1;
+    int q = 0, c = 0;
+    if (w > 0) {
+        if (hid[i] >= 0) c = (cur[i] + *CH - 1) / *CH;
+        else q = (int)((bound + target - 1) / target);
+    }
+    Q[i] = q;
+    C[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Q, const long long *uq_ptr, int *uq_item, int *uq_q,
+                                                     const int *C, const long long *uc_ptr, int *uc_item, int *uc_c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    long long b = uq_ptr[i];
+    for (int k = 0; k < Q[i]; k++) { uq_item[b + k] = i; uq_q[b + k] = k; }
+    b = uc_ptr[i];
+    for (int k = 0; k < C[i]; k++) { uc_item[b + k] = i; uc_c[b + k] = k; }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct TriArgs {
+    const long long *iptr;
+    const int *cur;          // raters with >= 2 ratings per item
+    const int *rc_e0; const int *rc_pos; const float *rc_rating; const int *rc_user;
+    const int *ub_item; const float *ub_rating;
+    const double *u_avg; const double *info;
+    int cap;
+    // light
+    const int *Q; const int *uq_item; const int *uq_q; long long unit_lo, unit_hi;
+    // heavy
+    const int *hid; const int *hlist; const int *CH; const int *uc_item; const int *uc_c;
+    const long long *uc_ptr; const int *C;
+    double *hp_hi; double *hp_lo; int *hp_cnt; int *hp_mut;    // [heavy units][HMAX]
+    // output: half COO + per-row counts
+    long long coo_cap;
+    int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
+    int *rowcnt;
+    unsigned long long *counters;   // [0] coo cursor, [1] pairs evaluated (unordered), [2] overflow, [3] coo overflow
+};
+
+// cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207) for one accumulated pair
+template <int METHOD>
+__device__ __forceinline__ bool finish_pair(const TriArgs &A, int i, int j, int n, int m, double dot, double &simv) {
+    const int c1 = (METHOD == XMAP_COSINE) ? 1 : 2;
+    const double np = A.info[(size_t)i * 4 + c1] * A.info[(size_t)j * 4 + c1];
+    const double cs = (np != 0.0) ? 1.0 * dot / np : 0.0;
+    const int mn = n < A.cap ? n : A.cap;
+    simv = 1.0 * cs * (double)mn / (double)A.cap;
+    return (simv != 0.0) && (m != 0);
+}
+
+// append the kept pairs of one wave's table (callback gives slot -> pair) to the half COO
+template <typename Slot>
+__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slots, Slot slot) {
+    const int lane = lane_id();
+    int kept = 0, occ = 0;
+    for (int s0 = 0; s0 < n_slots; s0 += 64) {
+        int j, n, m; double sv; bool o;
+        bool keep = slot(s0 + lane, j, n, m, sv, o);
+        kept += __popcll(__ballot(keep));
+        occ += __popcll(__ballot(o));
+    }
+    if (lane == 0 && occ) atomicAdd(&A.counters[1], (unsigned long long)occ);
+    if (!kept) return;
+    unsigned long long base = 0;
+    if (lane == 0) {
+        base = atomicAdd(&A.counters[0], (unsigned long long)kept);
+        atomicAdd(&A.rowcnt[i], kept);
+    }
+    base = ((unsigned long long)(unsigned)rl32((int)(base >> 32), 0) << 32) | (unsigned)rl32((int)(base & 0xffffffffull), 0);
+    if ((long long)(base + kept) > A.coo_cap) {
+        if (lane == 0) atomicOr(&A.counters[3], 1ull);
+        return;
+    }
+    for (int s0 = 0; s0 < n_slots; s0 += 64) {
+        int j, n, m; double sv; bool o;
+        bool keep = slot(s0 + lane, j, n, m, sv, o);
+        unsigned long long km = __ballot(keep);
+        if (keep) {
+            long long p = (long long)base + __popcll(km & lanemask_lt());
+            A.coo_i[p] = i; A.coo_j[p] = j; A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
+            atomicAdd(&A.rowcnt[j], 1);
+        }
+        base += __popcll(km);
+    }
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
+    __shared__ uint32_t key[T_SLOTS];
+    __shared__ uint32_t cnt[T_SLOTS];
+    __shared__ uint32_t mut[T_SLOTS];
+    __shared__ double dot[T_SLOTS];
+    __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? T_SLOTS : 1];
+
+    const int lane = lane_id();
+    const long long unit = A.unit_lo + blockIdx.x;
+    if (unit >= A.unit_hi) return;
+    for (int s = lane; s < T_SLOTS; s += 64) {
+        key[s] = T_EMPTY; cnt[s] = 0; mut[s] = 0; dot[s] = 0.0;
+        if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
+    }
+    const int i = uniform(A.uq_item[unit]);
+    const int q = uniform(A.uq_q[unit]);
+    const int Qi = uniform(A.Q[i]);
+    const int p0 = uniform((int)A.iptr[i]);
+    const int p1 = p0 + uniform(A.cur[i]);
+    int ovf = 0;
+    for (int base = p0; base < p1; base += 64) {
+        const int p = base + lane;
+        int e0 = 0, pw = 0;
+        float r = 0.f;
+        double au = 0.0;
+        if (p < p1) {
+            e0 = A.rc_e0[p];
+            pw = A.rc_pos[p];
+            r = A.rc_rating[p];
+            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[A.rc_user[p]];
+        }
+        const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
+        // prefetch the next rater's first 64 prefix entries
+        int nb0 = rl32(e0, 0), nb1 = nb0 + (rl32(pw, 0) & 0x7fffffff);
+        int njw = 0;
+        float nrj = 0.f;
+        if (nb0 + lane < nb1) { njw = A.ub_item[nb0 + lane]; nrj = A.ub_rating[nb0 + lane]; }
+        for (int t = 0; t < nr; ++t) {
+            const int b0 = nb0, b1 = nb1;
+            int jw = njw;
+            float rj = nrj;
+            const unsigned gei = ((unsigned)rl32(pw, t)) >> 31;
+            if (t + 1 < nr) {
+                nb0 = rl32(e0, t + 1);
+                nb1 = nb0 + (rl32(pw, t + 1) & 0x7fffffff);
+                if (nb0 + lane < nb1) { njw = A.ub_item[nb0 + lane]; nrj = A.ub_rating[nb0 + lane]; }
+            }
+            if (b1 == b0) continue;
+            const double ri = (double)rlf(r, t);
+            const double a = (METHOD == XMAP_ADJUST_COSINE) ? rld(au, t) : 0.0;
+            for (int c0 = b0; c0 < b1; c0 += 64) {
+                const int e = c0 + lane;
+                if (c0 != b0 && e < b1) { jw = A.ub_item[e]; rj = A.ub_rating[e]; }
+                if (e < b1) {
+                    const int j = jw & 0x7fffffff;
+                    bool mine = true;
+                    if (Qi > 1) mine = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
+                    if (mine) {
+                        uint32_t h = ((uint32_t)j * 0x9E3779B1u) >> (32 - T_LOG_SLOTS);
+                        int probes = 0;
+                        bool ok = true;
+                        for (;;) {
+                            uint32_t prev = atomicCAS(&key[h], T_EMPTY, (uint32_t)j);
+                            if (prev == T_EMPTY || prev == (uint32_t)j) break;
+                            h = (h + 1) & (T_SLOTS - 1);
+                            if (++probes >= T_SLOTS) { ok = false; break; }
+                        }
+                        if (ok) {
+                            cnt[h] += 1;
+                            mut[h] += ((((unsigned)jw) >> 31) == gei) ? 1u : 0u;
+                            if (METHOD == XMAP_COSINE) {
+                                dot[h] += (1.0 * ri) * (double)rj;
+                            } else {
+                                double hi = dot[h], lo = dlo[h];
+                                dd_add(hi, lo, (ri - a) * ((double)rj - a));
+                                dot[h] = hi; dlo[h] = lo;
+                            }
+                        } else {
+                            ovf = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (__ballot(ovf)) {
+        if (lane == 0) atomicOr(&A.counters[2], 1ull);
+        return;
+    }
+    append_pairs(A, i, T_SLOTS, [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
+        uint32_t kj = key[s];
+        o = kj != T_EMPTY;
+        if (!o) return false;
+        j = (int)kj; n = (int)cnt[s]; m = (int)mut[s];
+        return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
+    });
+}
+
+// rows of H: chunk c of the raters, dense table over H (partners of a heavy row are heavier, hence in H)
+template <int METHOD>
+__global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
+    __shared__ uint32_t cnt[HMAX];
+    __shared__ uint32_t mut[HMAX];
+    __shared__ double dot[HMAX];
+    __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? HMAX : 1];
+    const int lane = lane_id();
+    const int unit = blockIdx.x;
+    for (int s = lane; s < HMAX; s += 64) {
+        cnt[s] = 0; mut[s] = 0; dot[s] = 0.0;
+        if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
+    }
+    const int i = uniform(A.uc_item[unit]);
+    const int c = uniform(A.uc_c[unit]);
+    const int CH = uniform(*A.CH);
+    const int base0 = uniform((int)A.iptr[i]);
+    const int p0 = base0 + c * CH;
+    int p1 = base0 + uniform(A.cur[i]);
+    if (p0 + CH < p1) p1 = p0 + CH;
+    for (int base = p0; base < p1; base += 64) {
+        const int p = base + lane;
+        int e0 = 0, pw = 0;
+        float r = 0.f;
+        double au = 0.0;
+        if (p < p1) {
+            e0 = A.rc_e0[p]; pw = A.rc_pos[p]; r = A.rc_rating[p];
+            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[A.rc_user[p]];
+        }
+        const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
+        for (int t = 0; t < nr; ++t) {
+            const int b0 = rl32(e0, t), b1 = b0 + (rl32(pw, t) & 0x7fffffff);
+            const unsigned gei = ((unsigned)rl32(pw, t)) >> 31;
+            const double ri = (double)rlf(r, t);
+            const double a = (METHOD == XMAP_ADJUST_COSINE) ? rld(au, t) : 0.0;
+            for (int e = b0 + lane; e < b1; e += 64) {
+                const int jw = A.ub_item[e];
+                const float rj = A.ub_rating[e];
+                const int h = A.hid[jw & 0x7fffffff];
+                cnt[h] += 1;
+                mut[h] += ((((unsigned)jw) >> 31) == gei) ? 1u : 0u;
+                if (METHOD == XMAP_COSINE) {
+                    dot[h] += (1.0 * ri) * (double)rj;
+                } else {
+                    double hi = dot[h], lo = dlo[h];
+                    dd_add(hi, lo, (ri - a) * ((double)rj - a));
+                    dot[h] = hi; dlo[h] = lo;
+                }
+            }
+        }
+    }
+    for (int s = lane; s < HMAX; s += 64) {
+        size_t o = (size_t)unit * HMAX + s;
+        A.hp_cnt[o] = (int)cnt[s];
+        A.hp_mut[o] = (int)mut[s];
+        A.hp_hi[o] = dot[s];
+        A.hp_lo[o] = (METHOD == XMAP_ADJUST_COSINE) ? dlo[s] : 0.0;
+    }
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(64) void k_heavy_merge(TriArgs A, int n_heavy) {
+    __shared__ uint32_t cnt[HMAX];
+    __shared__ uint32_t mut[HMAX];
+    __shared__ double dot[HMAX];
+    const int lane = lane_id();
+    const int h = blockIdx.x;
+    if (h >= n_heavy) return;
+    const int i = A.hlist[h];
+    const int nc = A.C[i];
+    const long long u0 = A.uc_ptr[i];
+    for (int s = lane; s < HMAX; s += 64) {
+        unsigned cn = 0, mu = 0;
+        double hi = 0.0, lo = 0.0;
+        for (int c = 0; c < nc; c++) {
+            size_t o = (size_t)(u0 + c) * HMAX + s;
+            cn += (unsigned)A.hp_cnt[o];
+            mu += (unsigned)A.hp_mut[o];
+            if (METHOD == XMAP_COSINE) {
+                hi += A.hp_hi[o];
+            } else {
+                dd_add(hi, lo, A.hp_hi[o]);
+                dd_add(hi, lo, A.hp_lo[o]);
+            }
+        }
+        cnt[s] = cn; mut[s] = mu; dot[s] = hi;
+    }
+    if (nc == 0) return;
+    append_pairs(A, i, HMAX, [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
+        o = cnt[s] != 0;
+        if (!o) return false;
+        j = A.hlist[s]; n = (int)cnt[s]; m = (int)mut[s];
+        return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
+    });
+}
+
+__global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, const int *coo_j, const double *coo_sim,
+                                                 const int *coo_mutu, const int *coo_nij, const long long *row_ptr,
+                                                 int *fill, int *col, double *sim, int *mutu, int *nij) {
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int i = coo_i[r], j = coo_j[r];
+    const double s = coo_sim[r];
+    const int m = coo_mutu[r], nn = coo_nij[r];
+    long long a = row_ptr[i] + atomicAdd(&fill[i], 1);
+    col[a] = j; sim[a] = s; mutu[a] = m; nij[a] = nn;
+    long long b = row_ptr[j] + atomicAdd(&fill[j], 1);
+    col[b] = i; sim[b] = s; mutu[b] = m; nij[b] = nn;
+}
+
+}  // namespace xmap
+
+using namespace xmap;
+
+extern "C" {
+
+int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
+                     int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]: CH, n_heavy*/, int32_t *hid, int32_t *hlist /*[1024]*/,
+                     uint64_t *ub_key, int32_t *ub_item, float *ub_rating, int32_t *cur, int32_t *rc_e0, int32_t *rc_pos,
+                     float *rc_rating, int32_t *rc_user, uint64_t *Wp, int32_t *h_ctl /*[2]*/) {
+    XM_ARG(R && info && hist && pre && ctl && hid && hlist && ub_key && ub_item && ub_rating && cur);
+    XM_ARG(rc_e0 && rc_pos && rc_rating && rc_user && Wp && ch_min >= 64);
+    XM_ARG(R->nnz < 0x7fffffffLL && R->n_users < 0x7ffffff0LL);
+    hipStream_t st = (hipStream_t)stream;
+    const int I = R->n_items;
+    const int HB = (int)R->n_users + 2;
+    XM_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)HB, st));
+    XM_HIP(hipMemsetAsync(cur, 0, sizeof(int32_t) * (size_t)(I > 0 ? I : 1), st));
+    XM_HIP(hipMemsetAsync(Wp, 0, sizeof(uint64_t) * (size_t)(I > 0 ? I : 1), st));
+    XM_HIP(hipMemsetAsync(ctl, 0x7f, sizeof(int32_t), st));          // CH = 0x7f7f7f7f: "no heavy rows"
+    XM_HIP(hipMemsetAsync(ctl + 1, 0, 3 * sizeof(int32_t), st));
+    if (I > 0) {
+        k_hist<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, (const long long *)R->item_ptr, HB, hist);
+        XM_LAUNCH_CHECK();
+    }
+    int rc = xmap_exclusive_scan_i32_to_i64(stream, hist, pre, HB, nullptr);
+    if (rc) return rc;
+    if (HB - 1 > ch_min) {
+        k_threshold<<<dim3((unsigned)((HB + 255) / 256)), dim3(256), 0, st>>>(I, HB, (const long long *)pre, ch_min, ctl);
+        XM_LAUNCH_CHECK();
+    }
+    if (I > 0) {
+        k_mark_heavy<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, (const long long *)R->item_ptr, ctl, hid,
+                                                                                hlist, ctl + 1);
+        XM_LAUNCH_CHECK();
+    }
+    if (R->n_users > 0) {
+        k_sort_profiles<<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, st>>>(
+            R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->item_ptr, info,
+            (unsigned long long *)ub_key, ub_item, ub_rating, cur, rc_e0, rc_pos, rc_rating, rc_user,
+            (unsigned long long *)Wp);
+        XM_LAUNCH_CHECK();
+    }
+    if (h_ctl) {
+        XM_HIP(hipMemcpyAsync(h_ctl, ctl, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        XM_HIP(hipStreamSynchronize(st));
+        if (h_ctl[1] > HMAX) {
+            set_error("heavy set larger than %d", HMAX);
+            return XMAP_ERR_OVERFLOW;
+        }
+    }
+    return XMAP_OK;
+}
+
+int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int32_t *cur, const uint64_t *Wp,
+                   const int64_t *pre, const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, int64_t *uq_ptr,
+                   int64_t *uc_ptr, int64_t *h_counts /*[2]: light units, heavy units*/) {
+    XM_ARG(R && cur && Wp && pre && hid && ctl && Q && C && uq_ptr && uc_ptr && h_counts);
+    XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
+    hipStream_t st = (hipStream_t)stream;
+    const int I = R->n_items;
+    if (I > 0) {
+        k_plan2<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(
+            I, (const long long *)R->item_ptr, cur, (const unsigned long long *)Wp, (const long long *)pre,
+            (int)R->n_users + 2, hid, ctl, slot_target, Q, C);
+        XM_LAUNCH_CHECK();
+    }
+    int rc = xmap_exclusive_scan_i32_to_i64(stream, Q, uq_ptr, I, &h_counts[0]);
+    if (rc) return rc;
+    return xmap_exclusive_scan_i32_to_i64(stream, C, uc_ptr, I, &h_counts[1]);
+}
+
+int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64_t *uq_ptr, int32_t *uq_item,
+                    int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c) {
+    XM_ARG(Q && uq_ptr && uq_item && uq_q && C && uc_ptr && uc_item && uc_c);
+    if (n_items == 0) return XMAP_OK;
+    k_fill_units2<<<dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        n_items, Q, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *info,
+                    const int32_t *cur, const int32_t *rc_e0, const int32_t *rc_pos, const float *rc_rating,
+                    const int32_t *rc_user, const int32_t *ub_item, const float *ub_rating, const int32_t *Q,
+                    const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
+                    const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
+                    const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int do_heavy,
+                    double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
+                    int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
+                    int64_t *d_counters /*[4]*/) {
+    XM_ARG(R && u_avg && info && cur && rc_e0 && rc_pos && rc_rating && rc_user && ub_item && ub_rating);
+    XM_ARG(Q && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
+    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && d_counters && coo_cap >= 0);
+    XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
+    XM_ARG(n_heavy_units == 0 || !do_heavy || (hp_hi && hp_lo && hp_cnt && hp_mut));
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+    XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
+    TriArgs A;
+    memset(&A, 0, sizeof(A));
+    A.iptr = (const long long *)R->item_ptr; A.cur = cur;
+    A.rc_e0 = rc_e0; A.rc_pos = rc_pos; A.rc_rating = rc_rating; A.rc_user = rc_user;
+    A.ub_item = ub_item; A.ub_rating = ub_rating; A.u_avg = u_avg; A.info = info; A.cap = cap;
+    A.Q = Q; A.uq_item = uq_item; A.uq_q = uq_q; A.unit_lo = unit_lo; A.unit_hi = unit_hi;
+    A.hid = hid; A.hlist = hlist; A.CH = ctl; A.uc_item = uc_item; A.uc_c = uc_c;
+    A.uc_ptr = (const long long *)uc_ptr; A.C = C;
+    A.hp_hi = hp_hi; A.hp_lo = hp_lo; A.hp_cnt = hp_cnt; A.hp_mut = hp_mut;
+    A.coo_cap = coo_cap; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
+    A.rowcnt = rowcnt; A.counters = (unsigned long long *)d_counters;
+    if (do_heavy && n_heavy_units > 0) {   // heavy rows first: they are the long units
+        if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
+        else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
+        XM_LAUNCH_CHECK();
+    }
+    if (unit_hi > unit_lo) {
+        dim3 grid((unsigned)(unit_hi - unit_lo));
+        if (method == XMAP_COSINE) k_pair_tri<XMAP_COSINE><<<grid, dim3(64), 0, st>>>(A);
+        else k_pair_tri<XMAP_ADJUST_COSINE><<<grid, dim3(64), 0, st>>>(A);
+        XM_LAUNCH_CHECK();
+    }
+    if (do_heavy && n_heavy_units > 0 && n_heavy > 0) {
+        if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
+        else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
+
+int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
+                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *row_ptr,
+                      int32_t *fill /*[I] scratch*/, int32_t *col, double *sim, int32_t *mutu, int32_t *nij) {
+    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && row_ptr && fill && col && sim && mutu && nij);
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
+    if (n_coo > 0) {
+        k_scatter<<<dim3((unsigned)((n_coo + 255) / 256)), dim3(256), 0, st>>>(
+            n_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, (const long long *)row_ptr, fill, col, sim, mutu, nij);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
+}

@@ -160,8 +160,11 @@ class Engine(object):
         n = (R.item_ptr[1:] - R.item_ptr[:-1])
         return n * Pn.Q[:R.n_items].to(torch.int64)
 
-    def item_sim(self, method, cap, slot_target=640, item_range=None, stats=None, plan=None):
-        """baseliner_calculate_sim_pipeline for the rows in item_range (default: all)."""
+    def item_sim(self, method, cap, slot_target=640, item_range=None, stats=None, plan=None, algo="tri"):
+        """baseliner_calculate_sim_pipeline.  algo "tri" (default): each unordered pair once + mirror
+        (stage_a2.hip); algo "rows": complete rows per unit (stage_a.hip), supports item_range."""
+        if algo == "tri" and item_range is None and plan is None:
+            return self.item_sim_tri(method, cap, slot_target)
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -217,6 +220,138 @@ class Engine(object):
         S.c = abi.Sim(I, row_ptr.data_ptr(), col.data_ptr(), sim.data_ptr(), mutu.data_ptr(), nij.data_ptr(),
                       info.data_ptr(), 0)
         S._keep = (col, sim, mutu, nij)
+        return S
+
+    # ---- stage A, second formulation (stage_a2.hip): each unordered pair once, mirrored into the CSR
+    def tri_layout(self, stats, slot_target=640, ch_min=1024):
+        """weight-sorted private profiles, rater records, heavy set, work units (method independent)"""
+        R = self.R
+        st = _stream(self.dev)
+        I, U, nnz = R.n_items, R.n_users, R.nnz
+        info = stats[2]
+        L = SimResult()
+        L.hist = self._empty(U + 2, torch.int32)
+        L.pre = self._empty(U + 3, torch.int64)
+        L.ctl = self._empty(4, torch.int32)
+        L.hid = self._empty(max(I, 1), torch.int32)
+        L.hlist = self._zeros(1024, torch.int32)
+        L.ub_key = self._empty(max(nnz, 1), torch.int64)
+        L.ub_item = self._empty(max(nnz, 1), torch.int32)
+        L.ub_rating = self._empty(max(nnz, 1), torch.float32)
+        L.cur = self._empty(max(I, 1), torch.int32)
+        L.rc_e0 = self._empty(max(nnz, 1), torch.int32)
+        L.rc_pos = self._empty(max(nnz, 1), torch.int32)
+        L.rc_rating = self._empty(max(nnz, 1), torch.float32)
+        L.rc_user = self._empty(max(nnz, 1), torch.int32)
+        L.Wp = self._empty(max(I, 1), torch.int64)
+        h_ctl = (C.c_int32 * 2)()
+        with self.timed("tri_layout"):
+            check(lib.xmap_sim2_layout(st, C.byref(R.c), vp(info), i32(ch_min), vp(L.hist), vp(L.pre), vp(L.ctl),
+                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub_item), vp(L.ub_rating),
+                                       vp(L.cur), vp(L.rc_e0), vp(L.rc_pos), vp(L.rc_rating), vp(L.rc_user),
+                                       vp(L.Wp), h_ctl))
+        L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
+        L.slot_target = slot_target
+        self._tri_plan(L, slot_target)
+        L.half_contrib = int(L.Wp[:I].sum().item()) if I else 0
+        return L
+
+    def _tri_plan(self, L, slot_target):
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        L.Q = self._zeros(max(I, 1), torch.int32)
+        L.C = self._zeros(max(I, 1), torch.int32)
+        L.uq_ptr = self._zeros(I + 1, torch.int64)
+        L.uc_ptr = self._zeros(I + 1, torch.int64)
+        h = (C.c_int64 * 2)()
+        with self.timed("tri_plan"):
+            check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.cur), vp(L.Wp), vp(L.pre), vp(L.hid),
+                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.uq_ptr), vp(L.uc_ptr), h))
+            L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
+            L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
+            L.uq_q = self._empty(max(L.n_light, 1), torch.int32)
+            L.uc_item = self._empty(max(L.n_heavy_units, 1), torch.int32)
+            L.uc_c = self._empty(max(L.n_heavy_units, 1), torch.int32)
+            check(lib.xmap_sim2_units(st, i32(I), vp(L.Q), vp(L.uq_ptr), vp(L.uq_item), vp(L.uq_q),
+                                      vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
+        L.slot_target = slot_target
+
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True):
+        """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows)"""
+        R = self.R
+        st = _stream(self.dev)
+        m = abi.METHODS[method] if isinstance(method, str) else int(method)
+        u_avg, u_norm, info, _, _ = stats
+        I = R.n_items
+        while True:
+            lo, hi = (0, L.n_light) if unit_range is None else (int(unit_range[0]), int(unit_range[1]))
+            cap_coo = max(L.half_contrib, 1)
+            coo_i = self._empty(cap_coo, torch.int32)
+            coo_j = self._empty(cap_coo, torch.int32)
+            coo_sim = self._empty(cap_coo, torch.float64)
+            coo_mutu = self._empty(cap_coo, torch.int32)
+            coo_nij = self._empty(cap_coo, torch.int32)
+            rowcnt = self._empty(max(I, 1), torch.int32)
+            nh = L.n_heavy_units if do_heavy else 0
+            hp_hi = self._empty(max(nh, 1) * 1024, torch.float64)
+            hp_lo = self._empty(max(nh, 1) * 1024, torch.float64)
+            hp_cnt = self._empty(max(nh, 1) * 1024, torch.int32)
+            hp_mut = self._empty(max(nh, 1) * 1024, torch.int32)
+            d_cnt = self._zeros(4, torch.int64)
+            with self.timed("pair_tri"):
+                check(lib.xmap_sim2_pairs(
+                    st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(L.cur), vp(L.rc_e0), vp(L.rc_pos),
+                    vp(L.rc_rating), vp(L.rc_user), vp(L.ub_item), vp(L.ub_rating), vp(L.Q), vp(L.uq_item),
+                    vp(L.uq_q), i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
+                    vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), 1 if do_heavy else 0,
+                    vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
+                    vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(d_cnt)))
+            h = d_cnt.tolist()
+            if h[2]:
+                if L.slot_target <= 32:
+                    raise abi.XmapError(abi.ERR_OVERFLOW, "pair-table overflow")
+                self._tri_plan(L, L.slot_target // 2)
+                continue
+            if h[3]:
+                raise abi.XmapError(abi.ERR_CAPACITY, "half-COO overflow")
+            break
+        n = int(h[0])
+        return (coo_i[:n], coo_j[:n], coo_sim[:n], coo_mutu[:n], coo_nij[:n]), rowcnt, n, int(h[1])
+
+    def tri_scatter(self, coo, rowcnt, info):
+        """mirror a (complete) half COO into the CSR"""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo]
+        n = int(coo_i.numel())
+        row_ptr = self._zeros(I + 1, torch.int64)
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rowcnt), vp(row_ptr), i64(I), None))
+        kept = 2 * n
+        col = self._empty(max(kept, 1), torch.int32)
+        sim = self._empty(max(kept, 1), torch.float64)
+        mutu = self._empty(max(kept, 1), torch.int32)
+        nij = self._empty(max(kept, 1), torch.int32)
+        fill = self._empty(max(I, 1), torch.int32)
+        with self.timed("scatter"):
+          if n:
+            check(lib.xmap_sim2_scatter(st, i32(I), i64(n), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu),
+                                        vp(coo_nij), vp(row_ptr), vp(fill), vp(col), vp(sim), vp(mutu), vp(nij)))
+        return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
+
+    def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
+        """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU)."""
+        with self.timed("stats"):
+            stats = self.stats()
+        L = self.tri_layout(stats, slot_target, ch_min)
+        coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
+        S = self.tri_scatter(coo, rowcnt, stats[2])
+        S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
+        S.cap = int(cap)
+        S.u_avg, S.u_norm = stats[0], stats[1]
+        S.n_eval, S.n_contrib = 2 * n_unordered, 2 * L.half_contrib
+        S.n_units, S.layout, S.slot_target = L.n_light + L.n_heavy_units, L, L.slot_target
         return S
 
     def sim_from_device(self, row_ptr, col, sim, mutu, nij, info):
