@@ -41,6 +41,15 @@ def workloads():
     }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
 def cpu_baseline(r, attrs, method, target_s=15.0, threads=4):
     """Oracle (CPU restatement, `port`) timed on this host on a bounded row sample of the same workload."""
     from oracle import xmap_oracle as xo
@@ -79,6 +88,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("XMAP_DIST_BACKEND", "nccl") != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if args.gpus > 1 and world == 1:
         log("bench.py: --gpus %d needs torch.distributed.run; running 1 rank" % args.gpus)
     dist = None
@@ -86,7 +97,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("XMAP_DIST_BACKEND", "nccl")   # "gloo": rehearsal with several ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
 
@@ -134,11 +149,16 @@ def main():
 
     if rank == 0:
         D, Dk, P, nnz, I = res["n_eval"], res["n_kept"], res["n_contrib"], r.nnz, r.n_items
-        # dominant kernel: k_pair_sim (fill launch); algorithmic bytes per launch, SURVEY.md 8d:
-        #   8 B per directed co-rating contribution + CSR and CSC read once + item stats + kept pairs written
-        fill_ms = float(np.mean(tm.get("pair_fill", [0.0])))
-        bytes_fill = 8.0 * res["n_contrib_local"] + 16.0 * nnz + 32.0 * I + 20.0 * res["n_kept_local"]
-        ach = bytes_fill / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+        # Stage-A dominant kernel: k_pair_tri (one launch per step).  Algorithmic bytes per launch (SURVEY.md 8d,
+        # DESIGN.md 4): 8 B per directed co-rating contribution it processes + CSR and rater records read once
+        # (16 B per rating) + item stats (32 B per item) + the kept pairs it emits (24 B per unordered pair).
+        tri_ms = float(np.mean(tm.get("pair_tri", [0.0])))
+        bytes_tri = 8.0 * res["n_contrib_light"] + 16.0 * nnz + 32.0 * I + 12.0 * res["n_kept_local"]
+        ach = bytes_tri / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
+        # Stage-B dominant kernel: k_paths.  Compulsory HBM bytes are the knn tables + the outputs (SURVEY.md 8d:
+        # 12 E + 12 N_out); it is latency / random-access bound, paths/s is the figure of merit.
+        paths_ms = float(np.mean(tm.get("paths", [0.0])))
+        bytes_paths = 12.0 * res["knn_entries"] + 12.0 * res["n_out"]
         out = {
             "metric": "item_sim_pairs_per_s", "value": D / t_a if t_a > 0 else 0.0, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -152,9 +172,15 @@ def main():
             "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
             "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},
             "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
-            "roofline": {"bound": "hbm", "kernel": "k_pair_sim<fill>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": bytes_fill, "launch_ms": fill_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_pair_tri", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_pair_tri"),
+                         "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms},
+            "roofline_stage_b": {"bound": "hbm", "kernel": "k_paths", "achieved": bytes_paths / (paths_ms * 1e-3) / 1e9
+                                 if paths_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (bytes_paths / (paths_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if paths_ms > 0 else 0.0,
+                                 "traffic": pmc_traffic("k_paths"), "algorithmic_bytes_per_launch": bytes_paths,
+                                 "launch_ms": paths_ms, "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                                 "note": "latency/random-access bound: 32 B double-double read-modify-write per path"},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(r, attrs, args.method)

@@ -111,7 +111,8 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
  *            them), W+[i] contributions per row, the heavy set H = items with more than CH raters (|H| <= 1024;
  *            ctl[0] = CH >= ch_min, ctl[1] = |H|), pre[v] = #items with fewer than v raters.
  *   plan   : Q[i] hash partitions for light rows, C[i] rater chunks for rows of H; exclusive scans uq_ptr / uc_ptr.
- *   pairs  : light units [unit_lo, unit_hi) (+ all heavy rows if do_heavy): kept pairs (i lighter, j heavier) ->
+ *   pairs  : phases bit 8 = reset counters/rowcnt, 1 = k_pair_heavy (chunk partials of the rows of H), 2 = k_pair_tri
+ *            (light units [unit_lo, unit_hi)), 4 = k_heavy_merge; kept pairs (i lighter, j heavier) ->
  *            half COO (coo_cap entries), rowcnt[i]++ / rowcnt[j]++; d_counters[0] = COO entries, [1] = unordered
  *            pairs evaluated, [2] = table overflow, [3] = COO overflow.
  *   scatter: after an exclusive scan of rowcnt -> row_ptr, both directions of every COO entry into the CSR. */
@@ -130,7 +131,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     const int32_t *rc_user, const int32_t *ub_item, const float *ub_rating, const int32_t *Q,
                     const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
-                    const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int do_heavy,
+                    const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
                     int64_t *d_counters /*[4]*/);

@@ -1,0 +1,58 @@
+"""world_size-2 gloo test (CPU) of the collectives wrapper the sharded step uses (xmap.engine.sharded.Comm):
+variable-length all-gather in rank order, all-reduce sum/max, and the shard planning being identical on all ranks."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmap.engine.sharded import Comm, balanced_ranges
+    comm = Comm(dist)
+    # the half-COO parts of two ranks: different lengths, including an empty one
+    part = torch.arange(3 * rank, dtype=torch.int32) + 100 * rank
+    allp = comm.all_gather_var(part)
+    val = comm.all_gather_var(torch.full((2 - rank,), float(rank), dtype=torch.float64))
+    cnt = torch.tensor([1, 2, 3], dtype=torch.int32) * (rank + 1)
+    comm.all_reduce(cnt)
+    top = torch.full((4,), -1, dtype=torch.int32)
+    top[rank * 2:(rank + 1) * 2] = rank + 7
+    comm.all_reduce(top, "max")
+    w = np.array([4, 1, 1, 1, 1, 4, 2, 2])
+    q.put((rank, allp.tolist(), val.tolist(), cnt.tolist(), top.tolist(), balanced_ranges(w, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, allp, val, cnt, top, ranges in got:
+        assert allp == [100, 101, 102]            # rank 0 contributed nothing, rank 1 three entries
+        assert val == [0.0, 0.0, 1.0]
+        assert cnt == [3, 6, 9]
+        assert top == [7, 7, 8, 8]
+        assert ranges == [(0, 5), (5, 8)]

@@ -1,0 +1,71 @@
+"""The item-sharded step (xmap.engine.sharded.run_step with world_size 2, gloo collectives, both ranks on the
+one GPU of the test box) must give exactly the single-rank result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _summary(res):
+    S, E, G = res["S"], res["E"], res["G"]
+    rp = S.row_ptr.cpu().numpy()
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    col = S.col.cpu().numpy()
+    o = np.lexsort((col, rows))
+    return dict(n_eval=res["n_eval"], n_kept=res["n_kept"], n_paths=res["n_paths"], n_rows=res["n_rows"],
+                n_profiles=res["n_profiles"], row_ptr=rp, col=col[o], sim=S.sim.cpu().numpy()[o],
+                n_cand=E.n_cand.cpu().numpy(), top_end=E.top_end.cpu().numpy(), top_val=E.top_val.cpu().numpy(),
+                choice=res["choice"].cpu().numpy(), map=res["map"].cpu().numpy(),
+                ae_user=G.user.cpu().numpy(), ae_item=G.item.cpu().numpy(), ae_rating=G.rating.cpu().numpy())
+
+
+def _engine():
+    from xmap.engine import synth, device
+    r = synth.make_two_domain(21, 4000, 700, 700)
+    return device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs()))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmap.engine import sharded
+    res = sharded.run_step(_engine(), "adjust_cosine", 50, 5, True, dist, rank, world)
+    q.put((rank, _summary(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_equals_world1():
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    from xmap.engine import sharded
+    ref = _summary(sharded.run_step(_engine(), "adjust_cosine", 50, 5, True))
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ref["n_kept"] > 0 and ref["n_paths"] > 0 and ref["n_rows"] > 0
+    for rank, out in got:
+        for key, v in ref.items():
+            assert np.array_equal(out[key], v), (rank, key)

@@ -498,7 +498,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     const int32_t *rc_user, const int32_t *ub_item, const float *ub_rating, const int32_t *Q,
                     const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
-                    const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int do_heavy,
+                    const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
                     int64_t *d_counters /*[4]*/) {
@@ -506,10 +506,12 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     XM_ARG(Q && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && d_counters && coo_cap >= 0);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
-    XM_ARG(n_heavy_units == 0 || !do_heavy || (hp_hi && hp_lo && hp_cnt && hp_mut));
+    XM_ARG(n_heavy_units == 0 || !(phases & 5) || (hp_hi && hp_lo && hp_cnt && hp_mut));
     hipStream_t st = (hipStream_t)stream;
-    XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
-    XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
+    if (phases & 8) {   // reset the COO cursor / counters / row counts
+        XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+        XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
+    }
     TriArgs A;
     memset(&A, 0, sizeof(A));
     A.iptr = (const long long *)R->item_ptr; A.cur = cur;
@@ -521,18 +523,18 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.hp_hi = hp_hi; A.hp_lo = hp_lo; A.hp_cnt = hp_cnt; A.hp_mut = hp_mut;
     A.coo_cap = coo_cap; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.rowcnt = rowcnt; A.counters = (unsigned long long *)d_counters;
-    if (do_heavy && n_heavy_units > 0) {   // heavy rows first: they are the long units
+    if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials
         if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
         else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
         XM_LAUNCH_CHECK();
     }
-    if (unit_hi > unit_lo) {
+    if ((phases & 2) && unit_hi > unit_lo) {
         dim3 grid((unsigned)(unit_hi - unit_lo));
         if (method == XMAP_COSINE) k_pair_tri<XMAP_COSINE><<<grid, dim3(64), 0, st>>>(A);
         else k_pair_tri<XMAP_ADJUST_COSINE><<<grid, dim3(64), 0, st>>>(A);
         XM_LAUNCH_CHECK();
     }
-    if (do_heavy && n_heavy_units > 0 && n_heavy > 0) {
+    if ((phases & 4) && n_heavy_units > 0 && n_heavy > 0) {
         if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
         else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
         XM_LAUNCH_CHECK();

@@ -254,6 +254,7 @@ class Engine(object):
         L.slot_target = slot_target
         self._tri_plan(L, slot_target)
         L.half_contrib = int(L.Wp[:I].sum().item()) if I else 0
+        L.heavy_half = int(L.Wp[L.hlist[:L.n_heavy].long()].sum().item()) if L.n_heavy else 0
         return L
 
     def _tri_plan(self, L, slot_target):
@@ -277,7 +278,7 @@ class Engine(object):
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
-    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True):
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows)"""
         R = self.R
         st = _stream(self.dev)
@@ -299,25 +300,34 @@ class Engine(object):
             hp_cnt = self._empty(max(nh, 1) * 1024, torch.int32)
             hp_mut = self._empty(max(nh, 1) * 1024, torch.int32)
             d_cnt = self._zeros(4, torch.int64)
-            with self.timed("pair_tri"):
+            def run(phases):
                 check(lib.xmap_sim2_pairs(
                     st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(L.cur), vp(L.rc_e0), vp(L.rc_pos),
                     vp(L.rc_rating), vp(L.rc_user), vp(L.ub_item), vp(L.ub_rating), vp(L.Q), vp(L.uq_item),
                     vp(L.uq_q), i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
-                    vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), 1 if do_heavy else 0,
+                    vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
                     vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(d_cnt)))
+            with self.timed("pair_heavy"):
+                run(8 | (1 if do_heavy else 0))
+            with self.timed("pair_tri"):
+                run(2)
+            with self.timed("heavy_merge"):
+                run(4 if do_heavy else 0)
             h = d_cnt.tolist()
             if h[2]:
                 if L.slot_target <= 32:
                     raise abi.XmapError(abi.ERR_OVERFLOW, "pair-table overflow")
+                if not retry:      # sharded callers re-plan collectively
+                    return None, rowcnt, 0, 0, 1
                 self._tri_plan(L, L.slot_target // 2)
                 continue
             if h[3]:
                 raise abi.XmapError(abi.ERR_CAPACITY, "half-COO overflow")
             break
         n = int(h[0])
-        return (coo_i[:n], coo_j[:n], coo_sim[:n], coo_mutu[:n], coo_nij[:n]), rowcnt, n, int(h[1])
+        out = ((coo_i[:n], coo_j[:n], coo_sim[:n], coo_mutu[:n], coo_nij[:n]), rowcnt, n, int(h[1]))
+        return out if retry else out + (0,)
 
     def tri_scatter(self, coo, rowcnt, info):
         """mirror a (complete) half COO into the CSR"""
@@ -428,7 +438,7 @@ class Engine(object):
         check(lib.xmap_reverse_fill(st, *args, vp(rptr), vp(ridx), vp(rval), vp(rflag)))
         return rptr, ridx, rval, rflag, n
 
-    def path_units(self, E, start_range=None, chunk=None, row_budget=48 << 30):
+    def path_units(self, E, start_range=None, chunk=None, row_budget=48 << 30, start_split=None):
         """Work units of the path enumeration from the exact per-start path counts: starts with more than
         `chunk` paths are split into G round-robin chunks with dedicated accumulator rows (merged on the
         device afterwards); units are ordered heaviest first."""
@@ -442,6 +452,9 @@ class Engine(object):
                                         vp(E.att[0]), vp(E.att[1]), vp(E.src[0]), vp(E.src[1]), vp(E.src[3]),
                                         vp(E.rnn[0]), vp(E.rnn[1]), vp(tmp), vp(P)))
         p = P.cpu().numpy()[:I].copy()
+        if start_split is not None:   # (rank, world): contiguous start ranges of equal path counts
+            from .sharded import balanced_ranges
+            start_range = balanced_ranges(p, start_split[1])[start_split[0]]
         lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
         p[:lo] = 0
         p[hi:] = 0
@@ -476,7 +489,8 @@ class Engine(object):
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
-    def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None):
+    def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None,
+               start_split=None):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
         I = R.n_items
@@ -486,7 +500,7 @@ class Engine(object):
             E.att = self._reverse(S, E, 0, None)
             E.src = self._reverse(S, E, 1, E.att[0])
             E.rnn = self._reverse(S, E, 2, None)
-        U = self.path_units(E, start_range, chunk)
+        U = self.path_units(E, start_range, chunk, start_split=start_split)
         E.units = U
         slot_budget = 48 << 30
         n_slots = int(max(4, min(n_slots, slot_budget // (36 * max(I, 1)), max(U.n_units, 4))))

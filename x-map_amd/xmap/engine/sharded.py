@@ -1,12 +1,14 @@
 """One pass of the hot path, optionally item-sharded over the ranks of one node.
 
-Sharding: inputs (CSR + CSC) are replicated in every GPU's HBM; outputs are sharded by
-item.  Stage A: each rank computes the complete similarity rows of its contiguous item range (no
-cross-GPU partials), then the kept rows are exchanged with one all-gather per array (S4/S6 of SURVEY
-2.3) so that every rank holds the full CSR.  Stage B: the knn tables are derived from the full CSR on
-every rank (one HBM pass, cheaper than exchanging them), the path enumeration is sharded by start
-item, and the fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C
-is a few HBM passes over nnz and is replicated.
+Sharding: inputs (CSR + CSC) are replicated in every GPU's HBM; the work is sharded by
+item.  Stage A: the work units (item, partition) of the pair kernel are split into contiguous ranges of
+equal rater-steps; each rank appends the kept pairs of its units to a half COO (every unordered pair is
+owned by exactly one unit, so there are no cross-GPU partials), the per-item row counts are all-reduced
+and the COO parts all-gathered (S4/S6 of SURVEY 2.3), then every rank mirrors the full COO into the CSR.
+Stage B: the knn tables are derived from the full CSR on every rank (one HBM pass, cheaper than
+exchanging them), the path enumeration is sharded by start item (ranges of equal path counts), and the
+fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
+passes over nnz and is replicated.
 
 Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on the MI355X node; "gloo"
 (host staging) is used by the CPU-side tests and for rehearsals with several ranks on one GPU.
@@ -80,45 +82,50 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             n_top, choice, mp = eng.select(E, private)
             G = eng.alterego(mp)
             n_prof = eng.n_profiles(G)
-        return dict(n_eval=S.n_eval, n_kept=S.n_kept, n_contrib=S.n_contrib, n_contrib_local=S.n_contrib,
-                    n_kept_local=S.n_kept, n_paths=E.n_paths, n_rows=G.n_rows, n_profiles=n_prof,
-                    S=S, E=E, G=G, choice=choice, map=mp)
+        L = S.layout
+        return dict(n_eval=S.n_eval, n_kept=S.n_kept, n_contrib=S.n_contrib,
+                    n_contrib_light=2 * (L.half_contrib - L.heavy_half), n_kept_local=S.n_kept,
+                    n_paths=E.n_paths, n_out=E.n_out, n_rows=G.n_rows, n_profiles=n_prof,
+                    knn_entries=int(E.kcnt.sum().item()), S=S, E=E, G=G, choice=choice, map=mp)
 
     comm = Comm(dist)
     dev = eng.dev
-    # ---- stage A: complete rows of this rank's item range, then all-gather the kept rows
+    # ---- stage A: every rank lays out the (replicated) ratings, computes the pairs of its share of the
+    # work units into a half COO, the COO parts are all-gathered and mirrored into the full CSR everywhere
     with eng.timed("stage_a"):
         stats = eng.stats()
-        plan = eng.plan()
-        wts = eng.item_weights(plan).cpu().numpy()
-        lo, hi = balanced_ranges(wts, world)[rank]
-        Sl = eng.item_sim(method, cap, item_range=(lo, hi), stats=stats, plan=plan)
-        counts = (Sl.row_ptr[1:] - Sl.row_ptr[:-1]).contiguous()
-        comm.all_reduce(counts)                       # rows outside [lo,hi) are empty locally
-        row_ptr = torch.zeros(I + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(counts, 0, out=row_ptr[1:])
-        col = comm.all_gather_var(Sl.col)
-        sim = comm.all_gather_var(Sl.sim)
-        mutu = comm.all_gather_var(Sl.mutu)
-        nij = comm.all_gather_var(Sl.nij)
-        tot = torch.tensor([Sl.n_eval, Sl.n_kept], dtype=torch.int64, device=dev)
+        L = eng.tri_layout(stats)
+        while True:
+            w = L.cur[L.uq_item[:L.n_light].long()].cpu().numpy() if L.n_light else np.zeros(0)
+            lo, hi = balanced_ranges(w, world)[rank]
+            coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
+                                                             do_heavy=(rank == 0), retry=False)
+            flag = torch.tensor([ovf], dtype=torch.int64, device=dev)
+            comm.all_reduce(flag, "max")
+            if int(flag.item()) == 0:
+                break
+            eng._tri_plan(L, L.slot_target // 2)      # every rank re-plans identically
+        comm.all_reduce(rowcnt)
+        coo = [comm.all_gather_var(x) for x in coo]
+        tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
-        S = eng.sim_from_device(row_ptr, col, sim, mutu, nij, Sl.info)
-        local_contrib = int(plan.W[lo:hi].sum().item())
-    # ---- stage B: knn tables everywhere, paths sharded by start item
+        S = eng.tri_scatter(coo, rowcnt, stats[2])
+        light_local = 2 * int(L.Wp[L.uq_item[lo:hi].long()].sum().item()) if hi > lo else 0
+    # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
+    # ranges balanced by the exact per-start path counts
     with eng.timed("stage_b"):
-        slo, shi = balanced_ranges(np.ones(I), world)[rank]
-        E = eng.extend(S, k, full=False, start_range=(slo, shi))
+        E = eng.extend(S, k, full=False, start_split=(rank, world))
         comm.all_reduce(E.n_cand)
         comm.all_reduce(E.top_end, "max")             # -1 outside the local range
         comm.all_reduce(E.top_val)                    # 0.0 outside the local range
-        pt = torch.tensor([E.n_paths], dtype=torch.int64, device=dev)
+        pt = torch.tensor([E.n_paths, E.n_out], dtype=torch.int64, device=dev)
         comm.all_reduce(pt)
-    # ---- stage C: replicated
+    # ---- stage C: replicated (a few ms)
     with eng.timed("stage_c"):
         n_top, choice, mp = eng.select(E, private)
         G = eng.alterego(mp)
         n_prof = eng.n_profiles(G)
-    return dict(n_eval=int(tot[0].item()), n_kept=int(tot[1].item()), n_contrib=plan.contrib,
-                n_contrib_local=local_contrib, n_kept_local=Sl.n_kept, n_paths=int(pt.item()),
-                n_rows=G.n_rows, n_profiles=n_prof, S=S, E=E, G=G, choice=choice, map=mp)
+    return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * L.half_contrib,
+                n_contrib_light=light_local, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
+                n_rows=G.n_rows, n_profiles=n_prof, knn_entries=int(E.kcnt.sum().item()),
+                S=S, E=E, G=G, choice=choice, map=mp)
