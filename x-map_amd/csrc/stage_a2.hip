@@ -30,6 +30,7 @@ constexpr int T_LOG_SLOTS = 10;
 constexpr int T_SLOTS = 1 << T_LOG_SLOTS;
 constexpr int HMAX = 1024;              // |H| <= HMAX: dense LDS table of the heavy kernel
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
+constexpr int SMALL_BOUND = 96;          // rows with at most this many partners use the 128-slot table
 
 __device__ __forceinline__ unsigned long long wkey(int n, int item) {
     return ((unsigned long long)(unsigned)n << 32) | (unsigned)item;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
 // light rows: Q partitions; heavy rows (in H): chunks of CH raters
 __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const int *cur, const unsigned long long *Wp,
                                                const long long *pre, int HB, const int *hid, const int *CH, int target,
-                                               int *Q, int *C) {
+                                               int *Q, int *C, uint8_t *small) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     long long n = iptr[i + 1] - iptr[i];
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     }
     Q[i] = q;
     C[i] = c;
+    small[i] = (q == 1 && bound <= SMALL_BOUND) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Q, const long long *uq_ptr, int *uq_item, int *uq_q,
@@ -143,16 +145,18 @@ struct TriArgs {
     const double *u_avg; const double *info;
     int cap;
     // light
-    const int *Q; const int *uq_item; const int *uq_q; long long unit_lo, unit_hi;
+    const int *Q; const uint8_t *small; const int *uq_item; const int *uq_q; long long unit_lo, unit_hi;
     // heavy
     const int *hid; const int *hlist; const int *CH; const int *uc_item; const int *uc_c;
     const long long *uc_ptr; const int *C;
     double *hp_hi; double *hp_lo; int *hp_cnt; int *hp_mut;    // [heavy units][HMAX]
     // output: half COO + per-row counts
-    long long coo_cap;
+    long long shard_cap;            // COO entries per shard
+    unsigned long long *shard_cur;  // [COO_SHARDS] cursors
+    unsigned long long *shard_occ;  // [COO_SHARDS] unordered pairs evaluated
     int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
     int *rowcnt;
-    unsigned long long *counters;   // [0] coo cursor, [1] pairs evaluated (unordered), [2] overflow, [3] coo overflow
+    unsigned long long *counters;   // [2] table overflow, [3] COO overflow
 };
 
 // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207) for one accumulated pair
@@ -167,9 +171,14 @@ __device__ __forceinline__ bool finish_pair(const TriArgs &A, int i, int j, int 
 }
 
 // append the kept pairs of one wave's table (callback gives slot -> pair) to the half COO
+// The COO is cut into COO_SHARDS segments with a cursor each (a single cursor word would serialise the ~4e5
+// appending waves: one word sustains only ~90 atomics/us); unused entries keep coo_i = -1.
+constexpr int COO_SHARDS = 4096;
+
 template <typename Slot>
 __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slots, Slot slot) {
     const int lane = lane_id();
+    const int shard = blockIdx.x & (COO_SHARDS - 1);
     int kept = 0, occ = 0;
     for (int s0 = 0; s0 < n_slots; s0 += 64) {
         int j, n, m; double sv; bool o;
@@ -177,18 +186,19 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slot
         kept += __popcll(__ballot(keep));
         occ += __popcll(__ballot(o));
     }
-    if (lane == 0 && occ) atomicAdd(&A.counters[1], (unsigned long long)occ);
+    if (lane == 0 && occ) atomicAdd(&A.shard_occ[shard], (unsigned long long)occ);
     if (!kept) return;
     unsigned long long base = 0;
     if (lane == 0) {
-        base = atomicAdd(&A.counters[0], (unsigned long long)kept);
+        base = atomicAdd(&A.shard_cur[shard], (unsigned long long)kept);
         atomicAdd(&A.rowcnt[i], kept);
     }
     base = ((unsigned long long)(unsigned)rl32((int)(base >> 32), 0) << 32) | (unsigned)rl32((int)(base & 0xffffffffull), 0);
-    if ((long long)(base + kept) > A.coo_cap) {
+    if ((long long)(base + kept) > A.shard_cap) {
         if (lane == 0) atomicOr(&A.counters[3], 1ull);
         return;
     }
+    base += (unsigned long long)shard * (unsigned long long)A.shard_cap;
     for (int s0 = 0; s0 < n_slots; s0 += 64) {
         int j, n, m; double sv; bool o;
         bool keep = slot(s0 + lane, j, n, m, sv, o);
@@ -202,26 +212,42 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slot
     }
 }
 
-template <int METHOD>
+// Light rows.  Eight raters are processed per step (8 lanes each): profile prefixes are short (half a
+// profile on average), so one rater per step would leave most lanes idle and only one dependent load in
+// flight.  Lanes of different raters may meet on one partner: the counters use LDS atomics, the fp64 sum is
+// either an LDS atomic add (cosine: integer-exact, order irrelevant) or, for the double-double sum of
+// adjusted cosine, serialised per slot through a claim word (conflicts are rare).
+constexpr int GRP = 8;                  // lanes per rater
+constexpr int NGRP = 64 / GRP;          // raters per step
+
+// The table size is a template parameter: rows whose partner bound is <= SMALL_BOUND (the vast majority: items
+// with a handful of raters) run with 128 slots (3.5 KB of LDS, full occupancy, 8x cheaper init/finalise), the
+// others with 1024.  Both launches cover all light units; a block whose row is of the other class exits at once.
+
+template <int METHOD, int LOG_SLOTS>
 __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
-    __shared__ uint32_t key[T_SLOTS];
-    __shared__ uint32_t cnt[T_SLOTS];
-    __shared__ uint32_t mut[T_SLOTS];
-    __shared__ double dot[T_SLOTS];
-    __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? T_SLOTS : 1];
+    constexpr int SLOTS_ = 1 << LOG_SLOTS;
+    __shared__ uint32_t key[SLOTS_];
+    __shared__ unsigned long long cm[SLOTS_];     // n_ij (low 32) | mutuality (high 32)
+    __shared__ double dot[SLOTS_];
+    __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? SLOTS_ : 1];
+    __shared__ unsigned short claim[METHOD == XMAP_ADJUST_COSINE ? SLOTS_ : 1];
 
     const int lane = lane_id();
     const long long unit = A.unit_lo + blockIdx.x;
     if (unit >= A.unit_hi) return;
-    for (int s = lane; s < T_SLOTS; s += 64) {
-        key[s] = T_EMPTY; cnt[s] = 0; mut[s] = 0; dot[s] = 0.0;
+    const int i = uniform(A.uq_item[unit]);
+    const bool small = A.small[i] != 0;
+    if (small != (LOG_SLOTS < T_LOG_SLOTS)) return;
+    for (int s = lane; s < SLOTS_; s += 64) {
+        key[s] = T_EMPTY; cm[s] = 0ull; dot[s] = 0.0;
         if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
     }
-    const int i = uniform(A.uq_item[unit]);
     const int q = uniform(A.uq_q[unit]);
     const int Qi = uniform(A.Q[i]);
     const int p0 = uniform((int)A.iptr[i]);
     const int p1 = p0 + uniform(A.cur[i]);
+    const int g = lane / GRP, sub = lane % GRP;
     int ovf = 0;
     for (int base = p0; base < p1; base += 64) {
         const int p = base + lane;
@@ -235,53 +261,64 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
             if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[A.rc_user[p]];
         }
         const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
-        // prefetch the next rater's first 64 prefix entries
-        int nb0 = rl32(e0, 0), nb1 = nb0 + (rl32(pw, 0) & 0x7fffffff);
-        int njw = 0;
+        // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
+        int nb0 = 0, nb1 = 0, npw = 0, njw = 0;
         float nrj = 0.f;
-        if (nb0 + lane < nb1) { njw = A.ub_item[nb0 + lane]; nrj = A.ub_rating[nb0 + lane]; }
-        for (int t = 0; t < nr; ++t) {
-            const int b0 = nb0, b1 = nb1;
+        {
+            const int t = g;
+            nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
+            nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
+            if (nb0 + sub < nb1) { njw = A.ub_item[nb0 + sub]; nrj = A.ub_rating[nb0 + sub]; }
+        }
+        for (int t0 = 0; t0 < nr; t0 += NGRP) {
+            const int t = t0 + g;                    // this lane group's rater
+            const int b0 = nb0, b1 = nb1, pwt = npw;
             int jw = njw;
             float rj = nrj;
-            const unsigned gei = ((unsigned)rl32(pw, t)) >> 31;
-            if (t + 1 < nr) {
-                nb0 = rl32(e0, t + 1);
-                nb1 = nb0 + (rl32(pw, t + 1) & 0x7fffffff);
-                if (nb0 + lane < nb1) { njw = A.ub_item[nb0 + lane]; nrj = A.ub_rating[nb0 + lane]; }
+            if (t0 + NGRP < nr) {
+                const int tn = t + NGRP;
+                nb0 = __shfl(e0, tn, 64); npw = __shfl(pw, tn, 64);
+                nb1 = (tn < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
+                if (nb0 + sub < nb1) { njw = A.ub_item[nb0 + sub]; nrj = A.ub_rating[nb0 + sub]; }
             }
-            if (b1 == b0) continue;
-            const double ri = (double)rlf(r, t);
-            const double a = (METHOD == XMAP_ADJUST_COSINE) ? rld(au, t) : 0.0;
-            for (int c0 = b0; c0 < b1; c0 += 64) {
-                const int e = c0 + lane;
-                if (c0 != b0 && e < b1) { jw = A.ub_item[e]; rj = A.ub_rating[e]; }
-                if (e < b1) {
-                    const int j = jw & 0x7fffffff;
-                    bool mine = true;
-                    if (Qi > 1) mine = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
-                    if (mine) {
-                        uint32_t h = ((uint32_t)j * 0x9E3779B1u) >> (32 - T_LOG_SLOTS);
-                        int probes = 0;
-                        bool ok = true;
-                        for (;;) {
-                            uint32_t prev = atomicCAS(&key[h], T_EMPTY, (uint32_t)j);
-                            if (prev == T_EMPTY || prev == (uint32_t)j) break;
-                            h = (h + 1) & (T_SLOTS - 1);
-                            if (++probes >= T_SLOTS) { ok = false; break; }
-                        }
-                        if (ok) {
-                            cnt[h] += 1;
-                            mut[h] += ((((unsigned)jw) >> 31) == gei) ? 1u : 0u;
-                            if (METHOD == XMAP_COSINE) {
-                                dot[h] += (1.0 * ri) * (double)rj;
-                            } else {
-                                double hi = dot[h], lo = dlo[h];
-                                dd_add(hi, lo, (ri - a) * ((double)rj - a));
-                                dot[h] = hi; dlo[h] = lo;
-                            }
-                        } else {
-                            ovf = 1;
+            const double ri = (double)__shfl(r, t, 64);
+            const double a = (METHOD == XMAP_ADJUST_COSINE) ? __shfl(au, t, 64) : 0.0;
+            const unsigned gei = ((unsigned)pwt) >> 31;
+            for (int e = b0 + sub; __ballot(e < b1); e += GRP) {
+                bool act = e < b1;
+                if (act && e >= b0 + GRP) { jw = A.ub_item[e]; rj = A.ub_rating[e]; }
+                const int j = jw & 0x7fffffff;
+                if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
+                uint32_t h = 0;
+                if (act) {
+                    h = ((uint32_t)j * 0x9E3779B1u) >> (32 - LOG_SLOTS);
+                    int probes = 0;
+                    for (;;) {
+                        uint32_t prev = atomicCAS(&key[h], T_EMPTY, (uint32_t)j);
+                        if (prev == T_EMPTY || prev == (uint32_t)j) break;
+                        h = (h + 1) & (SLOTS_ - 1);
+                        if (++probes >= SLOTS_) { act = false; ovf = 1; break; }
+                    }
+                }
+                if (act) {
+                    const unsigned long long inc = 1ull | (((((unsigned)jw) >> 31) == gei) ? (1ull << 32) : 0ull);
+                    atomicAdd(&cm[h], inc);
+                    if (METHOD == XMAP_COSINE) atomicAdd(&dot[h], (1.0 * ri) * (double)rj);   // integer-exact
+                }
+                if (METHOD == XMAP_ADJUST_COSINE) {
+                    const double term = (ri - a) * ((double)rj - a);
+                    // volatile: the claim word and the sums are shared between LANES of this wave; the compiler
+                    // must neither forward the claim store to the load nor hoist the sum loads out of the loop
+                    volatile unsigned short *vclaim = claim;
+                    volatile double *vhi = dot, *vlo = dlo;
+                    bool pending = act;
+                    while (__ballot(pending)) {       // lanes that share a slot take turns
+                        if (pending) vclaim[h] = (unsigned short)lane;
+                        if (pending && vclaim[h] == (unsigned short)lane) {
+                            double hi = vhi[h], lo = vlo[h];
+                            dd_add(hi, lo, term);
+                            vhi[h] = hi; vlo[h] = lo;
+                            pending = false;
                         }
                     }
                 }
@@ -292,11 +329,12 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
         if (lane == 0) atomicOr(&A.counters[2], 1ull);
         return;
     }
-    append_pairs(A, i, T_SLOTS, [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
+    append_pairs(A, i, SLOTS_, [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
         uint32_t kj = key[s];
         o = kj != T_EMPTY;
         if (!o) return false;
-        j = (int)kj; n = (int)cnt[s]; m = (int)mut[s];
+        unsigned long long c = cm[s];
+        j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32);
         return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
     });
 }
@@ -397,18 +435,40 @@ __global__ __launch_bounds__(64) void k_heavy_merge(TriArgs A, int n_heavy) {
     });
 }
 
+// Mirror the half COO into the CSR.  Records of one unit are contiguous and share the lighter item i, so the
+// i-side cursor is bumped once per run of equal i inside a wave and those writes are coalesced; the j-side
+// (heavier item) writes are scattered.
 __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, const int *coo_j, const double *coo_sim,
                                                  const int *coo_mutu, const int *coo_nij, const long long *row_ptr,
                                                  int *fill, int *col, double *sim, int *mutu, int *nij) {
-    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int i = coo_i[r], j = coo_j[r];
-    const double s = coo_sim[r];
-    const int m = coo_mutu[r], nn = coo_nij[r];
-    long long a = row_ptr[i] + atomicAdd(&fill[i], 1);
-    col[a] = j; sim[a] = s; mutu[a] = m; nij[a] = nn;
-    long long b = row_ptr[j] + atomicAdd(&fill[j], 1);
-    col[b] = i; sim[b] = s; mutu[b] = m; nij[b] = nn;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = lane_id();
+    const bool act = r < n;
+    int i = -1 - lane, j = 0, m = 0, nn = 0;   // inactive lanes: unique fake rows
+    double s = 0.0;
+    bool valid = false;
+    if (act) {
+        int ii = coo_i[r];
+        valid = ii >= 0;
+        if (valid) { i = ii; j = coo_j[r]; s = coo_sim[r]; m = coo_mutu[r]; nn = coo_nij[r]; }
+    }
+    const int prev = __shfl_up(i, 1, 64);
+    const bool leader = (lane == 0) || (prev != i);
+    const unsigned long long lm = __ballot(leader);
+    const unsigned long long below = lm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int lead = 63 - __clzll((long long)below);
+    const unsigned long long above = (lane == 63) ? 0ull : (lm >> (lane + 1));
+    // run length as seen by the leader: distance to the next leader
+    int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+    int base = 0;
+    if (leader && valid) base = atomicAdd(&fill[i], next - lane);
+    base = __shfl(base, lead, 64);
+    if (valid) {
+        const long long a = row_ptr[i] + base + (lane - lead);
+        col[a] = j; sim[a] = s; mutu[a] = m; nij[a] = nn;
+        const long long b = row_ptr[j] + atomicAdd(&fill[j], 1);
+        col[b] = i; sim[b] = s; mutu[b] = m; nij[b] = nn;
+    }
 }
 
 }  // namespace xmap
@@ -466,16 +526,16 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
 }
 
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int32_t *cur, const uint64_t *Wp,
-                   const int64_t *pre, const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, int64_t *uq_ptr,
-                   int64_t *uc_ptr, int64_t *h_counts /*[2]: light units, heavy units*/) {
-    XM_ARG(R && cur && Wp && pre && hid && ctl && Q && C && uq_ptr && uc_ptr && h_counts);
+                   const int64_t *pre, const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small,
+                   int64_t *uq_ptr, int64_t *uc_ptr, int64_t *h_counts /*[2]: light units, heavy units*/) {
+    XM_ARG(R && cur && Wp && pre && hid && ctl && Q && C && small && uq_ptr && uc_ptr && h_counts);
     XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
     hipStream_t st = (hipStream_t)stream;
     const int I = R->n_items;
     if (I > 0) {
         k_plan2<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(
             I, (const long long *)R->item_ptr, cur, (const unsigned long long *)Wp, (const long long *)pre,
-            (int)R->n_users + 2, hid, ctl, slot_target, Q, C);
+            (int)R->n_users + 2, hid, ctl, slot_target, Q, C, small);
         XM_LAUNCH_CHECK();
     }
     int rc = xmap_exclusive_scan_i32_to_i64(stream, Q, uq_ptr, I, &h_counts[0]);
@@ -496,20 +556,22 @@ int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *info,
                     const int32_t *cur, const int32_t *rc_e0, const int32_t *rc_pos, const float *rc_rating,
                     const int32_t *rc_user, const int32_t *ub_item, const float *ub_rating, const int32_t *Q,
-                    const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
+                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
-                    int64_t *d_counters /*[4]*/) {
+                    int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/) {
     XM_ARG(R && u_avg && info && cur && rc_e0 && rc_pos && rc_rating && rc_user && ub_item && ub_rating);
-    XM_ARG(Q && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
-    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && d_counters && coo_cap >= 0);
+    XM_ARG(Q && small && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
+    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && d_shards && d_counters && coo_cap >= COO_SHARDS);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
     XM_ARG(n_heavy_units == 0 || !(phases & 5) || (hp_hi && hp_lo && hp_cnt && hp_mut));
     hipStream_t st = (hipStream_t)stream;
     if (phases & 8) {   // reset the COO cursor / counters / row counts
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+        XM_HIP(hipMemsetAsync(d_shards, 0, 2 * COO_SHARDS * sizeof(int64_t), st));
+        XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry
         XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
     }
     TriArgs A;
@@ -517,11 +579,12 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.iptr = (const long long *)R->item_ptr; A.cur = cur;
     A.rc_e0 = rc_e0; A.rc_pos = rc_pos; A.rc_rating = rc_rating; A.rc_user = rc_user;
     A.ub_item = ub_item; A.ub_rating = ub_rating; A.u_avg = u_avg; A.info = info; A.cap = cap;
-    A.Q = Q; A.uq_item = uq_item; A.uq_q = uq_q; A.unit_lo = unit_lo; A.unit_hi = unit_hi;
+    A.Q = Q; A.small = small; A.uq_item = uq_item; A.uq_q = uq_q; A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     A.hid = hid; A.hlist = hlist; A.CH = ctl; A.uc_item = uc_item; A.uc_c = uc_c;
     A.uc_ptr = (const long long *)uc_ptr; A.C = C;
     A.hp_hi = hp_hi; A.hp_lo = hp_lo; A.hp_cnt = hp_cnt; A.hp_mut = hp_mut;
-    A.coo_cap = coo_cap; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
+    A.shard_cap = coo_cap / COO_SHARDS; A.shard_cur = (unsigned long long *)d_shards;
+    A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.rowcnt = rowcnt; A.counters = (unsigned long long *)d_counters;
     if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials
         if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
@@ -530,8 +593,13 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     }
     if ((phases & 2) && unit_hi > unit_lo) {
         dim3 grid((unsigned)(unit_hi - unit_lo));
-        if (method == XMAP_COSINE) k_pair_tri<XMAP_COSINE><<<grid, dim3(64), 0, st>>>(A);
-        else k_pair_tri<XMAP_ADJUST_COSINE><<<grid, dim3(64), 0, st>>>(A);
+        if (method == XMAP_COSINE) {
+            k_pair_tri<XMAP_COSINE, T_LOG_SLOTS><<<grid, dim3(64), 0, st>>>(A);
+            k_pair_tri<XMAP_COSINE, 7><<<grid, dim3(64), 0, st>>>(A);
+        } else {
+            k_pair_tri<XMAP_ADJUST_COSINE, T_LOG_SLOTS><<<grid, dim3(64), 0, st>>>(A);
+            k_pair_tri<XMAP_ADJUST_COSINE, 7><<<grid, dim3(64), 0, st>>>(A);
+        }
         XM_LAUNCH_CHECK();
     }
     if ((phases & 4) && n_heavy_units > 0 && n_heavy > 0) {

@@ -263,12 +263,13 @@ class Engine(object):
         I = R.n_items
         L.Q = self._zeros(max(I, 1), torch.int32)
         L.C = self._zeros(max(I, 1), torch.int32)
+        L.small = self._zeros(max(I, 1), torch.uint8)
         L.uq_ptr = self._zeros(I + 1, torch.int64)
         L.uc_ptr = self._zeros(I + 1, torch.int64)
         h = (C.c_int64 * 2)()
         with self.timed("tri_plan"):
             check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.cur), vp(L.Wp), vp(L.pre), vp(L.hid),
-                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.uq_ptr), vp(L.uc_ptr), h))
+                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.uq_ptr), vp(L.uc_ptr), h))
             L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
             L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
             L.uq_q = self._empty(max(L.n_light, 1), torch.int32)
@@ -285,9 +286,11 @@ class Engine(object):
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
         u_avg, u_norm, info, _, _ = stats
         I = R.n_items
+        coo_slack = 1.0
         while True:
             lo, hi = (0, L.n_light) if unit_range is None else (int(unit_range[0]), int(unit_range[1]))
-            cap_coo = max(L.half_contrib, 1)
+            # per-shard capacity >= one full table (1024 kept pairs) + the expected share with slack
+            cap_coo = (max(int(L.half_contrib * coo_slack), 1) // 4096 + 1100) * 4096
             coo_i = self._empty(cap_coo, torch.int32)
             coo_j = self._empty(cap_coo, torch.int32)
             coo_sim = self._empty(cap_coo, torch.float64)
@@ -300,14 +303,16 @@ class Engine(object):
             hp_cnt = self._empty(max(nh, 1) * 1024, torch.int32)
             hp_mut = self._empty(max(nh, 1) * 1024, torch.int32)
             d_cnt = self._zeros(4, torch.int64)
+            d_shards = self._empty(2 * 4096, torch.int64)
+
             def run(phases):
                 check(lib.xmap_sim2_pairs(
                     st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(L.cur), vp(L.rc_e0), vp(L.rc_pos),
-                    vp(L.rc_rating), vp(L.rc_user), vp(L.ub_item), vp(L.ub_rating), vp(L.Q), vp(L.uq_item),
+                    vp(L.rc_rating), vp(L.rc_user), vp(L.ub_item), vp(L.ub_rating), vp(L.Q), vp(L.small), vp(L.uq_item),
                     vp(L.uq_q), i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
-                    vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(d_cnt)))
+                    vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(d_shards), vp(d_cnt)))
             with self.timed("pair_heavy"):
                 run(8 | (1 if do_heavy else 0))
             with self.timed("pair_tri"):
@@ -322,20 +327,26 @@ class Engine(object):
                     return None, rowcnt, 0, 0, 1
                 self._tri_plan(L, L.slot_target // 2)
                 continue
-            if h[3]:
-                raise abi.XmapError(abi.ERR_CAPACITY, "half-COO overflow")
+            if h[3]:            # a COO shard overflowed: more slack
+                if coo_slack > 64:
+                    raise abi.XmapError(abi.ERR_CAPACITY, "half-COO overflow")
+                coo_slack *= 2
+                continue
             break
-        n = int(h[0])
-        out = ((coo_i[:n], coo_j[:n], coo_sim[:n], coo_mutu[:n], coo_nij[:n]), rowcnt, n, int(h[1]))
+        sh = d_shards.view(2, 4096).sum(dim=1).tolist()
+        n, n_unordered = int(sh[0]), int(sh[1])
+        out = ((coo_i, coo_j, coo_sim, coo_mutu, coo_nij), rowcnt, n, n_unordered)
         return out if retry else out + (0,)
 
-    def tri_scatter(self, coo, rowcnt, info):
-        """mirror a (complete) half COO into the CSR"""
+    def tri_scatter(self, coo, rowcnt, info, n=None):
+        """mirror a (complete) half COO (n valid entries; unused ones have coo_i = -1) into the CSR"""
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
         coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo]
-        n = int(coo_i.numel())
+        n_scan = int(coo_i.numel())
+        if n is None:
+            n = n_scan
         row_ptr = self._zeros(I + 1, torch.int64)
         check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rowcnt), vp(row_ptr), i64(I), None))
         kept = 2 * n
@@ -346,7 +357,7 @@ class Engine(object):
         fill = self._empty(max(I, 1), torch.int32)
         with self.timed("scatter"):
           if n:
-            check(lib.xmap_sim2_scatter(st, i32(I), i64(n), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu),
+            check(lib.xmap_sim2_scatter(st, i32(I), i64(n_scan), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu),
                                         vp(coo_nij), vp(row_ptr), vp(fill), vp(col), vp(sim), vp(mutu), vp(nij)))
         return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
 
@@ -356,7 +367,7 @@ class Engine(object):
             stats = self.stats()
         L = self.tri_layout(stats, slot_target, ch_min)
         coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
-        S = self.tri_scatter(coo, rowcnt, stats[2])
+        S = self.tri_scatter(coo, rowcnt, stats[2], n)
         S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
         S.cap = int(cap)
         S.u_avg, S.u_norm = stats[0], stats[1]

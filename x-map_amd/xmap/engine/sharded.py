@@ -106,7 +106,8 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
                 break
             eng._tri_plan(L, L.slot_target // 2)      # every rank re-plans identically
         comm.all_reduce(rowcnt)
-        coo = [comm.all_gather_var(x) for x in coo]
+        valid = coo[0] >= 0                            # compact the padded local COO before the exchange
+        coo = [comm.all_gather_var(x[valid].contiguous()) for x in coo]
         tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
         S = eng.tri_scatter(coo, rowcnt, stats[2])
