@@ -586,6 +586,313 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
     }
 }
 
+// =============================================================================================
+// Second formulation of the enumeration ("middle lists").  Every joint path has the shape
+//   [y'] - x' - t - s - [x - [y]]      with x', x non-bridge items, t in NB_BB(x'), (t,s) joint.
+// For each non-bridge x' the middles (t,s,x) ("X records") and (t,s) ("S records") are materialised ONCE,
+// grouped by x resp. s.  A head (start, x') then streams the groups of x': all records of one group hit the
+// same ends {x} U NN(x), so each lane keeps its end's double-double sums in REGISTERS across the group and the
+// start's row in HBM is touched once per (head, group) instead of once per path (about 4x fewer random
+// read-modify-writes at BASELINE configs[1]).  The edge products sim*mutu and the fractions are stored per edge,
+// so a path's (sum sim*mutu, sum mutu, prod frac) is rebuilt in the reference's left-to-right order, bit for bit.
+struct MidX { double sm2, sm3, sm4, f2, f3, f4, mu; int x; int pad; };   // 64 B
+struct MidS { double sm2, sm3, f2, f3, mu; int s; int pad; };            // 48 B
+struct MidDir { int key; int off; int cnt; };                            // group directory entry
+
+constexpr int MID_LOG = 12;
+constexpr int MID_SLOTS = 1 << MID_LOG;
+
+struct MidArgs {
+    int I, k;
+    const uint8_t *cls; const int *kcnt; const int *kcol; const double *kval; const uint8_t *flags;
+    const long long *att_ptr; const int *att_idx; const double *att_val;
+    const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
+    int n_nb; const int *nb_list;                 // the non-bridge records x'
+    long long *cntX; long long *cntS;             // [n_nb] record counts (count pass)
+    const long long *ptrX; const long long *ptrS; // [n_nb+1]
+    MidX *midX; MidS *midS; MidDir *dirX; MidDir *dirS; int *ngX; int *ngS;   // fill pass
+};
+
+// enumerate the (t,s) pairs of x' in chunks of 64 lanes; f(lane has pair, t-list position q, src position p)
+template <typename F>
+__device__ __forceinline__ void for_each_ts(const MidArgs &A, int xp, F f) {
+    const int lane = lane_id();
+    const int nb = A.kcnt[(size_t)xp * 2];
+    for (int q = 0; q < nb; q++) {
+        const size_t o = ((size_t)xp * 2) * A.k + q;
+        const int t = A.kcol[o];
+        if (!(A.flags[t] & 2)) continue;
+        const long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
+        for (long long base = s0; base < s1; base += 64) {
+            const long long p = base + lane;
+            const bool act = (p < s1) && (A.src_flag[p] & 1);
+            f(act, o, p);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mid_count(MidArgs A) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= A.n_nb) return;
+    const int xp = A.nb_list[w];
+    long long nS = 0, nX = 0;
+    for_each_ts(A, xp, [&](bool act, size_t o, long long p) {
+        if (act) {
+            const int s = A.src_idx[p];
+            nS += 1;
+            nX += A.att_ptr[s + 1] - A.att_ptr[s];
+        }
+    });
+    nS = wave_sum_ll(nS);
+    nX = wave_sum_ll(nX);
+    if (lane_id() == 0) { A.cntS[w] = nS; A.cntX[w] = nX; }
+}
+
+// open-addressing insert into a wave-private LDS table; returns slot or -1 on overflow
+__device__ __forceinline__ int mid_slot(uint32_t *key, int k) {
+    uint32_t h = ((uint32_t)k * 0x9E3779B1u) >> (32 - MID_LOG);
+    for (int probes = 0; probes < MID_SLOTS; probes++) {
+        uint32_t prev = atomicCAS(&key[h], 0xFFFFFFFFu, (uint32_t)k);
+        if (prev == 0xFFFFFFFFu || prev == (uint32_t)k) return (int)h;
+        h = (h + 1) & (MID_SLOTS - 1);
+    }
+    return -1;
+}
+
+// one wave per x': two enumerations -- group sizes, then placement -- for the X records (grouped by x) and the S
+// records (grouped by s).  If a table overflows, every record becomes its own group (correct, just less reuse).
+__global__ __launch_bounds__(64) void k_mid_fill(MidArgs A) {
+    __shared__ uint32_t keyX[MID_SLOTS];
+    __shared__ int cX[MID_SLOTS];
+    __shared__ uint32_t keyS[MID_SLOTS];
+    __shared__ int cS[MID_SLOTS];
+    const int w = blockIdx.x;
+    if (w >= A.n_nb) return;
+    const int lane = lane_id();
+    const int xp = A.nb_list[w];
+    const long long bX = A.ptrX[w], bS = A.ptrS[w];
+    const long long nX = A.ptrX[w + 1] - bX, nS = A.ptrS[w + 1] - bS;
+    for (int s = lane; s < MID_SLOTS; s += 64) { keyX[s] = 0xFFFFFFFFu; cX[s] = 0; keyS[s] = 0xFFFFFFFFu; cS[s] = 0; }
+    int ovf = 0;
+    for_each_ts(A, xp, [&](bool act, size_t o, long long p) {
+        if (act) {
+            const int s = A.src_idx[p];
+            int hs = mid_slot(keyS, s);
+            if (hs < 0) ovf = 1; else atomicAdd(&cS[hs], 1);
+            for (long long ap = A.att_ptr[s]; ap < A.att_ptr[s + 1]; ap++) {
+                int hx = mid_slot(keyX, A.att_idx[ap]);
+                if (hx < 0) ovf = 1; else atomicAdd(&cX[hx], 1);
+            }
+        }
+    });
+    const bool grouped = !__ballot(ovf);
+    // group offsets = exclusive scan of the counts in slot order; directory entries in slot order
+    int ngx = 0, ngs = 0;
+    if (grouped) {
+        int runX = 0, runS = 0;
+        for (int s0 = 0; s0 < MID_SLOTS; s0 += 64) {
+            const int s = s0 + lane;
+            int cx = cX[s], cs = cS[s];
+            int ix = cx, is = cs;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int ox = __shfl_up(ix, d, 64), os = __shfl_up(is, d, 64);
+                if (lane >= d) { ix += ox; is += os; }
+            }
+            const unsigned long long mx = __ballot(cx > 0), ms = __ballot(cs > 0);
+            if (cx > 0) {
+                MidDir d; d.key = (int)keyX[s]; d.off = runX + ix - cx; d.cnt = cx;
+                A.dirX[bX + ngx + __popcll(mx & lanemask_lt())] = d;
+            }
+            if (cs > 0) {
+                MidDir d; d.key = (int)keyS[s]; d.off = runS + is - cs; d.cnt = cs;
+                A.dirS[bS + ngs + __popcll(ms & lanemask_lt())] = d;
+            }
+            cX[s] = runX + ix - cx;    // becomes the placement cursor of the group
+            cS[s] = runS + is - cs;
+            runX += __shfl(ix, 63, 64);
+            runS += __shfl(is, 63, 64);
+            ngx += __popcll(mx);
+            ngs += __popcll(ms);
+        }
+    } else {
+        for (long long r = lane; r < nX; r += 64) { MidDir d; d.key = -1; d.off = (int)r; d.cnt = 1; A.dirX[bX + r] = d; }
+        for (long long r = lane; r < nS; r += 64) { MidDir d; d.key = -1; d.off = (int)r; d.cnt = 1; A.dirS[bS + r] = d; }
+        ngx = (int)nX; ngs = (int)nS;
+        if (lane == 0) { cX[0] = 0; cS[0] = 0; }
+    }
+    if (lane == 0) { A.ngX[w] = ngx; A.ngS[w] = ngs; }
+    // placement
+    for_each_ts(A, xp, [&](bool act, size_t o, long long p) {
+        if (act) {
+            const int s = A.src_idx[p];
+            const double v2 = A.kval[o * 3], m2 = A.kval[o * 3 + 1], f2 = A.kval[o * 3 + 2];       // edge (x', t)
+            const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];  // edge (t, s)
+            int ps = grouped ? atomicAdd(&cS[mid_slot(keyS, s)], 1) : atomicAdd(&cS[0], 1);
+            MidS rs; rs.sm2 = v2 * m2; rs.sm3 = v3 * m3; rs.f2 = f2; rs.f3 = f3; rs.mu = m2 + m3; rs.s = s; rs.pad = 0;
+            A.midS[bS + ps] = rs;
+            for (long long ap = A.att_ptr[s]; ap < A.att_ptr[s + 1]; ap++) {
+                const int x = A.att_idx[ap];
+                const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
+                int px = grouped ? atomicAdd(&cX[mid_slot(keyX, x)], 1) : atomicAdd(&cX[0], 1);
+                MidX rx; rx.sm2 = v2 * m2; rx.sm3 = v3 * m3; rx.sm4 = v4 * m4; rx.f2 = f2; rx.f3 = f3; rx.f4 = f4;
+                rx.mu = (m2 + m3) + m4; rx.x = x; rx.pad = 0;
+                A.midX[bX + px] = rx;
+            }
+        }
+    });
+}
+
+struct Path2Args {
+    PathArgs P;
+    const int *nb_id;                     // [I] position of a non-bridge record in nb_list, -1 otherwise
+    const long long *ptrX; const long long *ptrS;
+    const MidX *midX; const MidS *midS; const MidDir *dirX; const MidDir *dirS; const int *ngX; const int *ngS;
+};
+
+// merge a lane's register sums into the start's row (distinct ends per call)
+__device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, double s_hi, double s_lo, double c_hi, double c_lo) {
+    bool first = false;
+    if (active) {
+        double *a = W.acc + (size_t)end * 4;
+        double h0 = a[0], l0 = a[1], h1 = a[2], l1 = a[3];
+        first = (h1 == 0.0);
+        dd_add(h0, l0, s_hi); dd_add(h0, l0, s_lo);
+        dd_add(h1, l1, c_hi); dd_add(h1, l1, c_lo);
+        a[0] = h0; a[1] = l0; a[2] = h1; a[3] = l1;
+    }
+    unsigned long long m = __ballot(first);
+    if (first) W.touched[W.nt + __popcll(m & lanemask_lt())] = end;
+    W.nt += __popcll(m);
+}
+
+// all joint paths of one head: start -(e1)- x' - ... ; has_e1 = false for start == x'
+__device__ __forceinline__ void head_paths(const Path2Args &B, WaveAcc &W, int xp, bool has_e1, double sm1, double mu1, double f1) {
+    const PathArgs &A = B.P;
+    const int lane = lane_id();
+    const int k = A.k;
+    const int w = B.nb_id[xp];
+    const long long bX = B.ptrX[w], bS = B.ptrS[w];
+    const int ngx = B.ngX[w], ngs = B.ngS[w];
+    // X groups: ends {x} U NN(x); one group at a time, lanes = ends
+    for (int g = 0; g < ngx; g++) {
+        const MidDir d = B.dirX[bX + g];
+        const int x = (d.key >= 0) ? d.key : B.midX[bX + d.off].x;
+        const int ne = 1 + A.kcnt[(size_t)x * 2 + 1];
+        for (int b = 0; b < ne; b += 64) {
+            const int idx = b + lane;
+            const bool act = idx < ne;
+            int end = x;
+            double sm5 = 0.0, mu5 = 0.0, f5 = 1.0;
+            const bool has5 = act && idx > 0;
+            if (has5) {
+                size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
+                end = A.kcol[o];
+                sm5 = A.kval[o * 3] * A.kval[o * 3 + 1]; mu5 = A.kval[o * 3 + 1]; f5 = A.kval[o * 3 + 2];
+            }
+            double s_hi = 0.0, s_lo = 0.0, c_hi = 0.0, c_lo = 0.0;
+            for (int r = 0; r < d.cnt; r++) {
+                const MidX m = B.midX[bX + d.off + r];
+                double sm, c;
+                if (has_e1) { sm = ((sm1 + m.sm2) + m.sm3) + m.sm4; c = ((f1 * m.f2) * m.f3) * m.f4; }
+                else { sm = (m.sm2 + m.sm3) + m.sm4; c = (m.f2 * m.f3) * m.f4; }
+                double mu = m.mu + (has_e1 ? mu1 : 0.0);
+                if (has5) { sm = sm + sm5; c = c * f5; mu = mu + mu5; }
+                const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
+                dd_add(s_hi, s_lo, sp * c);
+                dd_add(c_hi, c_lo, c);
+            }
+            flush_end(W, act, end, s_hi, s_lo, c_hi, c_lo);
+            W.paths += (unsigned long long)d.cnt * (unsigned long long)__popcll(__ballot(act));
+        }
+    }
+    // S groups: end s; lanes = groups
+    for (int g0 = 0; g0 < ngs; g0 += 64) {
+        const int g = g0 + lane;
+        const bool act = g < ngs;
+        int end = 0;
+        double s_hi = 0.0, s_lo = 0.0, c_hi = 0.0, c_lo = 0.0;
+        int cnt = 0;
+        if (act) {
+            const MidDir d = B.dirS[bS + g];
+            cnt = d.cnt;
+            for (int r = 0; r < d.cnt; r++) {
+                const MidS m = B.midS[bS + d.off + r];
+                end = m.s;
+                double sm, c, mu;
+                if (has_e1) { sm = (sm1 + m.sm2) + m.sm3; c = (f1 * m.f2) * m.f3; mu = m.mu + mu1; }
+                else { sm = m.sm2 + m.sm3; c = m.f2 * m.f3; mu = m.mu; }
+                const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
+                dd_add(s_hi, s_lo, sp * c);
+                dd_add(c_hi, c_lo, c);
+            }
+        }
+        // without grouping (table overflow) two lanes may hold the same s: flush lane by lane then
+        if (ngs > 0 && B.dirS[bS].key < 0) {
+            for (int l = 0; l < 64; l++) flush_end(W, act && lane == l, end, s_hi, s_lo, c_hi, c_lo);
+        } else {
+            flush_end(W, act, end, s_hi, s_lo, c_hi, c_lo);
+        }
+        W.paths += (unsigned long long)wave_sum_ll((long long)cnt);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
+    const PathArgs &A = B.P;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.n_slots) return;
+    const int lane = lane_id();
+    WaveAcc W;
+    W.paths = 0;
+    unsigned long long cand_total = 0;
+    for (;;) {
+        int u_ = 0;
+        if (lane == 0) u_ = (int)atomicAdd(&A.counters[2], 1ull);
+        const int unit = uniform(u_);
+        if (unit >= A.n_units) break;  // every wave reaches this exit: the cursor only grows
+        const int start = uniform(A.unit_start[unit]);
+        const int c = uniform(A.unit_c[unit]);
+        const int G = uniform(A.unit_G[unit]);
+        const int row = uniform(A.unit_row[unit]);
+        if (row < 0) {
+            W.acc = A.acc + (size_t)slot * A.I * 4;
+            W.touched = A.touched + (size_t)slot * A.I;
+        } else {
+            W.acc = A.hacc + (size_t)row * A.I * 4;
+            W.touched = A.htouched + (size_t)row * A.I;
+        }
+        W.nt = 0;
+        int ent = 0;  // entries of a start: role T, the head (start = x'), the heads (start in NN(x'))
+        if (A.flags[start] & 2) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
+            if (G == 1 || ent % G == c) {
+                Carry none; none.sm = 0; none.mu = 0; none.c = 0;
+                through_t(A, W, start, false, none);
+            }
+            ent++;
+        }
+        if (A.cls[start] == 2) {    // target_path: start = x' (extender.py:160-163)
+            if (G == 1 || ent % G == c) head_paths(B, W, start, false, 0.0, 0.0, 1.0);
+            ent++;
+        }
+        {                           // longest_path: start = y' in NN(x') (extender.py:164-167)
+            long long r0 = A.rnn_ptr[start], r1 = A.rnn_ptr[start + 1];
+            for (long long rp = r0; rp < r1; rp++) {
+                if (G == 1 || ent % G == c) {
+                    const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1], fr = A.rnn_val[rp * 3 + 2];
+                    head_paths(B, W, A.rnn_idx[rp], true, sv * mu, mu, fr);
+                }
+                ent++;
+            }
+        }
+        if (row < 0) cand_total += finalize_start(A, W.acc, W.touched, W.nt, start);
+        else if (lane == 0) A.unit_nt[unit] = W.nt;
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], cand_total);
+        atomicAdd(&A.counters[1], W.paths);
+    }
+}
+
 // heavy starts: add the G partial rows into the first one (double-double merge), then finalise
 __global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -771,7 +1078,7 @@ int xmap_path_weights(void *stream, int32_t n_items, int top_k, const uint8_t *c
     return XMAP_OK;
 }
 
-int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
                       const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
                       const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
                       const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
@@ -803,7 +1110,13 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *c
         A.counters = (unsigned long long *)d_counters;
         int slots = n_slots < n_units ? n_slots : n_units;
         A.n_slots = slots;
-        k_paths<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(A);
+        if (mid) {
+            Path2Args B = *mid;
+            B.P = A;
+            k_paths2<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(B);
+        } else {
+            k_paths<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(A);
+        }
         XM_LAUNCH_CHECK();
         if (n_heavy > 0) {
             k_merge<<<dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, st>>>(A, n_heavy, heavy_unit0);
@@ -819,6 +1132,83 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *c
             return XMAP_ERR_CAPACITY;
         }
     }
+    return XMAP_OK;
+}
+
+int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters) {
+    return extend_paths_impl(nullptr, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
+}
+
+int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
+                       const int32_t *nb_id, const int64_t *mid_ptrX, const int64_t *mid_ptrS, const void *midX,
+                       const void *midS, const void *dirX, const void *dirS, const int32_t *ngX, const int32_t *ngS) {
+    XM_ARG(nb_id && mid_ptrX && mid_ptrS && midX && midS && dirX && dirS && ngX && ngS);
+    Path2Args B;
+    memset(&B, 0, sizeof(B));
+    B.nb_id = nb_id; B.ptrX = (const long long *)mid_ptrX; B.ptrS = (const long long *)mid_ptrS;
+    B.midX = (const MidX *)midX; B.midS = (const MidS *)midS; B.dirX = (const MidDir *)dirX; B.dirS = (const MidDir *)dirS;
+    B.ngX = ngX; B.ngS = ngS;
+    return extend_paths_impl(&B, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
+}
+
+static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                        const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                        const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                        const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list) {
+    MidArgs A;
+    memset(&A, 0, sizeof(A));
+    A.I = n_items; A.k = top_k; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval; A.flags = flags;
+    A.att_ptr = (const long long *)att_ptr; A.att_idx = att_idx; A.att_val = att_val;
+    A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
+    A.n_nb = n_nb; A.nb_list = nb_list;
+    return A;
+}
+
+int xmap_mid_count(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                   const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                   const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, int64_t *cntX, int64_t *cntS) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && cntX && cntS);
+    if (n_nb == 0) return XMAP_OK;
+    MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
+                         src_flag, n_nb, nb_list);
+    A.cntX = (long long *)cntX; A.cntS = (long long *)cntS;
+    k_mid_count<<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(A);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_mid_fill(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                  const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                  const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                  const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int64_t *ptrX, const int64_t *ptrS,
+                  void *midX, void *midS, void *dirX, void *dirS, int32_t *ngX, int32_t *ngS) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && ptrX && ptrS);
+    XM_ARG(midX && midS && dirX && dirS && ngX && ngS);
+    if (n_nb == 0) return XMAP_OK;
+    MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
+                         src_flag, n_nb, nb_list);
+    A.ptrX = (const long long *)ptrX; A.ptrS = (const long long *)ptrS;
+    A.midX = (MidX *)midX; A.midS = (MidS *)midS; A.dirX = (MidDir *)dirX; A.dirS = (MidDir *)dirS;
+    A.ngX = ngX; A.ngS = ngS;
+    k_mid_fill<<<dim3((unsigned)n_nb), dim3(64), 0, (hipStream_t)stream>>>(A);
+    XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
 }

@@ -500,8 +500,43 @@ class Engine(object):
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
+    def mid_lists(self, E):
+        """middle lists of all joint paths, grouped per (x', x) and (x', s) (stage_b.hip, second formulation)"""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        nb_list = torch.nonzero(E.cls[:I] == 2).flatten().to(torch.int32).contiguous()
+        n_nb = int(nb_list.numel())
+        M = ExtResult()
+        M.n_nb = n_nb
+        M.nb_list = nb_list if n_nb else self._zeros(1, torch.int32)
+        M.nb_id = torch.full((max(I, 1),), -1, dtype=torch.int32, device=self.dev)
+        if n_nb:
+            M.nb_id[nb_list.long()] = torch.arange(n_nb, dtype=torch.int32, device=self.dev)
+        cntX = self._zeros(max(n_nb, 1), torch.int64)
+        cntS = self._zeros(max(n_nb, 1), torch.int64)
+        common = (i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags), vp(E.att[0]), vp(E.att[1]),
+                  vp(E.att[2]), vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]), i32(n_nb), vp(M.nb_list))
+        with self.timed("mid_build"):
+            check(lib.xmap_mid_count(st, *common, vp(cntX), vp(cntS)))
+            M.ptrX = self._zeros(n_nb + 1, torch.int64)
+            M.ptrS = self._zeros(n_nb + 1, torch.int64)
+            tx, ts = C.c_int64(0), C.c_int64(0)
+            check(lib.xmap_exclusive_scan_i64(st, vp(cntX), vp(M.ptrX), i64(n_nb), C.byref(tx)))
+            check(lib.xmap_exclusive_scan_i64(st, vp(cntS), vp(M.ptrS), i64(n_nb), C.byref(ts)))
+            M.nX, M.nS = int(tx.value), int(ts.value)
+            M.midX = self._empty(max(M.nX, 1) * 64, torch.uint8)
+            M.midS = self._empty(max(M.nS, 1) * 48, torch.uint8)
+            M.dirX = self._empty(max(M.nX, 1) * 3, torch.int32)
+            M.dirS = self._empty(max(M.nS, 1) * 3, torch.int32)
+            M.ngX = self._zeros(max(n_nb, 1), torch.int32)
+            M.ngS = self._zeros(max(n_nb, 1), torch.int32)
+            check(lib.xmap_mid_fill(st, *common, vp(M.ptrX), vp(M.ptrS), vp(M.midX), vp(M.midS), vp(M.dirX),
+                                    vp(M.dirS), vp(M.ngX), vp(M.ngS)))
+        return M
+
     def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None,
-               start_split=None):
+               start_split=None, algo="mid"):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
         I = R.n_items
@@ -513,6 +548,8 @@ class Engine(object):
             E.rnn = self._reverse(S, E, 2, None)
         U = self.path_units(E, start_range, chunk, start_split=start_split)
         E.units = U
+        M = self.mid_lists(E) if algo == "mid" else None
+        E.mid = M
         slot_budget = 48 << 30
         n_slots = int(max(4, min(n_slots, slot_budget // (36 * max(I, 1)), max(U.n_units, 4))))
         acc = self._zeros(n_slots * max(I, 1) * 4, torch.float64)
@@ -531,9 +568,7 @@ class Engine(object):
             xs_off = self._zeros(max(I, 1), torch.int64) if cap else None
             xs_end = self._empty(max(cap, 1), torch.int32) if cap else None
             xs_val = self._empty(max(cap, 1), torch.float64) if cap else None
-            with self.timed("paths"):
-                rc = lib.xmap_extend_paths(
-                    st, i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags),
+            args = (st, i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags),
                     vp(E.att[0]), vp(E.att[1]), vp(E.att[2]),
                     vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]),
                     vp(E.rnn[0]), vp(E.rnn[1]), vp(E.rnn[2]),
@@ -542,6 +577,12 @@ class Engine(object):
                     i32(n_slots), vp(acc), vp(touched), vp(hacc), vp(htouched),
                     vp(E.n_cand), vp(E.top_end), vp(E.top_val),
                     i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
+            with self.timed("paths"):
+                if M is not None:
+                    rc = lib.xmap_extend_paths2(*args, vp(M.nb_id), vp(M.ptrX), vp(M.ptrS), vp(M.midX), vp(M.midS),
+                                                vp(M.dirX), vp(M.dirS), vp(M.ngX), vp(M.ngS))
+                else:
+                    rc = lib.xmap_extend_paths(*args)
             if rc == abi.ERR_CAPACITY:
                 cap = int(h_cnt[0])
                 continue
