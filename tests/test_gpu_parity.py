@@ -224,8 +224,8 @@ def test_determinism_and_partitions(dev):
     S = eng.item_sim("adjust_cosine", CAP)
     E1 = eng.extend(S, 5, full=True, chunk=1 << 40)
     E2 = eng.extend(S, 5, full=True, chunk=64, n_slots=64)
-    E3 = eng.extend(S, 5, full=True, algo="enum")              # first formulation: one accumulate per path
-    E4 = eng.extend(S, 5, full=True, algo="enum", chunk=64)
+    E3 = eng.extend(S, 5, full=True, algo="mid")               # middle lists + register-tile accumulation
+    E4 = eng.extend(S, 5, full=True, algo="mid", chunk=64)
     for Ex in (E3, E4):
         assert Ex.n_paths == E1.n_paths and Ex.n_out == E1.n_out
         for x, y in zip(_xsim_lists(E1, r.n_items), _xsim_lists(Ex, r.n_items)):

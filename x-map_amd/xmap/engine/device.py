@@ -536,7 +536,7 @@ class Engine(object):
         return M
 
     def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None,
-               start_split=None, algo="mid"):
+               start_split=None, algo="enum"):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
         I = R.n_items
