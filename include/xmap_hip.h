@@ -216,23 +216,26 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *c
                       int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters /*[4] device*/,
                       int64_t *h_counters /*[4]*/);
 
-/* Second formulation of the enumeration ("middle lists", stage_b.hip): per non-bridge record x' (nb_list) the middles
- * (t,s,x) [64-byte records] and (t,s) [48-byte records] of all joint paths through x' are materialised once, grouped by
- * x resp. s (directory entries of 12 bytes: key, offset, count).  xmap_mid_count sizes them (cntX/cntS per x'; scan them
- * into ptrX/ptrS with xmap_exclusive_scan_i64), xmap_mid_fill writes them.  xmap_extend_paths2 is xmap_extend_paths with
- * the joint paths streamed from these lists: a lane keeps its end's double-double sums in registers across a group, so
- * a start's row is touched once per (head, group) instead of once per path.  Same results (the sums are exact).
- * nb_id[i] = position of i in nb_list, -1 for other items.  dirX/dirS need one entry per record (upper bound). */
-int xmap_mid_count(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+/* Second formulation of the enumeration ("middle lists", stage_b.hip): per non-bridge record x' (nb_list, n_nb of
+ * them; nb_id[i] = position of i in nb_list or -1) the middles (t,s,x) of all joint paths through x' are materialised
+ * once as 64-byte records grouped per tile (x', x).  A dense n_nb x n_nb table gives the tile sizes:
+ *   xmap_mid_tally : tile_cnt[x'][x] and ng[x'] = number of non-empty tiles of x';
+ *   (caller: exclusive scans tile_cnt -> tile_off [n_nb*n_nb+1], ng -> dir_ptr [n_nb+1]; allocates dir, midX)
+ *   xmap_mid_place : the tile directory of every x' (16 B per tile: x index, count, offset) and the records.
+ * xmap_extend_paths2 is xmap_extend_paths with the joint paths streamed from these lists: a lane keeps its end's
+ * double-double sums in registers across a tile, so a start's row is touched once per (head, tile) instead of once
+ * per path.  Same results (the sums are exact). */
+int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                    const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
-                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, int64_t *cntX, int64_t *cntS);
-int xmap_mid_fill(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
-                  const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
-                  const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
-                  const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int64_t *ptrX, const int64_t *ptrS,
-                  void *midX /*64 B each*/, void *midS /*48 B each*/, void *dirX /*12 B each*/, void *dirS,
-                  int32_t *ngX /*[n_nb]*/, int32_t *ngS /*[n_nb]*/);
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                   int32_t *tile_cnt /*[n_nb*n_nb]*/, int32_t *ng /*[n_nb]*/);
+int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                   const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                   const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                   int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
+                   void *dir /*16 B per tile*/, void *midX /*64 B per record*/);
 int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
                        const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
                        const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
@@ -242,8 +245,8 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
                        const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
                        int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
                        int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
-                       const int32_t *nb_id, const int64_t *mid_ptrX, const int64_t *mid_ptrS, const void *midX,
-                       const void *midS, const void *dirX, const void *dirS, const int32_t *ngX, const int32_t *ngS);
+                       const int32_t *nb_id, const int32_t *nb_list, const void *midX, const void *dir,
+                       const int64_t *dir_ptr, const int32_t *ng);
 
 /* Candidate arrays from explicit X-Sim lists (an extended_simRDD that did not come from this engine,
  * e.g. a canonically re-fed one): CSR (xs_ptr, xs_end, xs_val) -> n_cand, top_end, top_val as above. */

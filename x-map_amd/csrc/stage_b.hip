@@ -589,165 +589,91 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
 // =============================================================================================
 // Second formulation of the enumeration ("middle lists").  Every joint path has the shape
 //   [y'] - x' - t - s - [x - [y]]      with x', x non-bridge items, t in NB_BB(x'), (t,s) joint.
-// For each non-bridge x' the middles (t,s,x) ("X records") and (t,s) ("S records") are materialised ONCE,
-// grouped by x resp. s.  A head (start, x') then streams the groups of x': all records of one group hit the
-// same ends {x} U NN(x), so each lane keeps its end's double-double sums in REGISTERS across the group and the
-// start's row in HBM is touched once per (head, group) instead of once per path (about 4x fewer random
-// read-modify-writes at BASELINE configs[1]).  The edge products sim*mutu and the fractions are stored per edge,
-// so a path's (sum sim*mutu, sum mutu, prod frac) is rebuilt in the reference's left-to-right order, bit for bit.
-struct MidX { double sm2, sm3, sm4, f2, f3, f4, mu; int x; int pad; };   // 64 B
-struct MidS { double sm2, sm3, f2, f3, mu; int s; int pad; };            // 48 B
-struct MidDir { int key; int off; int cnt; };                            // group directory entry
+// For each non-bridge x' the middles (t,s,x) are materialised ONCE, grouped by x (one "tile" per (x', x); a dense
+// n_nb x n_nb count table gives the tile offsets, so the build is a tally pass + a placement pass over
+// (x', t) work items -- no per-x' serial section).  A head (start, x') then streams the tiles of x': all
+// records of one tile hit the same ends {x} U NN(x), so each lane keeps its end's double-double sums in
+// REGISTERS across the tile and the start's row in HBM is touched once per (head, tile) instead of once per
+// path.  The edge products sim*mutu and the fractions are stored per edge, so a path's (sum sim*mutu, sum
+// mutu, prod frac) is rebuilt in the reference's left-to-right order, bit for bit.
+struct MidX { double sm2, sm3, sm4, f2, f3, f4, mu; int xid; int pad; };   // 64 B; xid = index of x in nb_list
+struct MidDir { int xid; int cnt; long long off; };                        // one tile of x': records [off, off+cnt)
 
-constexpr int MID_LOG = 12;
-constexpr int MID_SLOTS = 1 << MID_LOG;
+constexpr int MID_GC = 64;   // tiles per work entry of the path kernel
 
 struct MidArgs {
     int I, k;
     const uint8_t *cls; const int *kcnt; const int *kcol; const double *kval; const uint8_t *flags;
     const long long *att_ptr; const int *att_idx; const double *att_val;
     const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
-    int n_nb; const int *nb_list;                 // the non-bridge records x'
-    long long *cntX; long long *cntS;             // [n_nb] record counts (count pass)
-    const long long *ptrX; const long long *ptrS; // [n_nb+1]
-    MidX *midX; MidS *midS; MidDir *dirX; MidDir *dirS; int *ngX; int *ngS;   // fill pass
+    int n_nb; const int *nb_list; const int *nb_id;
+    int *tile_cnt;                 // [n_nb * n_nb] tally, then placement cursor
+    const long long *tile_off;     // [n_nb * n_nb + 1]
+    MidX *midX;
 };
 
-// enumerate the (t,s) pairs of x' in chunks of 64 lanes; f(lane has pair, t-list position q, src position p)
-template <typename F>
-__device__ __forceinline__ void for_each_ts(const MidArgs &A, int xp, F f) {
+// one wave per (x', position q in NB_BB(x')): lanes over the joint (t,s), each walks attach(s)
+template <bool PLACE>
+__global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)A.n_nb * A.k) return;
+    const int xpid = (int)(w / A.k), q = (int)(w % A.k);
+    const int xp = A.nb_list[xpid];
+    if (q >= A.kcnt[(size_t)xp * 2]) return;
+    const size_t o = ((size_t)xp * 2) * A.k + q;
+    const int t = A.kcol[o];
+    if (!(A.flags[t] & 2)) return;
     const int lane = lane_id();
-    const int nb = A.kcnt[(size_t)xp * 2];
-    for (int q = 0; q < nb; q++) {
-        const size_t o = ((size_t)xp * 2) * A.k + q;
-        const int t = A.kcol[o];
-        if (!(A.flags[t] & 2)) continue;
-        const long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
-        for (long long base = s0; base < s1; base += 64) {
-            const long long p = base + lane;
-            const bool act = (p < s1) && (A.src_flag[p] & 1);
-            f(act, o, p);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mid_count(MidArgs A) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= A.n_nb) return;
-    const int xp = A.nb_list[w];
-    long long nS = 0, nX = 0;
-    for_each_ts(A, xp, [&](bool act, size_t o, long long p) {
-        if (act) {
-            const int s = A.src_idx[p];
-            nS += 1;
-            nX += A.att_ptr[s + 1] - A.att_ptr[s];
-        }
-    });
-    nS = wave_sum_ll(nS);
-    nX = wave_sum_ll(nX);
-    if (lane_id() == 0) { A.cntS[w] = nS; A.cntX[w] = nX; }
-}
-
-// open-addressing insert into a wave-private LDS table; returns slot or -1 on overflow
-__device__ __forceinline__ int mid_slot(uint32_t *key, int k) {
-    uint32_t h = ((uint32_t)k * 0x9E3779B1u) >> (32 - MID_LOG);
-    for (int probes = 0; probes < MID_SLOTS; probes++) {
-        uint32_t prev = atomicCAS(&key[h], 0xFFFFFFFFu, (uint32_t)k);
-        if (prev == 0xFFFFFFFFu || prev == (uint32_t)k) return (int)h;
-        h = (h + 1) & (MID_SLOTS - 1);
-    }
-    return -1;
-}
-
-// one wave per x': two enumerations -- group sizes, then placement -- for the X records (grouped by x) and the S
-// records (grouped by s).  If a table overflows, every record becomes its own group (correct, just less reuse).
-__global__ __launch_bounds__(64) void k_mid_fill(MidArgs A) {
-    __shared__ uint32_t keyX[MID_SLOTS];
-    __shared__ int cX[MID_SLOTS];
-    __shared__ uint32_t keyS[MID_SLOTS];
-    __shared__ int cS[MID_SLOTS];
-    const int w = blockIdx.x;
-    if (w >= A.n_nb) return;
-    const int lane = lane_id();
-    const int xp = A.nb_list[w];
-    const long long bX = A.ptrX[w], bS = A.ptrS[w];
-    const long long nX = A.ptrX[w + 1] - bX, nS = A.ptrS[w + 1] - bS;
-    for (int s = lane; s < MID_SLOTS; s += 64) { keyX[s] = 0xFFFFFFFFu; cX[s] = 0; keyS[s] = 0xFFFFFFFFu; cS[s] = 0; }
-    int ovf = 0;
-    for_each_ts(A, xp, [&](bool act, size_t o, long long p) {
-        if (act) {
-            const int s = A.src_idx[p];
-            int hs = mid_slot(keyS, s);
-            if (hs < 0) ovf = 1; else atomicAdd(&cS[hs], 1);
-            for (long long ap = A.att_ptr[s]; ap < A.att_ptr[s + 1]; ap++) {
-                int hx = mid_slot(keyX, A.att_idx[ap]);
-                if (hx < 0) ovf = 1; else atomicAdd(&cX[hx], 1);
-            }
-        }
-    });
-    const bool grouped = !__ballot(ovf);
-    // group offsets = exclusive scan of the counts in slot order; directory entries in slot order
-    int ngx = 0, ngs = 0;
-    if (grouped) {
-        int runX = 0, runS = 0;
-        for (int s0 = 0; s0 < MID_SLOTS; s0 += 64) {
-            const int s = s0 + lane;
-            int cx = cX[s], cs = cS[s];
-            int ix = cx, is = cs;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int ox = __shfl_up(ix, d, 64), os = __shfl_up(is, d, 64);
-                if (lane >= d) { ix += ox; is += os; }
-            }
-            const unsigned long long mx = __ballot(cx > 0), ms = __ballot(cs > 0);
-            if (cx > 0) {
-                MidDir d; d.key = (int)keyX[s]; d.off = runX + ix - cx; d.cnt = cx;
-                A.dirX[bX + ngx + __popcll(mx & lanemask_lt())] = d;
-            }
-            if (cs > 0) {
-                MidDir d; d.key = (int)keyS[s]; d.off = runS + is - cs; d.cnt = cs;
-                A.dirS[bS + ngs + __popcll(ms & lanemask_lt())] = d;
-            }
-            cX[s] = runX + ix - cx;    // becomes the placement cursor of the group
-            cS[s] = runS + is - cs;
-            runX += __shfl(ix, 63, 64);
-            runS += __shfl(is, 63, 64);
-            ngx += __popcll(mx);
-            ngs += __popcll(ms);
-        }
-    } else {
-        for (long long r = lane; r < nX; r += 64) { MidDir d; d.key = -1; d.off = (int)r; d.cnt = 1; A.dirX[bX + r] = d; }
-        for (long long r = lane; r < nS; r += 64) { MidDir d; d.key = -1; d.off = (int)r; d.cnt = 1; A.dirS[bS + r] = d; }
-        ngx = (int)nX; ngs = (int)nS;
-        if (lane == 0) { cX[0] = 0; cS[0] = 0; }
-    }
-    if (lane == 0) { A.ngX[w] = ngx; A.ngS[w] = ngs; }
-    // placement
-    for_each_ts(A, xp, [&](bool act, size_t o, long long p) {
-        if (act) {
-            const int s = A.src_idx[p];
-            const double v2 = A.kval[o * 3], m2 = A.kval[o * 3 + 1], f2 = A.kval[o * 3 + 2];       // edge (x', t)
-            const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];  // edge (t, s)
-            int ps = grouped ? atomicAdd(&cS[mid_slot(keyS, s)], 1) : atomicAdd(&cS[0], 1);
-            MidS rs; rs.sm2 = v2 * m2; rs.sm3 = v3 * m3; rs.f2 = f2; rs.f3 = f3; rs.mu = m2 + m3; rs.s = s; rs.pad = 0;
-            A.midS[bS + ps] = rs;
-            for (long long ap = A.att_ptr[s]; ap < A.att_ptr[s + 1]; ap++) {
-                const int x = A.att_idx[ap];
+    const double v2 = A.kval[o * 3], m2 = A.kval[o * 3 + 1], f2 = A.kval[o * 3 + 2];              // edge (x', t)
+    for (long long p = A.src_ptr[t] + lane; p < A.src_ptr[t + 1]; p += 64) {
+        if (!(A.src_flag[p] & 1)) continue;
+        const int s = A.src_idx[p];
+        const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];  // edge (t, s)
+        for (long long ap = A.att_ptr[s]; ap < A.att_ptr[s + 1]; ap++) {
+            const int xid = A.nb_id[A.att_idx[ap]];
+            const size_t tile = (size_t)xpid * A.n_nb + xid;
+            if (!PLACE) {
+                atomicAdd(&A.tile_cnt[tile], 1);
+            } else {
+                const long long pos = A.tile_off[tile] + atomicAdd(&A.tile_cnt[tile], 1);
                 const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
-                int px = grouped ? atomicAdd(&cX[mid_slot(keyX, x)], 1) : atomicAdd(&cX[0], 1);
-                MidX rx; rx.sm2 = v2 * m2; rx.sm3 = v3 * m3; rx.sm4 = v4 * m4; rx.f2 = f2; rx.f3 = f3; rx.f4 = f4;
-                rx.mu = (m2 + m3) + m4; rx.x = x; rx.pad = 0;
-                A.midX[bX + px] = rx;
+                MidX r;
+                r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
+                r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
+                A.midX[pos] = r;
             }
         }
-    });
+    }
+}
+
+// directory of the non-empty tiles of every x' (row of the dense table): count, then fill
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, const long long *tile_off,
+                                                 int *ng, const long long *dir_ptr, MidDir *dir) {
+    const int xpid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xpid >= n_nb) return;
+    const int lane = lane_id();
+    const size_t row = (size_t)xpid * n_nb;
+    long long out = FILL ? dir_ptr[xpid] : 0;
+    int total = 0;
+    for (int b = 0; b < n_nb; b += 64) {
+        const int xid = b + lane;
+        const int c = (xid < n_nb) ? tile_cnt[row + xid] : 0;
+        const unsigned long long m = __ballot(c > 0);
+        if (FILL && c > 0) {
+            MidDir d; d.xid = xid; d.cnt = c; d.off = tile_off[row + xid];
+            dir[out + __popcll(m & lanemask_lt())] = d;
+        }
+        out += __popcll(m);
+        total += __popcll(m);
+    }
+    if (!FILL && lane == 0) ng[xpid] = total;
 }
 
 struct Path2Args {
     PathArgs P;
-    const int *nb_id;                     // [I] position of a non-bridge record in nb_list, -1 otherwise
-    const long long *ptrX; const long long *ptrS;
-    const MidX *midX; const MidS *midS; const MidDir *dirX; const MidDir *dirS; const int *ngX; const int *ngS;
+    const int *nb_id; const int *nb_list;
+    const MidX *midX; const MidDir *dir; const long long *dir_ptr; const int *ng;
 };
 
 // merge a lane's register sums into the start's row (distinct ends per call)
@@ -766,18 +692,41 @@ __device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, doub
     W.nt += __popcll(m);
 }
 
-// all joint paths of one head: start -(e1)- x' - ... ; has_e1 = false for start == x'
-__device__ __forceinline__ void head_paths(const Path2Args &B, WaveAcc &W, int xp, bool has_e1, double sm1, double mu1, double f1) {
+// paths [start -] x' - t - s of one head (end s): lanes over the joint (t,s) of each t in NB_BB(x')
+__device__ __forceinline__ void head_S(const PathArgs &A, WaveAcc &W, int xp, bool has_e1, Carry e1) {
+    const int lane = lane_id();
+    const int nb = A.kcnt[(size_t)xp * 2];
+    for (int q = 0; q < nb; q++) {
+        const size_t o = ((size_t)xp * 2) * A.k + q;
+        const int t = A.kcol[o];
+        if (!(A.flags[t] & 2)) continue;
+        const Carry c2 = has_e1 ? add_edge(e1, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2])
+                                : first_edge(A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+        const long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
+        for (long long base = s0; base < s1; base += 64) {
+            const long long p = base + lane;
+            const bool act = (p < s1) && (A.src_flag[p] & 1);
+            int s = 0;
+            Carry c = c2;
+            if (act) {
+                s = A.src_idx[p];
+                c = add_edge(c2, A.src_val[p * 3], A.src_val[p * 3 + 1], A.src_val[p * 3 + 2]);
+            }
+            W.add(act, s, c);
+        }
+    }
+}
+
+// tiles [g0, g1) of x' for one head: ends {x} U NN(x), register accumulation across the records of a tile
+__device__ __forceinline__ void head_X(const Path2Args &B, WaveAcc &W, int xpid, int g0, int g1, bool has_e1,
+                                       double sm1, double mu1, double f1) {
     const PathArgs &A = B.P;
     const int lane = lane_id();
     const int k = A.k;
-    const int w = B.nb_id[xp];
-    const long long bX = B.ptrX[w], bS = B.ptrS[w];
-    const int ngx = B.ngX[w], ngs = B.ngS[w];
-    // X groups: ends {x} U NN(x); one group at a time, lanes = ends
-    for (int g = 0; g < ngx; g++) {
-        const MidDir d = B.dirX[bX + g];
-        const int x = (d.key >= 0) ? d.key : B.midX[bX + d.off].x;
+    const long long dbase = B.dir_ptr[xpid];
+    for (int g = g0; g < g1; g++) {
+        const MidDir d = B.dir[dbase + g];
+        const int x = B.nb_list[d.xid];
         const int ne = 1 + A.kcnt[(size_t)x * 2 + 1];
         for (int b = 0; b < ne; b += 64) {
             const int idx = b + lane;
@@ -791,49 +740,28 @@ __device__ __forceinline__ void head_paths(const Path2Args &B, WaveAcc &W, int x
                 sm5 = A.kval[o * 3] * A.kval[o * 3 + 1]; mu5 = A.kval[o * 3 + 1]; f5 = A.kval[o * 3 + 2];
             }
             double s_hi = 0.0, s_lo = 0.0, c_hi = 0.0, c_lo = 0.0;
-            for (int r = 0; r < d.cnt; r++) {
-                const MidX m = B.midX[bX + d.off + r];
-                double sm, c;
-                if (has_e1) { sm = ((sm1 + m.sm2) + m.sm3) + m.sm4; c = ((f1 * m.f2) * m.f3) * m.f4; }
-                else { sm = (m.sm2 + m.sm3) + m.sm4; c = (m.f2 * m.f3) * m.f4; }
-                double mu = m.mu + (has_e1 ? mu1 : 0.0);
-                if (has5) { sm = sm + sm5; c = c * f5; mu = mu + mu5; }
-                const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
-                dd_add(s_hi, s_lo, sp * c);
-                dd_add(c_hi, c_lo, c);
+            for (int r0 = 0; r0 < d.cnt; r0 += 64) {
+                // the records of the tile are fetched 64 at a time (one per lane), then broadcast lane by lane
+                MidX m;
+                m.sm2 = m.sm3 = m.sm4 = m.f2 = m.f3 = m.f4 = m.mu = 0.0;
+                if (r0 + lane < d.cnt) m = B.midX[d.off + r0 + lane];
+                const int nr = (d.cnt - r0) < 64 ? (d.cnt - r0) : 64;
+                for (int r = 0; r < nr; r++) {
+                    const double sm2 = rld(m.sm2, r), sm3 = rld(m.sm3, r), sm4 = rld(m.sm4, r);
+                    const double f2 = rld(m.f2, r), f3 = rld(m.f3, r), f4 = rld(m.f4, r), mum = rld(m.mu, r);
+                    double sm, c;
+                    if (has_e1) { sm = ((sm1 + sm2) + sm3) + sm4; c = ((f1 * f2) * f3) * f4; }
+                    else { sm = (sm2 + sm3) + sm4; c = (f2 * f3) * f4; }
+                    double mu = mum + (has_e1 ? mu1 : 0.0);
+                    if (has5) { sm = sm + sm5; c = c * f5; mu = mu + mu5; }
+                    const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
+                    dd_add(s_hi, s_lo, sp * c);
+                    dd_add(c_hi, c_lo, c);
+                }
             }
             flush_end(W, act, end, s_hi, s_lo, c_hi, c_lo);
             W.paths += (unsigned long long)d.cnt * (unsigned long long)__popcll(__ballot(act));
         }
-    }
-    // S groups: end s; lanes = groups
-    for (int g0 = 0; g0 < ngs; g0 += 64) {
-        const int g = g0 + lane;
-        const bool act = g < ngs;
-        int end = 0;
-        double s_hi = 0.0, s_lo = 0.0, c_hi = 0.0, c_lo = 0.0;
-        int cnt = 0;
-        if (act) {
-            const MidDir d = B.dirS[bS + g];
-            cnt = d.cnt;
-            for (int r = 0; r < d.cnt; r++) {
-                const MidS m = B.midS[bS + d.off + r];
-                end = m.s;
-                double sm, c, mu;
-                if (has_e1) { sm = (sm1 + m.sm2) + m.sm3; c = (f1 * m.f2) * m.f3; mu = m.mu + mu1; }
-                else { sm = m.sm2 + m.sm3; c = m.f2 * m.f3; mu = m.mu; }
-                const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
-                dd_add(s_hi, s_lo, sp * c);
-                dd_add(c_hi, c_lo, c);
-            }
-        }
-        // without grouping (table overflow) two lanes may hold the same s: flush lane by lane then
-        if (ngs > 0 && B.dirS[bS].key < 0) {
-            for (int l = 0; l < 64; l++) flush_end(W, act && lane == l, end, s_hi, s_lo, c_hi, c_lo);
-        } else {
-            flush_end(W, act, end, s_hi, s_lo, c_hi, c_lo);
-        }
-        W.paths += (unsigned long long)wave_sum_ll((long long)cnt);
     }
 }
 
@@ -862,7 +790,7 @@ __global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
             W.touched = A.htouched + (size_t)row * A.I;
         }
         W.nt = 0;
-        int ent = 0;  // entries of a start: role T, the head (start = x'), the heads (start in NN(x'))
+        int ent = 0;  // work entries of a start: role T; per head: its (t,s) part and chunks of MID_GC tiles
         if (A.flags[start] & 2) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
             if (G == 1 || ent % G == c) {
                 Carry none; none.sm = 0; none.mu = 0; none.c = 0;
@@ -870,17 +798,21 @@ __global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
             }
             ent++;
         }
-        if (A.cls[start] == 2) {    // target_path: start = x' (extender.py:160-163)
-            if (G == 1 || ent % G == c) head_paths(B, W, start, false, 0.0, 0.0, 1.0);
+        const long long r0 = A.rnn_ptr[start], r1 = A.rnn_ptr[start + 1];
+        const int self = (A.cls[start] == 2) ? 1 : 0;
+        for (long long h = -self; h < r1 - r0; h++) {
+            // h == -1: target_path, start = x' (extender.py:160-163); h >= 0: longest_path, start in NN(x') (:164-167)
+            const int xp = (h < 0) ? start : A.rnn_idx[r0 + h];
+            const bool has_e1 = h >= 0;
+            Carry e1; e1.sm = 0; e1.mu = 0; e1.c = 1.0;
+            if (has_e1) e1 = first_edge(A.rnn_val[(r0 + h) * 3], A.rnn_val[(r0 + h) * 3 + 1], A.rnn_val[(r0 + h) * 3 + 2]);
+            if (G == 1 || ent % G == c) head_S(A, W, xp, has_e1, e1);
             ent++;
-        }
-        {                           // longest_path: start = y' in NN(x') (extender.py:164-167)
-            long long r0 = A.rnn_ptr[start], r1 = A.rnn_ptr[start + 1];
-            for (long long rp = r0; rp < r1; rp++) {
-                if (G == 1 || ent % G == c) {
-                    const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1], fr = A.rnn_val[rp * 3 + 2];
-                    head_paths(B, W, A.rnn_idx[rp], true, sv * mu, mu, fr);
-                }
+            const int xpid = B.nb_id[xp];
+            const int ng = B.ng[xpid];
+            for (int g0 = 0; g0 < ng; g0 += MID_GC) {
+                if (G == 1 || ent % G == c)
+                    head_X(B, W, xpid, g0, (g0 + MID_GC < ng) ? g0 + MID_GC : ng, has_e1, e1.sm, e1.mu, e1.c);
                 ent++;
             }
         }
@@ -1156,58 +1088,68 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
                       const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
                       int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
                       int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
-                       const int32_t *nb_id, const int64_t *mid_ptrX, const int64_t *mid_ptrS, const void *midX,
-                       const void *midS, const void *dirX, const void *dirS, const int32_t *ngX, const int32_t *ngS) {
-    XM_ARG(nb_id && mid_ptrX && mid_ptrS && midX && midS && dirX && dirS && ngX && ngS);
+                       const int32_t *nb_id, const int32_t *nb_list, const void *midX, const void *dir,
+                       const int64_t *dir_ptr, const int32_t *ng) {
+    XM_ARG(nb_id && nb_list && midX && dir && dir_ptr && ng);
     Path2Args B;
     memset(&B, 0, sizeof(B));
-    B.nb_id = nb_id; B.ptrX = (const long long *)mid_ptrX; B.ptrS = (const long long *)mid_ptrS;
-    B.midX = (const MidX *)midX; B.midS = (const MidS *)midS; B.dirX = (const MidDir *)dirX; B.dirS = (const MidDir *)dirS;
-    B.ngX = ngX; B.ngS = ngS;
+    B.nb_id = nb_id; B.nb_list = nb_list; B.midX = (const MidX *)midX; B.dir = (const MidDir *)dir;
+    B.dir_ptr = (const long long *)dir_ptr; B.ng = ng;
     return extend_paths_impl(&B, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
 }
 
 static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                         const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                         const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
-                        const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list) {
+                        const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id) {
     MidArgs A;
     memset(&A, 0, sizeof(A));
     A.I = n_items; A.k = top_k; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval; A.flags = flags;
     A.att_ptr = (const long long *)att_ptr; A.att_idx = att_idx; A.att_val = att_val;
     A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
-    A.n_nb = n_nb; A.nb_list = nb_list;
+    A.n_nb = n_nb; A.nb_list = nb_list; A.nb_id = nb_id;
     return A;
 }
 
-int xmap_mid_count(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                    const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
-                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, int64_t *cntX, int64_t *cntS) {
-    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && cntX && cntS);
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                   int32_t *tile_cnt /*[n_nb*n_nb], zeroed here*/, int32_t *ng /*[n_nb]*/) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id && tile_cnt && ng);
     if (n_nb == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
-                         src_flag, n_nb, nb_list);
-    A.cntX = (long long *)cntX; A.cntS = (long long *)cntS;
-    k_mid_count<<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(A);
+                         src_flag, n_nb, nb_list, nb_id);
+    A.tile_cnt = tile_cnt;
+    XM_HIP(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * (size_t)n_nb * (size_t)n_nb, st));
+    const long long waves = (long long)n_nb * top_k;
+    k_mid_build<false><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
+    XM_LAUNCH_CHECK();
+    k_mid_dir<false><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, nullptr, ng, nullptr, nullptr);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
 
-int xmap_mid_fill(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
-                  const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
-                  const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
-                  const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int64_t *ptrX, const int64_t *ptrS,
-                  void *midX, void *midS, void *dirX, void *dirS, int32_t *ngX, int32_t *ngS) {
-    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && ptrX && ptrS);
-    XM_ARG(midX && midS && dirX && dirS && ngX && ngS);
+int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                   const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                   const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                   int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
+                   void *dir /*16 B per tile*/, void *midX /*64 B per record*/) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id);
+    XM_ARG(tile_cnt && tile_off && dir_ptr && dir && midX);
     if (n_nb == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
-                         src_flag, n_nb, nb_list);
-    A.ptrX = (const long long *)ptrX; A.ptrS = (const long long *)ptrS;
-    A.midX = (MidX *)midX; A.midS = (MidS *)midS; A.dirX = (MidDir *)dirX; A.dirS = (MidDir *)dirS;
-    A.ngX = ngX; A.ngS = ngS;
-    k_mid_fill<<<dim3((unsigned)n_nb), dim3(64), 0, (hipStream_t)stream>>>(A);
+                         src_flag, n_nb, nb_list, nb_id);
+    A.tile_cnt = tile_cnt; A.tile_off = (const long long *)tile_off; A.midX = (MidX *)midX;
+    k_mid_dir<true><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, (const long long *)tile_off,
+                                                                            nullptr, (const long long *)dir_ptr, (MidDir *)dir);
+    XM_LAUNCH_CHECK();
+    XM_HIP(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * (size_t)n_nb * (size_t)n_nb, st));   // now the placement cursors
+    const long long waves = (long long)n_nb * top_k;
+    k_mid_build<true><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

@@ -500,43 +500,41 @@ class Engine(object):
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
-    def mid_lists(self, E):
-        """middle lists of all joint paths, grouped per (x', x) and (x', s) (stage_b.hip, second formulation)"""
+    def mid_lists(self, E, table_budget=24 << 30):
+        """middle lists of all joint paths, one tile of records per (x', x) (stage_b.hip, second formulation).
+        Returns None when the dense n_nb x n_nb tile table would not fit the budget (callers fall back to the
+        per-path enumeration)."""
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
         nb_list = torch.nonzero(E.cls[:I] == 2).flatten().to(torch.int32).contiguous()
         n_nb = int(nb_list.numel())
+        if n_nb == 0 or n_nb * n_nb * 12 > table_budget:
+            return None
         M = ExtResult()
-        M.n_nb = n_nb
-        M.nb_list = nb_list if n_nb else self._zeros(1, torch.int32)
+        M.n_nb, M.nb_list = n_nb, nb_list
         M.nb_id = torch.full((max(I, 1),), -1, dtype=torch.int32, device=self.dev)
-        if n_nb:
-            M.nb_id[nb_list.long()] = torch.arange(n_nb, dtype=torch.int32, device=self.dev)
-        cntX = self._zeros(max(n_nb, 1), torch.int64)
-        cntS = self._zeros(max(n_nb, 1), torch.int64)
+        M.nb_id[nb_list.long()] = torch.arange(n_nb, dtype=torch.int32, device=self.dev)
         common = (i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags), vp(E.att[0]), vp(E.att[1]),
-                  vp(E.att[2]), vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]), i32(n_nb), vp(M.nb_list))
+                  vp(E.att[2]), vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]), i32(n_nb), vp(M.nb_list),
+                  vp(M.nb_id))
         with self.timed("mid_build"):
-            check(lib.xmap_mid_count(st, *common, vp(cntX), vp(cntS)))
-            M.ptrX = self._zeros(n_nb + 1, torch.int64)
-            M.ptrS = self._zeros(n_nb + 1, torch.int64)
-            tx, ts = C.c_int64(0), C.c_int64(0)
-            check(lib.xmap_exclusive_scan_i64(st, vp(cntX), vp(M.ptrX), i64(n_nb), C.byref(tx)))
-            check(lib.xmap_exclusive_scan_i64(st, vp(cntS), vp(M.ptrS), i64(n_nb), C.byref(ts)))
-            M.nX, M.nS = int(tx.value), int(ts.value)
-            M.midX = self._empty(max(M.nX, 1) * 64, torch.uint8)
-            M.midS = self._empty(max(M.nS, 1) * 48, torch.uint8)
-            M.dirX = self._empty(max(M.nX, 1) * 3, torch.int32)
-            M.dirS = self._empty(max(M.nS, 1) * 3, torch.int32)
-            M.ngX = self._zeros(max(n_nb, 1), torch.int32)
-            M.ngS = self._zeros(max(n_nb, 1), torch.int32)
-            check(lib.xmap_mid_fill(st, *common, vp(M.ptrX), vp(M.ptrS), vp(M.midX), vp(M.midS), vp(M.dirX),
-                                    vp(M.dirS), vp(M.ngX), vp(M.ngS)))
+            tile_cnt = self._empty(n_nb * n_nb, torch.int32)
+            M.ng = self._zeros(n_nb, torch.int32)
+            check(lib.xmap_mid_tally(st, *common, vp(tile_cnt), vp(M.ng)))
+            tile_off = self._empty(n_nb * n_nb + 1, torch.int64)
+            M.dir_ptr = self._zeros(n_nb + 1, torch.int64)
+            tx, tg = C.c_int64(0), C.c_int64(0)
+            check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(tile_cnt), vp(tile_off), i64(n_nb * n_nb), C.byref(tx)))
+            check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(M.ng), vp(M.dir_ptr), i64(n_nb), C.byref(tg)))
+            M.n_records, M.n_tiles = int(tx.value), int(tg.value)
+            M.dir = self._empty(max(M.n_tiles, 1) * 2, torch.int64)
+            M.midX = self._empty(max(M.n_records, 1) * 8, torch.float64)
+            check(lib.xmap_mid_place(st, *common, vp(tile_cnt), vp(tile_off), vp(M.dir_ptr), vp(M.dir), vp(M.midX)))
         return M
 
     def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None,
-               start_split=None, algo="enum"):
+               start_split=None, algo="mid"):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
         I = R.n_items
@@ -579,8 +577,8 @@ class Engine(object):
                     i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
             with self.timed("paths"):
                 if M is not None:
-                    rc = lib.xmap_extend_paths2(*args, vp(M.nb_id), vp(M.ptrX), vp(M.ptrS), vp(M.midX), vp(M.midS),
-                                                vp(M.dirX), vp(M.dirS), vp(M.ngX), vp(M.ngS))
+                    rc = lib.xmap_extend_paths2(*args, vp(M.nb_id), vp(M.nb_list), vp(M.midX), vp(M.dir),
+                                                vp(M.dir_ptr), vp(M.ng))
                 else:
                     rc = lib.xmap_extend_paths(*args)
             if rc == abi.ERR_CAPACITY:
