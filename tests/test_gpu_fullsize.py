@@ -1,0 +1,113 @@
+"""Parity at BASELINE configs[1] size (1 M users / 200k+200k items) through size-independent properties and a
+bounded oracle sample: the two independent stage-A formulations agree bit for bit, the CSR is symmetric, the
+counters match closed forms computed on the host, a row sample matches the CPU oracle exactly, the two stage-B
+formulations agree, and stage C conserves rows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+CAP = 50
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import torch
+    assert torch.cuda.is_available()
+    from xmap.engine import synth, device
+    r = synth.config_c2()
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs()))
+    return r, eng
+
+
+def _csr(S):
+    rp = S.row_ptr.cpu().numpy()
+    rows = np.repeat(np.arange(len(rp) - 1, dtype=np.int64), np.diff(rp))
+    col = S.col.cpu().numpy().astype(np.int64)
+    o = np.lexsort((col, rows))
+    return rp, rows[o], col[o], S.sim.cpu().numpy()[o], S.mutu.cpu().numpy()[o], S.nij.cpu().numpy()[o]
+
+
+def test_stage_a_full_size(c2):
+    from oracle import xmap_oracle as xo
+    r, eng = c2
+    method = "adjust_cosine"
+    S = eng.item_sim(method, CAP)                 # each unordered pair once + mirror
+    rp, rows, cols, sim, mutu, nij = _csr(S)
+    d = np.diff(r.user_ptr)
+    assert S.n_contrib == int((d * (d - 1)).sum())                   # P = sum d(d-1)
+    assert rp[-1] == S.n_kept and S.n_kept % 2 == 0 and S.n_eval % 2 == 0 and S.n_kept <= S.n_eval <= S.n_contrib
+    assert (np.diff(rp) >= 0).all()
+    # symmetry, bit for bit: the transposed entry list is the same list
+    o2 = np.lexsort((rows, cols))
+    assert np.array_equal(rows[o2], cols) and np.array_equal(cols[o2], rows)
+    assert np.array_equal(sim[o2], sim) and np.array_equal(mutu[o2], mutu) and np.array_equal(nij[o2], nij)
+    assert (sim != 0).all() and (mutu > 0).all() and (mutu <= nij).all() and (np.abs(sim) <= 1 + 1e-12).all()
+    n = np.bincount(r.item, minlength=r.n_items)
+    assert (nij <= np.minimum(n[rows], n[cols])).all()
+    # the complete-rows formulation (independent kernel, hash partitions, no mirroring) gives the same matrix
+    S2 = eng.item_sim(method, CAP, algo="rows")
+    assert S2.n_eval == S.n_eval and S2.n_kept == S.n_kept
+    rp2, rows2, cols2, sim2, mutu2, nij2 = _csr(S2)
+    assert np.array_equal(rp, rp2) and np.array_equal(cols, cols2) and np.array_equal(sim, sim2)
+    assert np.array_equal(mutu, mutu2) and np.array_equal(nij, nij2)
+    del S2
+    # bounded oracle sample: complete rows [0, 3000) from the CPU oracle
+    attrs = r.item_attrs()
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
+    hi = 3000
+    So = xo.item_sim(T, method, CAP, nthreads=8, rows=(0, hi))
+    assert np.array_equal(S.info.cpu().numpy(), So.info)
+    k = int(rp[hi])
+    assert np.array_equal(rp[:hi + 1], So.row_ptr[:hi + 1])
+    assert np.array_equal(cols[:k], So.col[:k]) and np.array_equal(sim[:k], So.sim[:k])
+    assert np.array_equal(mutu[:k], So.mutu[:k]) and np.array_equal(nij[:k], So.nij[:k])
+    xo.sim_free(So)
+
+
+def test_stage_b_c_full_size(c2):
+    r, eng = c2
+    I = r.n_items
+    S = eng.item_sim("cosine", CAP)
+    k = 10
+    E1 = eng.extend(S, k, algo="mid")
+    E2 = eng.extend(S, k, algo="enum")            # one accumulate per path: independent formulation
+    assert E1.n_paths == E2.n_paths == E1.units.total and E1.n_out == E2.n_out
+    assert np.array_equal(E1.n_cand.cpu().numpy(), E2.n_cand.cpu().numpy())
+    assert np.array_equal(E1.top_end.cpu().numpy(), E2.top_end.cpu().numpy())
+    assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
+    n_cand = E1.n_cand.cpu().numpy()[:I]
+    top_end = E1.top_end.cpu().numpy()[:I]
+    top_val = E1.top_val.cpu().numpy()[:I]
+    flags = r.item_attrs()[3]
+    has = n_cand > 0
+    assert int(n_cand.sum()) == E1.n_out
+    # starts are target-side, candidates source-side; candidate lists are sorted by (|xsim| desc, end asc)
+    assert (flags[np.nonzero(has)[0]] & 2).all()
+    m = np.minimum(n_cand, 10)
+    for q in range(10):
+        sel = m > q
+        assert (top_end[sel, q] >= 0).all() and (flags[top_end[sel, q]] & 1).all()
+        assert (top_end[~sel, q] == -1).all()
+        if q:
+            a, b = np.abs(top_val[sel, q - 1]), np.abs(top_val[sel, q])
+            assert (a >= b).all()
+            tie = a == b
+            assert (top_end[sel, q - 1][tie] < top_end[sel, q][tie]).all()
+    # stage C: private mapping = candidate 0; map is the max start per chosen source; rows are conserved
+    n_top, choice, mp_d = eng.select(E1, True)
+    choice, mp = choice.cpu().numpy()[:I], mp_d.cpu().numpy()[:I]
+    assert np.array_equal(choice[has], top_end[has, 0]) and (choice[~has] == -1).all()
+    want = np.full(I, -1, np.int64)
+    np.maximum.at(want, choice[has], np.nonzero(has)[0])
+    assert np.array_equal(mp, want)
+    G = eng.alterego(mp_d)
+    G2 = eng.alterego(mp_d)
+    u, it, rt = G.user.cpu().numpy(), G.item.cpu().numpy(), G.rating.cpu().numpy()
+    assert np.array_equal(u, G2.user.cpu().numpy()) and np.array_equal(rt, G2.rating.cpu().numpy())   # idempotent
+    n_t = int((flags[r.item] & 2).astype(bool).sum())
+    assert G.n_target_rows == n_t and (flags[it] & 2).all()
+    users = np.repeat(np.arange(r.n_users), np.diff(r.user_ptr))
+    mapped = mp[r.item] >= 0
+    key = users[mapped] * np.int64(I) + mp[r.item][mapped]
+    assert G.n_rows - n_t == len(np.unique(key))                      # one AlterEgo row per (user, mapped target)
+    assert (rt >= 1).all() and (rt <= 5).all()

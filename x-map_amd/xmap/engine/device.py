@@ -105,6 +105,15 @@ class Engine(object):
         self.R = ratings
         self.dev = ratings.device
         self.timers = None  # set to {} to collect per-call HIP-event timings
+        self._scratch = {}  # persistent zero-filled accumulator rows (the path kernels leave them zeroed)
+
+    def _zero_scratch(self, name, numel, dtype):
+        """Zero-filled scratch that kernels return zeroed: allocated (and cleared) once, reused across passes."""
+        t = self._scratch.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.zeros(numel, dtype=dtype, device=self.dev)
+            self._scratch[name] = t
+        return t
 
     def timed(self, name):
         return _Timed(self, name)
@@ -550,9 +559,9 @@ class Engine(object):
         E.mid = M
         slot_budget = 48 << 30
         n_slots = int(max(4, min(n_slots, slot_budget // (36 * max(I, 1)), max(U.n_units, 4))))
-        acc = self._zeros(n_slots * max(I, 1) * 4, torch.float64)
+        acc = self._zero_scratch("acc", n_slots * max(I, 1) * 4, torch.float64)
         touched = self._empty(n_slots * max(I, 1), torch.int32)
-        hacc = self._zeros(max(U.n_rows, 1) * max(I, 1) * 4, torch.float64) if U.n_rows else None
+        hacc = self._zero_scratch("hacc", max(U.n_rows, 1) * max(I, 1) * 4, torch.float64) if U.n_rows else None
         htouched = self._empty(max(U.n_rows, 1) * max(I, 1), torch.int32) if U.n_rows else None
         E.n_cand = self._zeros(max(I, 1), torch.int32)
         E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=self.dev)
