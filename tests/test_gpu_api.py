@@ -97,3 +97,17 @@ def test_three_pipelines(case, method):
             for s, c in ch:
                 want[iids[c]] = iids[s]
             assert map_to_dict(mapped) == want
+
+
+def test_end_to_end_driver(tmp_path):
+    """clean -> split -> GPU hot path -> recommender -> MAE through the drop-in API (examples/run_twodomain.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_twodomain", os.path.join(root, "examples", "run_twodomain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mae = mod.main(["--users", "1500", "--items", "300", "--workdir", str(tmp_path)])
+    a, b = [float(x) for x in mae.split(";")]
+    assert 0.0 < a < 2.5 and 0.0 < b < 2.5
+    assert os.path.isdir(os.path.join(str(tmp_path), "data", "output", "runs"))

@@ -51,6 +51,13 @@ class LocalRDD(object):
             acc[key] = merge_value(acc[key], v) if key in acc else create(v)
         return self._new(list(acc.items()))
 
+    def aggregateByKey(self, zero, seq_op, comb_op):
+        import copy
+        acc = {}
+        for key, v in self._data:
+            acc[key] = seq_op(acc[key] if key in acc else copy.deepcopy(zero), v)
+        return self._new(list(acc.items()))
+
     def groupByKey(self):
         acc = {}
         for key, v in self._data:

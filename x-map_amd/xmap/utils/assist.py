@@ -11,6 +11,35 @@ from os.path import join
 import yaml
 
 
+def baseliner_clean_data_pipeline(sc, clean_tool, path_rawdata, is_debug, num_partition):
+    """parse -> filter -> clean (-> debug subset).  reference utils/assist.py:9-21 (host-side ETL)"""
+    dataRDD = sc.textFile(path_rawdata, 30)
+    cleanedRDD = clean_tool.clean_data(clean_tool.filter_data(clean_tool.parse_data(dataRDD))).cache()
+    if is_debug:
+        return sc.parallelize(clean_tool.take_partial_data(cleanedRDD), num_partition).cache()
+    return cleanedRDD
+
+
+def baseliner_split_data_pipeline(sc, split_tool, sourceRDD, targetRDD):
+    """(trainRDD, testRDD).  reference utils/assist.py:24-38"""
+    overlap_bd = sc.broadcast(split_tool.find_overlap_user(sourceRDD, targetRDD).collect())
+    overlap_source, rest_source = split_tool.distinguish_data(overlap_bd, sourceRDD)
+    overlap_target, rest_target = split_tool.distinguish_data(overlap_bd, targetRDD)
+    trainRDD, testRDD = split_tool.split_data(rest_source, overlap_source, rest_target, overlap_target)
+    return trainRDD.cache(), testRDD.cache()
+
+
+def baseliner_split_multidomain_data_pipeline(sc, split_tool, sourceRDD1, sourceRDD2, targetRDD):
+    """(trainRDD1, trainRDD2, testRDD).  reference utils/assist.py:41-63"""
+    overlap_bd = sc.broadcast(
+        split_tool.find_overlap_user_multidomain(sourceRDD1, sourceRDD2, targetRDD).collect())
+    o1, r1 = split_tool.distinguish_data(overlap_bd, sourceRDD1)
+    o2, r2 = split_tool.distinguish_data(overlap_bd, sourceRDD2)
+    ot, rt = split_tool.distinguish_data(overlap_bd, targetRDD)
+    t1, t2, test = split_tool.split_data_multipledomain(r1, o1, r2, o2, rt, ot)
+    return t1.cache(), t2.cache(), test.cache()
+
+
 def baseliner_calculate_sim_pipeline(sc, itemsim_tool, trainRDD):
     """a pipeline to calculate itembased sim.  reference utils/assist.py:66-77
     returns RDD-like[((iid1, iid2), (sim, mutu, frac_mutu, label))]"""
@@ -60,6 +89,37 @@ def generator_pipeline(privatemap_tool, trainRDD, extended_simRDD, private):
     n_top, choice, mp = privatemap_tool.select(st, E, bool(private))
     G = st.engine.alterego(mp)
     return session.AlterEgoRDD(st, G, getattr(trainRDD, "ctx", None)).cache()
+
+
+def recommender_calculate_sim_pipeline(sc, cross_sim_tool, alterEgo_profile):
+    """similarity over the AlterEgo profile.  reference utils/assist.py:153-177"""
+    user_based = cross_sim_tool.build_sthbased_profile(alterEgo_profile, "user").cache()
+    item_based = cross_sim_tool.build_sthbased_profile(alterEgo_profile, "item").cache()
+    user_based_dict_bd = sc.broadcast(user_based.collectAsMap())
+    item_based_dict_bd = sc.broadcast(item_based.collectAsMap())
+    user_info_bd = sc.broadcast(cross_sim_tool.get_info(user_based).collectAsMap())
+    item_info_bd = sc.broadcast(cross_sim_tool.get_info(item_based).collectAsMap())
+    alterEgo_sim = cross_sim_tool.calculate_sim(item_based, user_based, item_info_bd, user_info_bd).cache()
+    return user_based, item_based, user_based_dict_bd, item_based_dict_bd, user_info_bd, item_info_bd, alterEgo_sim
+
+
+def recommender_privacy_pipeline(policy_tool, alterEgo_sim, is_private):
+    """neighbour selection + perturbation.  reference utils/assist.py:180-194"""
+    if is_private:
+        return policy_tool.noise_perturbation(policy_tool.private_neighbor_selection(alterEgo_sim))
+    return policy_tool.nonnoise_perturbation(policy_tool.nonprivate_neighbor_selection(alterEgo_sim))
+
+
+def recommender_prediction_pipeline(recommender_tool, cross_sim_tool, testRDD, simpair_dict_bd,
+                                    user_based_dict_bd, item_based_dict_bd, user_info_bd, item_info_bd):
+    """MAE string.  reference utils/assist.py:197-207 (the user-based branch exists only in the reference's egg)"""
+    if "user" in cross_sim_tool.method:
+        predicted = recommender_tool.user_based_recommendation(
+            testRDD, user_based_dict_bd, simpair_dict_bd, user_info_bd)
+    else:
+        predicted = recommender_tool.item_based_recommendation(
+            testRDD, item_based_dict_bd, simpair_dict_bd, item_info_bd)
+    return recommender_tool.calculate_mae(predicted)
 
 
 def map_to_dict(rdd):
