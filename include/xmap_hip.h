@@ -221,10 +221,11 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *c
  * once as 64-byte records grouped per tile (x', x).  A dense n_nb x n_nb table gives the tile sizes:
  *   xmap_mid_tally : tile_cnt[x'][x] and ng[x'] = number of non-empty tiles of x';
  *   (caller: exclusive scans tile_cnt -> tile_off [n_nb*n_nb+1], ng -> dir_ptr [n_nb+1]; allocates dir, midX)
- *   xmap_mid_place : the tile directory of every x' (16 B per tile: x index, count, offset) and the records.
- * xmap_extend_paths2 is xmap_extend_paths with the joint paths streamed from these lists: a lane keeps its end's
- * double-double sums in registers across a tile, so a start's row is touched once per (head, tile) instead of once
- * per path.  Same results (the sums are exact). */
+ *   xmap_mid_place : the tile directory of every x' (24 B per tile: x, 1+|NN(x)|, count, offset) and the records.
+ * xmap_extend_paths2 is xmap_extend_paths with the joint paths streamed from these lists, tile-major: the (up to 64)
+ * heads of a start are merged by x, a lane keeps its end's double-double sums in registers across all tiles (x', x)
+ * of the start's heads, so a start's row is touched once per (start, x) instead of once per path.  Same results
+ * (the sums are exact). */
 int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                    const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
@@ -235,7 +236,7 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
                    const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
                    int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
-                   void *dir /*16 B per tile*/, void *midX /*64 B per record*/);
+                   void *dir /*24 B per tile*/, void *midX /*64 B per record*/);
 int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
                        const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
                        const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
@@ -245,7 +246,7 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
                        const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
                        int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
                        int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
-                       const int32_t *nb_id, const int32_t *nb_list, const void *midX, const void *dir,
+                       const int32_t *nb_id, const int32_t *nb_list, int32_t n_nb, const void *midX, const void *dir,
                        const int64_t *dir_ptr, const int32_t *ng);
 
 /* Candidate arrays from explicit X-Sim lists (an extended_simRDD that did not come from this engine,

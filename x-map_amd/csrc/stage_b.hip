@@ -597,9 +597,7 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
 // path.  The edge products sim*mutu and the fractions are stored per edge, so a path's (sum sim*mutu, sum
 // mutu, prod frac) is rebuilt in the reference's left-to-right order, bit for bit.
 struct MidX { double sm2, sm3, sm4, f2, f3, f4, mu; int xid; int pad; };   // 64 B; xid = index of x in nb_list
-struct MidDir { int xid; int cnt; long long off; };                        // one tile of x': records [off, off+cnt)
-
-constexpr int MID_GC = 64;   // tiles per work entry of the path kernel
+struct MidDir { int x; int ne; int cnt; int pad; long long off; };          // one tile of x': item x, 1+|NN(x)| ends, records [off, off+cnt)
 
 struct MidArgs {
     int I, k;
@@ -649,7 +647,8 @@ __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
 // directory of the non-empty tiles of every x' (row of the dense table): count, then fill
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, const long long *tile_off,
-                                                 int *ng, const long long *dir_ptr, MidDir *dir) {
+                                                 int *ng, const long long *dir_ptr, MidDir *dir, const int *nb_list,
+                                                 const int *kcnt) {
     const int xpid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (xpid >= n_nb) return;
     const int lane = lane_id();
@@ -661,7 +660,8 @@ __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, 
         const int c = (xid < n_nb) ? tile_cnt[row + xid] : 0;
         const unsigned long long m = __ballot(c > 0);
         if (FILL && c > 0) {
-            MidDir d; d.xid = xid; d.cnt = c; d.off = tile_off[row + xid];
+            MidDir d;
+            d.x = nb_list[xid]; d.ne = 1 + kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = 0; d.off = tile_off[row + xid];
             dir[out + __popcll(m & lanemask_lt())] = d;
         }
         out += __popcll(m);
@@ -672,12 +672,16 @@ __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, 
 
 struct Path2Args {
     PathArgs P;
-    const int *nb_id; const int *nb_list;
+    const int *nb_id; const int *nb_list; int n_nb;
     const MidX *midX; const MidDir *dir; const long long *dir_ptr; const int *ng;
 };
 
 // merge a lane's register sums into the start's row (distinct ends per call)
 __device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, double s_hi, double s_lo, double c_hi, double c_lo) {
+#ifdef XM_EXP_NOFLUSH   // timing experiment only: no row traffic (results are wrong)
+    if (s_hi == 123.456) W.nt++;
+    return;
+#endif
     bool first = false;
     if (active) {
         double *a = W.acc + (size_t)end * 4;
@@ -717,17 +721,55 @@ __device__ __forceinline__ void head_S(const PathArgs &A, WaveAcc &W, int xp, bo
     }
 }
 
-// tiles [g0, g1) of x' for one head: ends {x} U NN(x), register accumulation across the records of a tile
-__device__ __forceinline__ void head_X(const Path2Args &B, WaveAcc &W, int xpid, int g0, int g1, bool has_e1,
-                                       double sm1, double mu1, double f1) {
+// Tile-major reduction over the heads of one start.  Up to 64 heads (one per lane) are merged by item x: every
+// head's tile directory is sorted by x, so the smallest current x over the lanes is the next tile column; all heads
+// that own a tile (x', x) for it are reduced into the SAME register sums before the start's row is touched -- one
+// row access per (start, x) instead of one per (head, x) (2.1x fewer at BASELINE configs[1], 25x for the starts
+// with many heads).  [xlo, xhi) restricts the columns (work splitting of heavy starts).
+__device__ __forceinline__ void heads_X(const Path2Args &B, WaveAcc &W, int start, long long h0, long long nH, int self,
+                                        int xlo, int xhi) {
     const PathArgs &A = B.P;
     const int lane = lane_id();
     const int k = A.k;
-    const long long dbase = B.dir_ptr[xpid];
-    for (int g = g0; g < g1; g++) {
-        const MidDir d = B.dir[dbase + g];
-        const int x = B.nb_list[d.xid];
-        const int ne = 1 + A.kcnt[(size_t)x * 2 + 1];
+    const int INF = 0x7fffffff;
+    // this lane's head
+    const long long h = h0 + lane;
+    const bool hv = h < nH;
+    double sm1 = 0.0, mu1 = 0.0, f1 = 1.0;
+    bool has_e1 = false;
+    long long dpos = 0, dend = 0;
+    if (hv) {
+        int xp = start;
+        if (h >= self) {
+            const long long rp = A.rnn_ptr[start] + (h - self);
+            xp = A.rnn_idx[rp];
+            const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1];
+            sm1 = sv * mu; mu1 = mu; f1 = A.rnn_val[rp * 3 + 2];
+            has_e1 = true;
+        }
+        const int xpid = B.nb_id[xp];
+        dpos = B.dir_ptr[xpid];
+        dend = B.dir_ptr[xpid + 1];
+        if (xlo > 0) {   // lower bound of xlo in this head's directory (sorted by x)
+            long long lo = dpos, hi = dend;
+            while (lo < hi) {
+                long long mid = (lo + hi) >> 1;
+                if (B.dir[mid].x < xlo) lo = mid + 1; else hi = mid;
+            }
+            dpos = lo;
+        }
+    }
+    MidDir cur;
+    cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
+    if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+    for (;;) {
+        int xmin = cur.x;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(xmin, m, 64); xmin = o < xmin ? o : xmin; }
+        if (xmin == INF) break;
+        const unsigned long long part = __ballot(cur.x == xmin);
+        const int x = xmin;
+        const int ne = rl32(cur.ne, __ffsll((long long)part) - 1);
         for (int b = 0; b < ne; b += 64) {
             const int idx = b + lane;
             const bool act = idx < ne;
@@ -737,30 +779,46 @@ __device__ __forceinline__ void head_X(const Path2Args &B, WaveAcc &W, int xpid,
             if (has5) {
                 size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
                 end = A.kcol[o];
-                sm5 = A.kval[o * 3] * A.kval[o * 3 + 1]; mu5 = A.kval[o * 3 + 1]; f5 = A.kval[o * 3 + 2];
+                const double v = A.kval[o * 3], m = A.kval[o * 3 + 1];
+                sm5 = v * m; mu5 = m; f5 = A.kval[o * 3 + 2];
             }
             double s_hi = 0.0, s_lo = 0.0, c_hi = 0.0, c_lo = 0.0;
-            for (int r0 = 0; r0 < d.cnt; r0 += 64) {
-                // the records of the tile are fetched 64 at a time (one per lane), then broadcast lane by lane
-                MidX m;
-                m.sm2 = m.sm3 = m.sm4 = m.f2 = m.f3 = m.f4 = m.mu = 0.0;
-                if (r0 + lane < d.cnt) m = B.midX[d.off + r0 + lane];
-                const int nr = (d.cnt - r0) < 64 ? (d.cnt - r0) : 64;
-                for (int r = 0; r < nr; r++) {
-                    const double sm2 = rld(m.sm2, r), sm3 = rld(m.sm3, r), sm4 = rld(m.sm4, r);
-                    const double f2 = rld(m.f2, r), f3 = rld(m.f3, r), f4 = rld(m.f4, r), mum = rld(m.mu, r);
-                    double sm, c;
-                    if (has_e1) { sm = ((sm1 + sm2) + sm3) + sm4; c = ((f1 * f2) * f3) * f4; }
-                    else { sm = (sm2 + sm3) + sm4; c = (f2 * f3) * f4; }
-                    double mu = mum + (has_e1 ? mu1 : 0.0);
-                    if (has5) { sm = sm + sm5; c = c * f5; mu = mu + mu5; }
-                    const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
-                    dd_add(s_hi, s_lo, sp * c);
-                    dd_add(c_hi, c_lo, c);
+            unsigned long long np = 0;
+            unsigned long long pm = part;
+            while (pm) {
+                const int l = __ffsll((long long)pm) - 1;
+                pm &= pm - 1;
+                const int cnt = rl32(cur.cnt, l);
+                const long long off = rl64(cur.off, l);
+                const bool he1 = rl32((int)has_e1, l) != 0;
+                const double hsm1 = rld(sm1, l), hmu1 = rld(mu1, l), hf1 = rld(f1, l);
+                np += (unsigned long long)cnt;
+                for (int r0 = 0; r0 < cnt; r0 += 64) {
+                    MidX m;
+                    m.sm2 = m.sm3 = m.sm4 = m.f2 = m.f3 = m.f4 = m.mu = 0.0;
+                    if (r0 + lane < cnt) m = B.midX[off + r0 + lane];
+                    const int nr = (cnt - r0) < 64 ? (cnt - r0) : 64;
+                    for (int r = 0; r < nr; r++) {
+                        const double sm2 = rld(m.sm2, r), sm3 = rld(m.sm3, r), sm4 = rld(m.sm4, r);
+                        const double f2 = rld(m.f2, r), f3 = rld(m.f3, r), f4 = rld(m.f4, r), mum = rld(m.mu, r);
+                        double sm, c;
+                        if (he1) { sm = ((hsm1 + sm2) + sm3) + sm4; c = ((hf1 * f2) * f3) * f4; }
+                        else { sm = (sm2 + sm3) + sm4; c = (f2 * f3) * f4; }
+                        double mu = mum + (he1 ? hmu1 : 0.0);
+                        if (has5) { sm = sm + sm5; c = c * f5; mu = mu + mu5; }
+                        const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
+                        dd_add(s_hi, s_lo, sp * c);
+                        dd_add(c_hi, c_lo, c);
+                    }
                 }
             }
             flush_end(W, act, end, s_hi, s_lo, c_hi, c_lo);
-            W.paths += (unsigned long long)d.cnt * (unsigned long long)__popcll(__ballot(act));
+            W.paths += np * (unsigned long long)__popcll(__ballot(act));
+        }
+        if (cur.x == xmin) {    // advance the heads that took part
+            dpos++;
+            cur.x = INF;
+            if (dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
         }
     }
 }
@@ -790,7 +848,7 @@ __global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
             W.touched = A.htouched + (size_t)row * A.I;
         }
         W.nt = 0;
-        int ent = 0;  // work entries of a start: role T; per head: its (t,s) part and chunks of MID_GC tiles
+        int ent = 0;  // work entries of a start: role T; per head its (t,s) part; per (64-head batch, column range) the tiles
         if (A.flags[start] & 2) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
             if (G == 1 || ent % G == c) {
                 Carry none; none.sm = 0; none.mu = 0; none.c = 0;
@@ -798,24 +856,34 @@ __global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
             }
             ent++;
         }
-        const long long r0 = A.rnn_ptr[start], r1 = A.rnn_ptr[start + 1];
-        const int self = (A.cls[start] == 2) ? 1 : 0;
-        for (long long h = -self; h < r1 - r0; h++) {
-            // h == -1: target_path, start = x' (extender.py:160-163); h >= 0: longest_path, start in NN(x') (:164-167)
-            const int xp = (h < 0) ? start : A.rnn_idx[r0 + h];
-            const bool has_e1 = h >= 0;
-            Carry e1; e1.sm = 0; e1.mu = 0; e1.c = 1.0;
-            if (has_e1) e1 = first_edge(A.rnn_val[(r0 + h) * 3], A.rnn_val[(r0 + h) * 3 + 1], A.rnn_val[(r0 + h) * 3 + 2]);
-            if (G == 1 || ent % G == c) head_S(A, W, xp, has_e1, e1);
+        const long long r0 = uniform((int)A.rnn_ptr[start]), r1 = uniform((int)A.rnn_ptr[start + 1]);
+        const int self = (A.cls[start] == 2) ? 1 : 0;   // head 0 = the start itself (target_path, extender.py:160-163)
+        const long long nH = self + (r1 - r0);          // heads >= self: start in NN(x') (longest_path, :164-167)
+        for (long long h = 0; h < nH; h++) {
+#ifndef XM_EXP_NOHEADS
+            if (G == 1 || ent % G == c) {
+                const bool has_e1 = h >= self;
+                const int xp = has_e1 ? A.rnn_idx[r0 + h - self] : start;
+                Carry e1; e1.sm = 0; e1.mu = 0; e1.c = 1.0;
+                if (has_e1) e1 = first_edge(A.rnn_val[(r0 + h - self) * 3], A.rnn_val[(r0 + h - self) * 3 + 1],
+                                            A.rnn_val[(r0 + h - self) * 3 + 2]);
+                head_S(A, W, xp, has_e1, e1);
+            }
+#endif
             ent++;
-            const int xpid = B.nb_id[xp];
-            const int ng = B.ng[xpid];
-            for (int g0 = 0; g0 < ng; g0 += MID_GC) {
-                if (G == 1 || ent % G == c)
-                    head_X(B, W, xpid, g0, (g0 + MID_GC < ng) ? g0 + MID_GC : ng, has_e1, e1.sm, e1.mu, e1.c);
+        }
+        const long long nbatch = (nH + 63) / 64;
+        const int RX = (nbatch > 0) ? (int)((G + nbatch - 1) / nbatch) : 1;   // column ranges: nbatch * RX >= G entries
+        const int n_nb = B.n_nb;
+        for (long long bt = 0; bt < nbatch; bt++)
+            for (int rx = 0; rx < RX; rx++) {
+                if (G == 1 || ent % G == c) {
+                    const int xlo = (rx == 0) ? 0 : B.nb_list[(long long)rx * n_nb / RX];
+                    const int xhi = (rx == RX - 1) ? 0x7fffffff : B.nb_list[(long long)(rx + 1) * n_nb / RX];
+                    heads_X(B, W, start, bt * 64, nH, self, xlo, xhi);
+                }
                 ent++;
             }
-        }
         if (row < 0) cand_total += finalize_start(A, W.acc, W.touched, W.nt, start);
         else if (lane == 0) A.unit_nt[unit] = W.nt;
     }
@@ -1088,12 +1156,12 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
                       const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
                       int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
                       int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
-                       const int32_t *nb_id, const int32_t *nb_list, const void *midX, const void *dir,
+                       const int32_t *nb_id, const int32_t *nb_list, int32_t n_nb, const void *midX, const void *dir,
                        const int64_t *dir_ptr, const int32_t *ng) {
-    XM_ARG(nb_id && nb_list && midX && dir && dir_ptr && ng);
+    XM_ARG(nb_id && nb_list && midX && dir && dir_ptr && ng && n_nb > 0);
     Path2Args B;
     memset(&B, 0, sizeof(B));
-    B.nb_id = nb_id; B.nb_list = nb_list; B.midX = (const MidX *)midX; B.dir = (const MidDir *)dir;
+    B.nb_id = nb_id; B.nb_list = nb_list; B.n_nb = n_nb; B.midX = (const MidX *)midX; B.dir = (const MidDir *)dir;
     B.dir_ptr = (const long long *)dir_ptr; B.ng = ng;
     return extend_paths_impl(&B, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
 }
@@ -1126,7 +1194,8 @@ int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
     const long long waves = (long long)n_nb * top_k;
     k_mid_build<false><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
     XM_LAUNCH_CHECK();
-    k_mid_dir<false><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, nullptr, ng, nullptr, nullptr);
+    k_mid_dir<false><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, nullptr, ng, nullptr, nullptr,
+                                                                             nullptr, nullptr);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -1136,7 +1205,7 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
                    const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
                    int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
-                   void *dir /*16 B per tile*/, void *midX /*64 B per record*/) {
+                   void *dir /*24 B per tile*/, void *midX /*64 B per record*/) {
     XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id);
     XM_ARG(tile_cnt && tile_off && dir_ptr && dir && midX);
     if (n_nb == 0) return XMAP_OK;
@@ -1145,7 +1214,7 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
                          src_flag, n_nb, nb_list, nb_id);
     A.tile_cnt = tile_cnt; A.tile_off = (const long long *)tile_off; A.midX = (MidX *)midX;
     k_mid_dir<true><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, (const long long *)tile_off,
-                                                                            nullptr, (const long long *)dir_ptr, (MidDir *)dir);
+                                                                            nullptr, (const long long *)dir_ptr, (MidDir *)dir, nb_list, kcnt);
     XM_LAUNCH_CHECK();
     XM_HIP(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * (size_t)n_nb * (size_t)n_nb, st));   // now the placement cursors
     const long long waves = (long long)n_nb * top_k;

@@ -537,7 +537,7 @@ class Engine(object):
             check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(tile_cnt), vp(tile_off), i64(n_nb * n_nb), C.byref(tx)))
             check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(M.ng), vp(M.dir_ptr), i64(n_nb), C.byref(tg)))
             M.n_records, M.n_tiles = int(tx.value), int(tg.value)
-            M.dir = self._empty(max(M.n_tiles, 1) * 2, torch.int64)
+            M.dir = self._empty(max(M.n_tiles, 1) * 3, torch.int64)
             M.midX = self._empty(max(M.n_records, 1) * 8, torch.float64)
             check(lib.xmap_mid_place(st, *common, vp(tile_cnt), vp(tile_off), vp(M.dir_ptr), vp(M.dir), vp(M.midX)))
         return M
@@ -586,7 +586,7 @@ class Engine(object):
                     i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
             with self.timed("paths"):
                 if M is not None:
-                    rc = lib.xmap_extend_paths2(*args, vp(M.nb_id), vp(M.nb_list), vp(M.midX), vp(M.dir),
+                    rc = lib.xmap_extend_paths2(*args, vp(M.nb_id), vp(M.nb_list), i32(M.n_nb), vp(M.midX), vp(M.dir),
                                                 vp(M.dir_ptr), vp(M.ng))
                 else:
                     rc = lib.xmap_extend_paths(*args)

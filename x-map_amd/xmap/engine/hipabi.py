@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(HERE, "..", "..", "libxmap_hip.so"))
+LIB_PATH = os.environ.get("XMAP_HIP_LIB") or os.path.normpath(os.path.join(HERE, "..", "..", "libxmap_hip.so"))
 
 COSINE, ADJUST_COSINE = 0, 1
 METHODS = {"cosine": COSINE, "adjust_cosine": ADJUST_COSINE}
