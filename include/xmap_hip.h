@@ -107,13 +107,15 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
 /* ---- stage A, second formulation (stage_a2.hip): each unordered pair is computed once, in the row of its lighter
  * item (weight = (rater count, index)), appended to a half COO and mirrored into the CSR.  Same results as
  * xmap_sim_count/fill (sums are exact, hence order-independent); about 40x fewer rater visits on skewed data.
- *   layout : per-user private profile copies sorted heaviest first (ub_*), rater records per item (rc_*, cur[i] of
- *            them), W+[i] contributions per row, the heavy set H = items with more than CH raters (|H| <= 1024;
- *            ctl[0] = CH >= ch_min, ctl[1] = |H|), pre[v] = #items with fewer than v raters.
- *   plan   : Q[i] hash partitions for light rows (small[i] = 1: at most 96 partners, 128-slot table), C[i] rater
+ *   layout : per-user private profile copies sorted heaviest first (ub: item | flag, rating interleaved), one 16-byte
+ *            rater record per CSC entry (profile offset, prefix length | flag, rating, user; no atomics, raters stay in
+ *            ascending user order), the heavy set H = items with more than CH raters (|H| <= 1024; ctl[0] = CH >=
+ *            ch_min, ctl[1] = |H|), pre[v] = #items with fewer than v raters.
+ *   plan   : W+[i] = contributions of row i (sum of its raters' prefix lengths); Q[i] hash partitions for light rows (small[i] = 1: at most 96 partners, 128-slot table), C[i] rater
  *            chunks for rows of H; exclusive scans uq_ptr / uc_ptr.
  *   pairs  : phases bit 8 = reset counters/rowcnt, 1 = k_pair_heavy (chunk partials of the rows of H), 2 = k_pair_tri
- *            (light units [unit_lo, unit_hi)), 4 = k_heavy_merge; kept pairs (i lighter, j heavier) ->
+ *            (light units [unit_lo, unit_hi)), 4 = k_heavy_merge, 16 = fold the heavy items' row-count replicas (last);
+ *            kept pairs (i lighter, j heavier) ->
  *            half COO: coo_cap entries cut into 4096 shards with a cursor each (d_shards[0][s]; unused entries keep
  *            coo_i = -1), rowcnt[i]++ / rowcnt[j]++; d_shards[1][s] sums to the unordered pairs evaluated;
  *            d_counters[2] = table overflow, [3] = COO shard overflow.
@@ -121,26 +123,27 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
  *            entries are scanned) into the CSR. */
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]*/, int32_t *hid /*[I]*/, int32_t *hlist /*[1024]*/,
-                     uint64_t *ub_key /*[nnz]*/, int32_t *ub_item, float *ub_rating, int32_t *cur /*[I]*/,
-                     int32_t *rc_e0, int32_t *rc_pos, float *rc_rating, int32_t *rc_user /*[nnz] each*/,
-                     uint64_t *Wp /*[I]*/, int32_t *h_ctl /*[2]*/);
-int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int32_t *cur, const uint64_t *Wp,
-                   const int64_t *pre, const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small /*[I]*/,
-                   int64_t *uq_ptr, int64_t *uc_ptr, int64_t *h_counts /*[2]*/);
+                     uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] x 8 B: item|flag, rating*/,
+                     void *rc /*[nnz] x 16 B rater records in CSC order*/, int32_t *h_ctl /*[2]*/);
+int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
+                   const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small /*[I]*/,
+                   uint64_t *Wp /*[I] out: contributions per row*/, int64_t *uq_ptr, int64_t *uc_ptr,
+                   int64_t *h_counts /*[2]*/);
 int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64_t *uq_ptr, int32_t *uq_item,
                     int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c);
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *info,
-                    const int32_t *cur, const int32_t *rc_e0, const int32_t *rc_pos, const float *rc_rating,
-                    const int32_t *rc_user, const int32_t *ub_item, const float *ub_rating, const int32_t *Q,
+                    const void *rc, const void *ub, const int32_t *Q,
                     const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
-                    int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/);
+                    int32_t *rowcnt_h /*[64][1024] scratch*/, int64_t *d_shards /*[2][4096]*/,
+                    int64_t *d_counters /*[4]*/);
 int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
                       const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *row_ptr,
-                      int32_t *fill /*[I] scratch*/, int32_t *col, double *sim, int32_t *mutu, int32_t *nij);
+                      int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist, int32_t *col, double *sim,
+                      int32_t *mutu, int32_t *nij);
 
 /* ---- stage B: extender_pipeline (utils/assist.py:80-133) ---------------------------------- */
 

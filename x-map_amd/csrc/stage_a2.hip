@@ -37,11 +37,25 @@ __device__ __forceinline__ unsigned long long wkey(int n, int item) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// most items have a handful of raters: the low bins are counted per workgroup in LDS first
+constexpr int HIST_LDS = 2048;
+constexpr int HIST_PER = 16;   // items per thread
 __global__ __launch_bounds__(256) void k_hist(int I, const long long *iptr, int HB, int *hist) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= I) return;
-    long long n = iptr[i + 1] - iptr[i];
-    atomicAdd(&hist[n < HB - 1 ? (int)n : HB - 1], 1);
+    __shared__ int loc[HIST_LDS];
+    for (int t = threadIdx.x; t < HIST_LDS; t += 256) loc[t] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * 256 * HIST_PER;
+    for (int q = 0; q < HIST_PER; q++) {
+        const long long i = base + (long long)q * 256 + threadIdx.x;
+        if (i < I) {
+            long long n = iptr[i + 1] - iptr[i];
+            int bin = n < HB - 1 ? (int)n : HB - 1;
+            if (bin < HIST_LDS) atomicAdd(&loc[bin], 1); else atomicAdd(&hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < HIST_LDS && t < HB; t += 256)
+        if (loc[t]) atomicAdd(&hist[t], loc[t]);
 }
 
 // pre[v] = #{items with n < v}.  CH = smallest v >= ch_min with #{n > v} <= HMAX.
@@ -66,64 +80,115 @@ __global__ __launch_bounds__(256) void k_mark_heavy(int I, const long long *iptr
     hid[i] = h;
 }
 
-// one thread per user: private copy of the profile sorted heaviest first; rater records per item.
+struct RaterRec { int e0; int pos_ge; float rating; int user; };   // 16 B: one rater of an item
+
+// one wave per user: private copy of the profile sorted heaviest first, (index | flag, rating) interleaved.
+// Profiles of up to 64 ratings (virtually all) are sorted in registers with a 64-lane bitonic network; longer ones
+// fall back to a serial insertion sort by lane 0 (ub_key is its scratch).
 __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long long *uptr, const int *uitem,
                                                        const float *urating, const long long *iptr, const double *info,
-                                                       unsigned long long *ub_key, int *ub_item, float *ub_rating,
-                                                       int *cur, int *rc_e0, int *rc_pos, float *rc_rating, int *rc_user,
-                                                       unsigned long long *Wp) {
-    long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                       unsigned long long *ub_key, int2 *ub) {
+    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= U) return;
+    const int lane = lane_id();
     const long long a = uptr[u], b = uptr[u + 1];
     const int d = (int)(b - a);
-    // insertion sort by descending weight key into the private copy
-    for (int p = 0; p < d; p++) {
+    if (d <= 64) {
+        unsigned long long key = 0ull;   // pads sort last
+        int px = 0, py = 0;
+        if (lane < d) {
+            const int it = uitem[a + lane];
+            const float r = urating[a + lane];
+            key = wkey((int)(iptr[it + 1] - iptr[it]), it);
+            const unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;   // rating >= item average
+            px = (int)((unsigned)it | ge);
+            py = __float_as_int(r);
+        }
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const unsigned long long ok = __shfl_xor(key, j, 64);
+                const int ox = __shfl_xor(px, j, 64), oy = __shfl_xor(py, j, 64);
+                const bool desc = (lane & k2) == 0;
+                const bool lower = (lane & j) == 0;
+                const bool take_other = (lower == desc) ? (ok > key) : (ok < key);
+                if (take_other) { key = ok; px = ox; py = oy; }
+            }
+        }
+        if (lane < d) ub[a + lane] = make_int2(px, py);
+        return;
+    }
+    if (lane) return;
+    for (int p = 0; p < d; p++) {   // insertion sort by descending weight key
         int it = uitem[a + p];
         float r = urating[a + p];
         unsigned long long key = wkey((int)(iptr[it + 1] - iptr[it]), it);
         int q = p;
         while (q > 0 && ub_key[a + q - 1] < key) {
             ub_key[a + q] = ub_key[a + q - 1];
-            ub_item[a + q] = ub_item[a + q - 1];
-            ub_rating[a + q] = ub_rating[a + q - 1];
+            ub[a + q] = ub[a + q - 1];
             q--;
         }
-        unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;   // rating >= item average
+        unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;
         ub_key[a + q] = key;
-        ub_item[a + q] = (int)((unsigned)it | ge);
-        ub_rating[a + q] = r;
-    }
-    if (d < 2) return;  // users with >= 2 ratings only (baselinerSim.py:184-185)
-    for (int p = 0; p < d; p++) {
-        int iw = ub_item[a + p];
-        int it = iw & 0x7fffffff;
-        int slot = (int)iptr[it] + atomicAdd(&cur[it], 1);
-        rc_e0[slot] = (int)a;
-        rc_pos[slot] = (int)((unsigned)p | ((unsigned)iw & 0x80000000u));
-        rc_rating[slot] = ub_rating[a + p];
-        rc_user[slot] = (int)u;
-        if (p) atomicAdd(&Wp[it], (unsigned long long)p);
+        ub[a + q] = make_int2((int)((unsigned)it | ge), __float_as_int(r));
     }
 }
 
-// light rows: Q partitions; heavy rows (in H): chunks of CH raters
-__global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const int *cur, const unsigned long long *Wp,
-                                               const long long *pre, int HB, const int *hid, const int *CH, int target,
-                                               int *Q, int *C, uint8_t *small) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one thread per CSC entry (item i, its p-th rater u): position of i in u's sorted profile = number of heavier
+// co-rated items = length of the prefix this rater contributes.  No atomics; raters stay in ascending user order.
+__global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, const long long *iptr, const int *iuser,
+                                                       const long long *uptr, const int2 *ub, RaterRec *rc) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    // item of CSC entry p: binary search in iptr
+    int lo = 0, hi = I;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (iptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int i = lo;
+    const int u = iuser[p];
+    const long long a = uptr[u], b = uptr[u + 1];
+    RaterRec r;
+    r.e0 = (int)a; r.pos_ge = 0; r.rating = 0.f; r.user = u;
+    for (long long e = a; e < b; e++) {
+        const int2 v = ub[e];
+        if ((v.x & 0x7fffffff) == i) {
+            const int pos = (b - a >= 2) ? (int)(e - a) : 0;   // users with >= 2 ratings only (baselinerSim.py:184-185)
+            r.pos_ge = (int)((unsigned)pos | ((unsigned)v.x & 0x80000000u));
+            r.rating = __int_as_float(v.y);
+            break;
+        }
+    }
+    rc[p] = r;
+}
+
+// light rows: Q partitions; heavy rows (in H): chunks of CH raters.  One wave per item sums W+ = the prefix lengths.
+__global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const RaterRec *rc, const long long *pre,
+                                               int HB, const int *hid, const int *CH, int target, int *Q, int *C,
+                                               uint8_t *small, unsigned long long *Wp) {
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
-    long long n = iptr[i + 1] - iptr[i];
-    long long w = (long long)Wp[i];
+    const int lane = lane_id();
+    const long long p0 = iptr[i], p1 = iptr[i + 1];
+    long long w = 0;
+    for (long long p = p0 + lane; p < p1; p += 64) w += rc[p].pos_ge & 0x7fffffff;
+    w = wave_sum_ll(w);
+    if (lane) return;
+    long long n = p1 - p0;
     long long ge = I - pre[n < HB - 1 ? n : HB - 1];   // #{items with at least as many raters}
     long long bound = w < ge - 1 ? w : ge - 1;
     int q = 0, c = 0;
     if (w > 0) {
-        if (hid[i] >= 0) c = (cur[i] + *CH - 1) / *CH;
+        if (hid[i] >= 0) c = (int)((n + *CH - 1) / *CH);
         else q = (int)((bound + target - 1) / target);
     }
     Q[i] = q;
     C[i] = c;
     small[i] = (q == 1 && bound <= SMALL_BOUND) ? 1 : 0;
+    Wp[i] = (unsigned long long)w;
 }
 
 __global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Q, const long long *uq_ptr, int *uq_item, int *uq_q,
@@ -139,9 +204,8 @@ __global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Q, const 
 // ---------------------------------------------------------------------------------------------
 struct TriArgs {
     const long long *iptr;
-    const int *cur;          // raters with >= 2 ratings per item
-    const int *rc_e0; const int *rc_pos; const float *rc_rating; const int *rc_user;
-    const int *ub_item; const float *ub_rating;
+    const RaterRec *rc;      // [nnz] rater records in CSC order
+    const int2 *ub;          // [nnz] weight-sorted profiles: (item | flag, rating bits)
     const double *u_avg; const double *info;
     int cap;
     // light
@@ -156,6 +220,7 @@ struct TriArgs {
     unsigned long long *shard_occ;  // [COO_SHARDS] unordered pairs evaluated
     int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
     int *rowcnt;
+    int *rowcnt_h;                  // [HEAVY_SHARDS][HMAX] replicas for the heavy items
     unsigned long long *counters;   // [2] table overflow, [3] COO overflow
 };
 
@@ -175,14 +240,21 @@ __device__ __forceinline__ bool finish_pair(const TriArgs &A, int i, int j, int 
 // appending waves: one word sustains only ~90 atomics/us); unused entries keep coo_i = -1.
 constexpr int COO_SHARDS = 4096;
 
-template <typename Slot>
-__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slots, Slot slot) {
+// Row counts of the (at most HMAX) heavy items are taken in HEAVY_SHARDS replicas: a heavy item is the partner of
+// up to ~I rows, and that many atomics on one word would serialise (k_fold_heavy adds the replicas up).
+constexpr int HEAVY_SHARDS = 64;
+
+// finalise(s, j, n, m, sim, occupied) -> keep.  Pass 1 finalises every slot once (the result is parked by `park`),
+// pass 2 writes the kept ones.
+template <typename Fin, typename Park, typename Get>
+__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slots, Fin fin, Park park, Get get) {
     const int lane = lane_id();
     const int shard = blockIdx.x & (COO_SHARDS - 1);
     int kept = 0, occ = 0;
     for (int s0 = 0; s0 < n_slots; s0 += 64) {
         int j, n, m; double sv; bool o;
-        bool keep = slot(s0 + lane, j, n, m, sv, o);
+        bool keep = fin(s0 + lane, j, n, m, sv, o);
+        park(s0 + lane, o, keep, sv);
         kept += __popcll(__ballot(keep));
         occ += __popcll(__ballot(o));
     }
@@ -200,16 +272,26 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slot
     }
     base += (unsigned long long)shard * (unsigned long long)A.shard_cap;
     for (int s0 = 0; s0 < n_slots; s0 += 64) {
-        int j, n, m; double sv; bool o;
-        bool keep = slot(s0 + lane, j, n, m, sv, o);
+        int j, n, m; double sv;
+        bool keep = get(s0 + lane, j, n, m, sv);
         unsigned long long km = __ballot(keep);
         if (keep) {
             long long p = (long long)base + __popcll(km & lanemask_lt());
             A.coo_i[p] = i; A.coo_j[p] = j; A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
-            atomicAdd(&A.rowcnt[j], 1);
+            const int hj = A.hid[j];
+            if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
+            else atomicAdd(&A.rowcnt[j], 1);
         }
         base += __popcll(km);
     }
+}
+
+__global__ __launch_bounds__(256) void k_fold_heavy(int n_heavy, const int *hlist, int *rowcnt_h, int *rowcnt) {
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_heavy) return;
+    int t = 0;
+    for (int s = 0; s < HEAVY_SHARDS; s++) { t += rowcnt_h[s * HMAX + h]; rowcnt_h[s * HMAX + h] = 0; }
+    if (t) atomicAdd(&rowcnt[hlist[h]], t);
 }
 
 // Light rows.  Eight raters are processed per step (8 lanes each): profile prefixes are short (half a
@@ -246,19 +328,23 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
     const int q = uniform(A.uq_q[unit]);
     const int Qi = uniform(A.Q[i]);
     const int p0 = uniform((int)A.iptr[i]);
-    const int p1 = p0 + uniform(A.cur[i]);
+    const int p1 = uniform((int)A.iptr[i + 1]);
     const int g = lane / GRP, sub = lane % GRP;
     int ovf = 0;
-    for (int base = p0; base < p1; base += 64) {
+#ifdef XM_EXP_NOWALK     // timing experiment only
+    const int p1w = p0;
+#else
+    const int p1w = p1;
+#endif
+    for (int base = p0; base < p1w; base += 64) {
         const int p = base + lane;
         int e0 = 0, pw = 0;
         float r = 0.f;
         double au = 0.0;
         if (p < p1) {
-            e0 = A.rc_e0[p];
-            pw = A.rc_pos[p];
-            r = A.rc_rating[p];
-            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[A.rc_user[p]];
+            const RaterRec rr = A.rc[p];
+            e0 = rr.e0; pw = rr.pos_ge; r = rr.rating;
+            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[rr.user];
         }
         const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
         // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
@@ -268,7 +354,7 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
             const int t = g;
             nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
             nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
-            if (nb0 + sub < nb1) { njw = A.ub_item[nb0 + sub]; nrj = A.ub_rating[nb0 + sub]; }
+            if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
         }
         for (int t0 = 0; t0 < nr; t0 += NGRP) {
             const int t = t0 + g;                    // this lane group's rater
@@ -279,14 +365,14 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
                 const int tn = t + NGRP;
                 nb0 = __shfl(e0, tn, 64); npw = __shfl(pw, tn, 64);
                 nb1 = (tn < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
-                if (nb0 + sub < nb1) { njw = A.ub_item[nb0 + sub]; nrj = A.ub_rating[nb0 + sub]; }
+                if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
             }
             const double ri = (double)__shfl(r, t, 64);
             const double a = (METHOD == XMAP_ADJUST_COSINE) ? __shfl(au, t, 64) : 0.0;
             const unsigned gei = ((unsigned)pwt) >> 31;
             for (int e = b0 + sub; __ballot(e < b1); e += GRP) {
                 bool act = e < b1;
-                if (act && e >= b0 + GRP) { jw = A.ub_item[e]; rj = A.ub_rating[e]; }
+                if (act && e >= b0 + GRP) { const int2 v = A.ub[e]; jw = v.x; rj = __int_as_float(v.y); }
                 const int j = jw & 0x7fffffff;
                 if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
                 uint32_t h = 0;
@@ -329,14 +415,29 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
         if (lane == 0) atomicOr(&A.counters[2], 1ull);
         return;
     }
-    append_pairs(A, i, SLOTS_, [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
-        uint32_t kj = key[s];
-        o = kj != T_EMPTY;
-        if (!o) return false;
-        unsigned long long c = cm[s];
-        j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32);
-        return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
-    });
+#ifdef XM_EXP_NOAPPEND   // timing experiment only
+    if (key[lane] == 12345u) A.rowcnt[0] = 1;
+    return;
+#endif
+    append_pairs(A, i, SLOTS_,
+        [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
+            uint32_t kj = key[s];
+            o = kj != T_EMPTY;
+            if (!o) return false;
+            unsigned long long c = cm[s];
+            j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32);
+            return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
+        },
+        [&](int s, bool o, bool keep, double sv) {      // park: weighted sim in dot[], dropped slots emptied
+            if (o) { if (keep) dot[s] = sv; else key[s] = T_EMPTY; }
+        },
+        [&](int s, int &j, int &n, int &m, double &sv) {
+            uint32_t kj = key[s];
+            if (kj == T_EMPTY) return false;
+            unsigned long long c = cm[s];
+            j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32); sv = dot[s];
+            return true;
+        });
 }
 
 // rows of H: chunk c of the raters, dense table over H (partners of a heavy row are heavier, hence in H)
@@ -357,7 +458,7 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
     const int CH = uniform(*A.CH);
     const int base0 = uniform((int)A.iptr[i]);
     const int p0 = base0 + c * CH;
-    int p1 = base0 + uniform(A.cur[i]);
+    int p1 = uniform((int)A.iptr[i + 1]);
     if (p0 + CH < p1) p1 = p0 + CH;
     for (int base = p0; base < p1; base += 64) {
         const int p = base + lane;
@@ -365,8 +466,9 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
         float r = 0.f;
         double au = 0.0;
         if (p < p1) {
-            e0 = A.rc_e0[p]; pw = A.rc_pos[p]; r = A.rc_rating[p];
-            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[A.rc_user[p]];
+            const RaterRec rr = A.rc[p];
+            e0 = rr.e0; pw = rr.pos_ge; r = rr.rating;
+            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[rr.user];
         }
         const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
         for (int t = 0; t < nr; ++t) {
@@ -375,8 +477,9 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
             const double ri = (double)rlf(r, t);
             const double a = (METHOD == XMAP_ADJUST_COSINE) ? rld(au, t) : 0.0;
             for (int e = b0 + lane; e < b1; e += 64) {
-                const int jw = A.ub_item[e];
-                const float rj = A.ub_rating[e];
+                const int2 v = A.ub[e];
+                const int jw = v.x;
+                const float rj = __int_as_float(v.y);
                 const int h = A.hid[jw & 0x7fffffff];
                 cnt[h] += 1;
                 mut[h] += ((((unsigned)jw) >> 31) == gei) ? 1u : 0u;
@@ -427,12 +530,21 @@ __global__ __launch_bounds__(64) void k_heavy_merge(TriArgs A, int n_heavy) {
         cnt[s] = cn; mut[s] = mu; dot[s] = hi;
     }
     if (nc == 0) return;
-    append_pairs(A, i, HMAX, [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
-        o = cnt[s] != 0;
-        if (!o) return false;
-        j = A.hlist[s]; n = (int)cnt[s]; m = (int)mut[s];
-        return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
-    });
+    append_pairs(A, i, HMAX,
+        [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
+            o = cnt[s] != 0;
+            if (!o) return false;
+            j = A.hlist[s]; n = (int)cnt[s]; m = (int)mut[s];
+            return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
+        },
+        [&](int s, bool o, bool keep, double sv) {
+            if (o) { if (keep) dot[s] = sv; else cnt[s] = 0; }
+        },
+        [&](int s, int &j, int &n, int &m, double &sv) {
+            if (cnt[s] == 0) return false;
+            j = A.hlist[s]; n = (int)cnt[s]; m = (int)mut[s]; sv = dot[s];
+            return true;
+        });
 }
 
 // Mirror the half COO into the CSR.  Records of one unit are contiguous and share the lighter item i, so the
@@ -479,25 +591,23 @@ extern "C" {
 
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]: CH, n_heavy*/, int32_t *hid, int32_t *hlist /*[1024]*/,
-                     uint64_t *ub_key, int32_t *ub_item, float *ub_rating, int32_t *cur, int32_t *rc_e0, int32_t *rc_pos,
-                     float *rc_rating, int32_t *rc_user, uint64_t *Wp, int32_t *h_ctl /*[2]*/) {
-    XM_ARG(R && info && hist && pre && ctl && hid && hlist && ub_key && ub_item && ub_rating && cur);
-    XM_ARG(rc_e0 && rc_pos && rc_rating && rc_user && Wp && ch_min >= 64);
+                     uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] 8 B*/, void *rc /*[nnz] 16 B*/,
+                     int32_t *h_ctl /*[2]*/) {
+    XM_ARG(R && info && hist && pre && ctl && hid && hlist && ub_key && ub && rc && ch_min >= 64);
     XM_ARG(R->nnz < 0x7fffffffLL && R->n_users < 0x7ffffff0LL);
     hipStream_t st = (hipStream_t)stream;
     const int I = R->n_items;
     const int HB = (int)R->n_users + 2;
     XM_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)HB, st));
-    XM_HIP(hipMemsetAsync(cur, 0, sizeof(int32_t) * (size_t)(I > 0 ? I : 1), st));
-    XM_HIP(hipMemsetAsync(Wp, 0, sizeof(uint64_t) * (size_t)(I > 0 ? I : 1), st));
     XM_HIP(hipMemsetAsync(ctl, 0x7f, sizeof(int32_t), st));          // CH = 0x7f7f7f7f: "no heavy rows"
     XM_HIP(hipMemsetAsync(ctl + 1, 0, 3 * sizeof(int32_t), st));
     if (I > 0) {
-        k_hist<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, (const long long *)R->item_ptr, HB, hist);
+        k_hist<<<dim3((unsigned)((I + 256 * HIST_PER - 1) / (256 * HIST_PER))), dim3(256), 0, st>>>(
+            I, (const long long *)R->item_ptr, HB, hist);
         XM_LAUNCH_CHECK();
     }
-    int rc = xmap_exclusive_scan_i32_to_i64(stream, hist, pre, HB, nullptr);
-    if (rc) return rc;
+    int rcode = xmap_exclusive_scan_i32_to_i64(stream, hist, pre, HB, nullptr);
+    if (rcode) return rcode;
     if (HB - 1 > ch_min) {
         k_threshold<<<dim3((unsigned)((HB + 255) / 256)), dim3(256), 0, st>>>(I, HB, (const long long *)pre, ch_min, ctl);
         XM_LAUNCH_CHECK();
@@ -508,10 +618,15 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
         XM_LAUNCH_CHECK();
     }
     if (R->n_users > 0) {
-        k_sort_profiles<<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, st>>>(
+        k_sort_profiles<<<dim3((unsigned)((R->n_users + 3) / 4)), dim3(256), 0, st>>>(
             R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->item_ptr, info,
-            (unsigned long long *)ub_key, ub_item, ub_rating, cur, rc_e0, rc_pos, rc_rating, rc_user,
-            (unsigned long long *)Wp);
+            (unsigned long long *)ub_key, (int2 *)ub);
+        XM_LAUNCH_CHECK();
+    }
+    if (R->nnz > 0) {
+        k_rater_records<<<dim3((unsigned)((R->nnz + 255) / 256)), dim3(256), 0, st>>>(
+            I, R->nnz, (const long long *)R->item_ptr, R->item_user, (const long long *)R->user_ptr, (const int2 *)ub,
+            (RaterRec *)rc);
         XM_LAUNCH_CHECK();
     }
     if (h_ctl) {
@@ -525,21 +640,21 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
     return XMAP_OK;
 }
 
-int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int32_t *cur, const uint64_t *Wp,
-                   const int64_t *pre, const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small,
+int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
+                   const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp /*[I] out*/,
                    int64_t *uq_ptr, int64_t *uc_ptr, int64_t *h_counts /*[2]: light units, heavy units*/) {
-    XM_ARG(R && cur && Wp && pre && hid && ctl && Q && C && small && uq_ptr && uc_ptr && h_counts);
+    XM_ARG(R && rc && Wp && pre && hid && ctl && Q && C && small && uq_ptr && uc_ptr && h_counts);
     XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
     hipStream_t st = (hipStream_t)stream;
     const int I = R->n_items;
     if (I > 0) {
-        k_plan2<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(
-            I, (const long long *)R->item_ptr, cur, (const unsigned long long *)Wp, (const long long *)pre,
-            (int)R->n_users + 2, hid, ctl, slot_target, Q, C, small);
+        k_plan2<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(
+            I, (const long long *)R->item_ptr, (const RaterRec *)rc, (const long long *)pre, (int)R->n_users + 2, hid, ctl,
+            slot_target, Q, C, small, (unsigned long long *)Wp);
         XM_LAUNCH_CHECK();
     }
-    int rc = xmap_exclusive_scan_i32_to_i64(stream, Q, uq_ptr, I, &h_counts[0]);
-    if (rc) return rc;
+    int rcode = xmap_exclusive_scan_i32_to_i64(stream, Q, uq_ptr, I, &h_counts[0]);
+    if (rcode) return rcode;
     return xmap_exclusive_scan_i32_to_i64(stream, C, uc_ptr, I, &h_counts[1]);
 }
 
@@ -554,38 +669,38 @@ int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64
 }
 
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *info,
-                    const int32_t *cur, const int32_t *rc_e0, const int32_t *rc_pos, const float *rc_rating,
-                    const int32_t *rc_user, const int32_t *ub_item, const float *ub_rating, const int32_t *Q,
+                    const void *rc, const void *ub, const int32_t *Q,
                     const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
-                    int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/) {
-    XM_ARG(R && u_avg && info && cur && rc_e0 && rc_pos && rc_rating && rc_user && ub_item && ub_rating);
+                    int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/) {
+    XM_ARG(R && u_avg && info && rc && ub);
     XM_ARG(Q && small && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
-    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && d_shards && d_counters && coo_cap >= COO_SHARDS);
+    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && rowcnt_h && d_shards && d_counters);
+    XM_ARG(coo_cap >= COO_SHARDS);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
     XM_ARG(n_heavy_units == 0 || !(phases & 5) || (hp_hi && hp_lo && hp_cnt && hp_mut));
     hipStream_t st = (hipStream_t)stream;
     if (phases & 8) {   // reset the COO cursor / counters / row counts
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
         XM_HIP(hipMemsetAsync(d_shards, 0, 2 * COO_SHARDS * sizeof(int64_t), st));
+        XM_HIP(hipMemsetAsync(rowcnt_h, 0, sizeof(int32_t) * HEAVY_SHARDS * HMAX, st));
         XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry
         XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
     }
     TriArgs A;
     memset(&A, 0, sizeof(A));
-    A.iptr = (const long long *)R->item_ptr; A.cur = cur;
-    A.rc_e0 = rc_e0; A.rc_pos = rc_pos; A.rc_rating = rc_rating; A.rc_user = rc_user;
-    A.ub_item = ub_item; A.ub_rating = ub_rating; A.u_avg = u_avg; A.info = info; A.cap = cap;
+    A.iptr = (const long long *)R->item_ptr; A.rc = (const RaterRec *)rc; A.ub = (const int2 *)ub;
+    A.u_avg = u_avg; A.info = info; A.cap = cap;
     A.Q = Q; A.small = small; A.uq_item = uq_item; A.uq_q = uq_q; A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     A.hid = hid; A.hlist = hlist; A.CH = ctl; A.uc_item = uc_item; A.uc_c = uc_c;
     A.uc_ptr = (const long long *)uc_ptr; A.C = C;
     A.hp_hi = hp_hi; A.hp_lo = hp_lo; A.hp_cnt = hp_cnt; A.hp_mut = hp_mut;
     A.shard_cap = coo_cap / COO_SHARDS; A.shard_cur = (unsigned long long *)d_shards;
     A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
-    A.rowcnt = rowcnt; A.counters = (unsigned long long *)d_counters;
+    A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials
         if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
         else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
@@ -607,16 +722,22 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
         XM_LAUNCH_CHECK();
     }
+    if ((phases & 16) && n_heavy > 0) {   // fold the heavy items' count replicas into rowcnt
+        k_fold_heavy<<<dim3((unsigned)((n_heavy + 255) / 256)), dim3(256), 0, st>>>(n_heavy, hlist, rowcnt_h, rowcnt);
+        XM_LAUNCH_CHECK();
+    }
     return XMAP_OK;
 }
 
 int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
                       const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *row_ptr,
-                      int32_t *fill /*[I] scratch*/, int32_t *col, double *sim, int32_t *mutu, int32_t *nij) {
-    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && row_ptr && fill && col && sim && mutu && nij);
+                      int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist, int32_t *col, double *sim,
+                      int32_t *mutu, int32_t *nij) {
+    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && row_ptr && fill && hid && hlist && col && sim && mutu && nij);
     hipStream_t st = (hipStream_t)stream;
     XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
     if (n_coo > 0) {
+        // (an LDS histogram that bumps the heavy items' cursors once per workgroup was measured slower: 2.9 vs 2.4 ms)
         k_scatter<<<dim3((unsigned)((n_coo + 255) / 256)), dim3(256), 0, st>>>(
             n_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, (const long long *)row_ptr, fill, col, sim, mutu, nij);
         XM_LAUNCH_CHECK();

@@ -245,20 +245,13 @@ class Engine(object):
         L.hid = self._empty(max(I, 1), torch.int32)
         L.hlist = self._zeros(1024, torch.int32)
         L.ub_key = self._empty(max(nnz, 1), torch.int64)
-        L.ub_item = self._empty(max(nnz, 1), torch.int32)
-        L.ub_rating = self._empty(max(nnz, 1), torch.float32)
-        L.cur = self._empty(max(I, 1), torch.int32)
-        L.rc_e0 = self._empty(max(nnz, 1), torch.int32)
-        L.rc_pos = self._empty(max(nnz, 1), torch.int32)
-        L.rc_rating = self._empty(max(nnz, 1), torch.float32)
-        L.rc_user = self._empty(max(nnz, 1), torch.int32)
+        L.ub = self._empty(max(nnz, 1), torch.int64)           # (item | flag, rating bits) pairs
+        L.rc = self._empty(max(nnz, 1) * 2, torch.int64)       # 16-byte rater records
         L.Wp = self._empty(max(I, 1), torch.int64)
         h_ctl = (C.c_int32 * 2)()
         with self.timed("tri_layout"):
             check(lib.xmap_sim2_layout(st, C.byref(R.c), vp(info), i32(ch_min), vp(L.hist), vp(L.pre), vp(L.ctl),
-                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub_item), vp(L.ub_rating),
-                                       vp(L.cur), vp(L.rc_e0), vp(L.rc_pos), vp(L.rc_rating), vp(L.rc_user),
-                                       vp(L.Wp), h_ctl))
+                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub), vp(L.rc), h_ctl))
         L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
         L.slot_target = slot_target
         self._tri_plan(L, slot_target)
@@ -277,8 +270,8 @@ class Engine(object):
         L.uc_ptr = self._zeros(I + 1, torch.int64)
         h = (C.c_int64 * 2)()
         with self.timed("tri_plan"):
-            check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.cur), vp(L.Wp), vp(L.pre), vp(L.hid),
-                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.uq_ptr), vp(L.uc_ptr), h))
+            check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.rc), vp(L.pre), vp(L.hid),
+                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.Wp), vp(L.uq_ptr), vp(L.uc_ptr), h))
             L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
             L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
             L.uq_q = self._empty(max(L.n_light, 1), torch.int32)
@@ -313,21 +306,22 @@ class Engine(object):
             hp_mut = self._empty(max(nh, 1) * 1024, torch.int32)
             d_cnt = self._zeros(4, torch.int64)
             d_shards = self._empty(2 * 4096, torch.int64)
+            rowcnt_h = self._empty(64 * 1024, torch.int32)
 
             def run(phases):
                 check(lib.xmap_sim2_pairs(
-                    st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(L.cur), vp(L.rc_e0), vp(L.rc_pos),
-                    vp(L.rc_rating), vp(L.rc_user), vp(L.ub_item), vp(L.ub_rating), vp(L.Q), vp(L.small), vp(L.uq_item),
+                    st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(L.rc), vp(L.ub), vp(L.Q), vp(L.small),
+                    vp(L.uq_item),
                     vp(L.uq_q), i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
-                    vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(d_shards), vp(d_cnt)))
+                    vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
             with self.timed("pair_heavy"):
                 run(8 | (1 if do_heavy else 0))
             with self.timed("pair_tri"):
                 run(2)
             with self.timed("heavy_merge"):
-                run(4 if do_heavy else 0)
+                run((4 if do_heavy else 0) | 16)
             h = d_cnt.tolist()
             if h[2]:
                 if L.slot_target <= 32:
@@ -347,7 +341,7 @@ class Engine(object):
         out = ((coo_i, coo_j, coo_sim, coo_mutu, coo_nij), rowcnt, n, n_unordered)
         return out if retry else out + (0,)
 
-    def tri_scatter(self, coo, rowcnt, info, n=None):
+    def tri_scatter(self, coo, rowcnt, info, n=None, L=None):
         """mirror a (complete) half COO (n valid entries; unused ones have coo_i = -1) into the CSR"""
         R = self.R
         st = _stream(self.dev)
@@ -367,7 +361,8 @@ class Engine(object):
         with self.timed("scatter"):
           if n:
             check(lib.xmap_sim2_scatter(st, i32(I), i64(n_scan), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu),
-                                        vp(coo_nij), vp(row_ptr), vp(fill), vp(col), vp(sim), vp(mutu), vp(nij)))
+                                        vp(coo_nij), vp(row_ptr), vp(fill), vp(L.hid), vp(L.hlist), vp(col), vp(sim), vp(mutu),
+                                        vp(nij)))
         return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
 
     def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
@@ -376,7 +371,7 @@ class Engine(object):
             stats = self.stats()
         L = self.tri_layout(stats, slot_target, ch_min)
         coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
-        S = self.tri_scatter(coo, rowcnt, stats[2], n)
+        S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
         S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
         S.cap = int(cap)
         S.u_avg, S.u_norm = stats[0], stats[1]

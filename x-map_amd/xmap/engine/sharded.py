@@ -96,7 +96,8 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         stats = eng.stats()
         L = eng.tri_layout(stats)
         while True:
-            w = L.cur[L.uq_item[:L.n_light].long()].cpu().numpy() if L.n_light else np.zeros(0)
+            n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
+            w = n_i[L.uq_item[:L.n_light].long()].cpu().numpy() if L.n_light else np.zeros(0)
             lo, hi = balanced_ranges(w, world)[rank]
             coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
                                                              do_heavy=(rank == 0), retry=False)
@@ -110,7 +111,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         coo = [comm.all_gather_var(x[valid].contiguous()) for x in coo]
         tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
-        S = eng.tri_scatter(coo, rowcnt, stats[2])
+        S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
         light_local = 2 * int(L.Wp[L.uq_item[lo:hi].long()].sum().item()) if hi > lo else 0
     # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
     # ranges balanced by the exact per-start path counts
