@@ -94,12 +94,20 @@ def case_mixed_prefix():
     return [(u, [(remap(i), r, t) for (i, r, t) in prof]) for (u, prof) in recs]
 
 
+def case_multilabel():
+    """Labels of the multi-domain demo (multidomain_demo.py:62-72): one source domain "S:1:" against "T:".
+    The knn classification uses iid[-2:] = "1:" / "T:" as substring tests (extender.py:29-35)."""
+    recs = case_synth(13, 300, 100, 100, overlap=0.35)
+    return [(u, [((i[:-2] + "S:1:") if i.endswith("S:") else i, r, t) for (i, r, t) in prof]) for (u, prof) in recs]
+
+
 CASES = {
     "kat7": (case_kat7, dict(ks=[2], seeds=[7])),
     "tiny": (lambda: case_synth(3, 60, 30, 30, overlap=0.5), dict(ks=[2, 5], seeds=[5])),
     "small": (lambda: case_synth(4, 400, 150, 150, overlap=0.3), dict(ks=[2, 5, 10], seeds=[5, 6])),
     "medium": (lambda: case_synth(5, 1500, 400, 400, overlap=0.25), dict(ks=[2, 5], seeds=[5])),
     "mixed": (case_mixed_prefix, dict(ks=[3], seeds=[5])),
+    "multilabel": (case_multilabel, dict(ks=[4], seeds=[5])),
 }
 
 

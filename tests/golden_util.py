@@ -7,7 +7,7 @@ import numpy as np
 from xmap.engine import ids as xids
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["kat7", "tiny", "mixed", "small", "medium"]
+CASES = ["kat7", "tiny", "mixed", "multilabel", "small", "medium"]
 METHODS = ["cosine", "adjust_cosine"]
 CAP = 50
 

@@ -25,7 +25,7 @@ def records(gold):
 
 
 @pytest.mark.parametrize("method", METHODS)
-@pytest.mark.parametrize("case", ["kat7", "small", "mixed"])
+@pytest.mark.parametrize("case", ["kat7", "small", "mixed", "multilabel"])
 def test_three_pipelines(case, method):
     import torch
     assert torch.cuda.is_available()
@@ -111,3 +111,16 @@ def test_end_to_end_driver(tmp_path):
     a, b = [float(x) for x in mae.split(";")]
     assert 0.0 < a < 2.5 and 0.0 < b < 2.5
     assert os.path.isdir(os.path.join(str(tmp_path), "data", "output", "runs"))
+
+
+def test_multidomain_driver(tmp_path):
+    """two source domains ("S:1:", "S:2:") against one target through the drop-in API (examples/run_multidomain.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_multidomain", os.path.join(root, "examples", "run_multidomain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mae = mod.main(["--users", "1200", "--items", "250", "--workdir", str(tmp_path)])
+    a, b = [float(x) for x in mae.split(";")]
+    assert 0.0 < a < 2.5 and 0.0 < b < 2.5
