@@ -114,7 +114,7 @@ def main():
     R = device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs, dev)
     eng = device.Engine(R)
     if rank == 0:
-        log("setup: users=%d items=%d nnz=%d in %.1f s (gen + CSC layout + H2D)" % (r.n_users, r.n_items, r.nnz, time.time() - t0))
+        log("setup: users=%d items=%d nnz=%d in %.1f s (synthetic data generation + H2D upload of the CSR)" % (r.n_users, r.n_items, r.nnz, time.time() - t0))
 
     def step():
         return sharded.run_step(eng, args.method, CAP, k, True, dist, rank, world)

@@ -65,6 +65,13 @@ int xmap_exclusive_scan_i32_to_i64(void *stream, const int32_t *in, int64_t *out
 
 /* ---- stage A: baseliner_calculate_sim_pipeline (utils/assist.py:66-77) ------------------- */
 
+/* CSC (item -> raters) of the ratings from the CSR by user: the device-side counterpart of the flatMap + combineByKey
+ * shuffle of get_universal_item_info (core/baselinerSim.py:65-82).  Rater order within an item is unspecified (every
+ * consumer sums exactly).  Fills item_ptr / item_user / item_rating, which xmap_ratings then points at. */
+int xmap_build_csc(void *stream, int64_t n_users, int32_t n_items, int64_t nnz, const int64_t *user_ptr,
+                   const int32_t *user_item, const float *user_rating, int32_t *cnt /*[I] scratch*/,
+                   int64_t *item_ptr /*[I+1]*/, int32_t *item_user /*[nnz]*/, float *item_rating /*[nnz]*/);
+
 /* BaselinerSim.get_universal_user_info (core/baselinerSim.py:17-38): avg[u], norm2[u] (fp64). */
 int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *u_norm2);
 

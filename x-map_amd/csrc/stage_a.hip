@@ -41,6 +41,24 @@ __global__ __launch_bounds__(256) void k_user_stats(long long U, const long long
     norm2[u] = sqrt(q);
 }
 
+// CSC (item -> raters) from the CSR: count, scan, fill.  The order of an item's raters is whatever the cursor
+// atomics produce -- every consumer sums exactly (integer-valued or double-double), so no order is needed.
+__global__ __launch_bounds__(256) void k_csc_count(long long nnz, const int *uitem, int *cnt) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) atomicAdd(&cnt[uitem[e]], 1);
+}
+__global__ __launch_bounds__(256) void k_csc_fill(long long U, const long long *uptr, const int *uitem, const float *urating,
+                                                  const long long *iptr, int *cur, int *iuser, float *irating) {
+    long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= U) return;
+    for (long long e = uptr[u] + lane_id(); e < uptr[u + 1]; e += 64) {
+        const int it = uitem[e];
+        const long long p = iptr[it] + atomicAdd(&cur[it], 1);
+        iuser[p] = (int)u;
+        irating[p] = urating[e];
+    }
+}
+
 // one wave per item: lane-strided partial sums, fixed butterfly reduction (deterministic)
 __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr, const int *iuser, const float *irating,
                                                     const double *u_avg, double *info, int *ia_user) {
@@ -352,6 +370,29 @@ static PairArgs make_args(const xmap_ratings *R, int cap, const double *u_avg, c
 using namespace xmap;
 
 extern "C" {
+
+int xmap_build_csc(void *stream, int64_t n_users, int32_t n_items, int64_t nnz, const int64_t *user_ptr,
+                   const int32_t *user_item, const float *user_rating, int32_t *cnt /*[I] scratch*/,
+                   int64_t *item_ptr /*[I+1]*/, int32_t *item_user, float *item_rating) {
+    XM_ARG(user_ptr && cnt && item_ptr && (nnz == 0 || (user_item && user_rating && item_user && item_rating)));
+    XM_ARG(nnz < 0x7fffffffLL);
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
+    if (nnz > 0) {
+        k_csc_count<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st>>>(nnz, user_item, cnt);
+        XM_LAUNCH_CHECK();
+    }
+    int rc = xmap_exclusive_scan_i32_to_i64(stream, cnt, item_ptr, n_items, nullptr);
+    if (rc) return rc;
+    XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
+    if (nnz > 0) {
+        k_csc_fill<<<dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st>>>(
+            n_users, (const long long *)user_ptr, user_item, user_rating, (const long long *)item_ptr, cnt, item_user,
+            item_rating);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
 
 int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *u_norm2) {
     XM_ARG(R && u_avg && u_norm2);

@@ -20,9 +20,9 @@ def _stream(dev):
 
 
 class DeviceRatings(object):
-    """trainRDD in index space, resident in HBM: CSR by user (trainRDD / profile order) and CSC by
-    item (raters ascending).  The CSC is laid out once on the host at upload time (stable sort), like
-    the id dictionary; neither is part of a timed pass."""
+    """trainRDD in index space, resident in HBM: CSR by user (trainRDD / profile order).  The CSC by item is
+    derived on the device at the start of every stage-A pass (Engine.build_csc); only the id dictionary and the
+    H2D upload are one-off host work."""
 
     def __init__(self, user_ptr, item, rating, time, n_items, attrs, device="cuda:0"):
         self.device = torch.device(device)
@@ -37,10 +37,6 @@ class DeviceRatings(object):
             raise ValueError("nnz must fit int32")
         if self.nnz and (item.min() < 0 or item.max() >= self.n_items):
             raise ValueError("item index out of range")
-        users = np.repeat(np.arange(self.n_users, dtype=np.int32), np.diff(user_ptr))
-        order = np.argsort(item, kind="stable")
-        item_ptr = np.zeros(self.n_items + 1, np.int64)
-        np.cumsum(np.bincount(item, minlength=self.n_items), out=item_ptr[1:])
         prefix_cls, suffix_cls, contains_mask, flags = attrs
         d = self.device
         t = torch.from_numpy
@@ -48,9 +44,10 @@ class DeviceRatings(object):
         self.user_item = t(item).to(d)
         self.user_rating = t(rating).to(d)
         self.user_time = t(time).to(d)
-        self.item_ptr = t(item_ptr).to(d)
-        self.item_user = t(np.ascontiguousarray(users[order])).to(d)
-        self.item_rating = t(np.ascontiguousarray(rating[order])).to(d)
+        self.item_ptr = torch.zeros(self.n_items + 1, dtype=torch.int64, device=d)
+        self.item_user = torch.zeros(max(self.nnz, 1), dtype=torch.int32, device=d)
+        self.item_rating = torch.zeros(max(self.nnz, 1), dtype=torch.float32, device=d)
+        self.csc_ready = False
         self.prefix_cls = t(np.ascontiguousarray(prefix_cls, np.int32)).to(d)
         self.suffix_cls = t(np.ascontiguousarray(suffix_cls, np.int32)).to(d)
         self.contains_mask = t(np.ascontiguousarray(contains_mask, np.uint32).view(np.int32)).to(d)
@@ -130,10 +127,21 @@ class Engine(object):
         return torch.zeros(shape, dtype=dtype, device=self.dev)
 
     # ------------------------------------------------------------------ stage A
-    def stats(self):
-        """A2 + A3: user info, item info and the flag-packed index copies."""
+    def build_csc(self):
+        """item -> raters layout of the ratings (device counting sort; part of every stage-A pass)"""
         R = self.R
         st = _stream(self.dev)
+        cnt = self._empty(max(R.n_items, 1), torch.int32)
+        with self.timed("build_csc"):
+            check(lib.xmap_build_csc(st, i64(R.n_users), i32(R.n_items), i64(R.nnz), vp(R.user_ptr), vp(R.user_item),
+                                     vp(R.user_rating), vp(cnt), vp(R.item_ptr), vp(R.item_user), vp(R.item_rating)))
+        R.csc_ready = True
+
+    def stats(self):
+        """A2 + A3: CSC layout, user info, item info and the flag-packed index copies."""
+        R = self.R
+        st = _stream(self.dev)
+        self.build_csc()
         u_avg = self._empty(max(R.n_users, 1), torch.float64)
         u_norm = self._empty(max(R.n_users, 1), torch.float64)
         check(lib.xmap_user_stats(st, C.byref(R.c), vp(u_avg), vp(u_norm)))
