@@ -31,6 +31,7 @@ constexpr int T_SLOTS = 1 << T_LOG_SLOTS;
 constexpr int HMAX = 1024;              // |H| <= HMAX: dense LDS table of the heavy kernel
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr int SMALL_BOUND = 96;          // rows with at most this many partners use the 128-slot table
+constexpr int MID_BOUND = 384;           // ... at most this many: the 512-slot table
 
 __device__ __forceinline__ unsigned long long wkey(int n, int item) {
     return ((unsigned long long)(unsigned)n << 32) | (unsigned)item;
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     }
     Q[i] = q;
     C[i] = c;
-    small[i] = (q == 1 && bound <= SMALL_BOUND) ? 1 : 0;
+    // table class: 1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024
+    small[i] = (q != 1) ? 0 : (bound <= SMALL_BOUND ? 1 : (bound <= 2 * SMALL_BOUND ? 3 : (bound <= MID_BOUND ? 2 : 0)));
     Wp[i] = (unsigned long long)w;
 }
 
@@ -303,8 +305,9 @@ constexpr int GRP = 8;                  // lanes per rater
 constexpr int NGRP = 64 / GRP;          // raters per step
 
 // The table size is a template parameter: rows whose partner bound is <= SMALL_BOUND (the vast majority: items
-// with a handful of raters) run with 128 slots (3.5 KB of LDS, full occupancy, 8x cheaper init/finalise), the
-// others with 1024.  Both launches cover all light units; a block whose row is of the other class exits at once.
+// with a handful of raters) run with 128 slots (3.5 KB of LDS, full occupancy, 8x cheaper init/finalise), rows up
+// to MID_BOUND with 512, the others with 1024.  Every launch covers all light units; a block whose row is of
+// another class exits at once.
 
 template <int METHOD, int LOG_SLOTS>
 __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
@@ -319,8 +322,8 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
     const long long unit = A.unit_lo + blockIdx.x;
     if (unit >= A.unit_hi) return;
     const int i = uniform(A.uq_item[unit]);
-    const bool small = A.small[i] != 0;
-    if (small != (LOG_SLOTS < T_LOG_SLOTS)) return;
+    const int tcls = A.small[i];   // 1: 128 slots, 3: 256, 2: 512, 0: 1024
+    if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : 0)))) return;
     for (int s = lane; s < SLOTS_; s += 64) {
         key[s] = T_EMPTY; cm[s] = 0ull; dot[s] = 0.0;
         if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
@@ -710,9 +713,13 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         dim3 grid((unsigned)(unit_hi - unit_lo));
         if (method == XMAP_COSINE) {
             k_pair_tri<XMAP_COSINE, T_LOG_SLOTS><<<grid, dim3(64), 0, st>>>(A);
+            k_pair_tri<XMAP_COSINE, 9><<<grid, dim3(64), 0, st>>>(A);
+            k_pair_tri<XMAP_COSINE, 8><<<grid, dim3(64), 0, st>>>(A);
             k_pair_tri<XMAP_COSINE, 7><<<grid, dim3(64), 0, st>>>(A);
         } else {
             k_pair_tri<XMAP_ADJUST_COSINE, T_LOG_SLOTS><<<grid, dim3(64), 0, st>>>(A);
+            k_pair_tri<XMAP_ADJUST_COSINE, 9><<<grid, dim3(64), 0, st>>>(A);
+            k_pair_tri<XMAP_ADJUST_COSINE, 8><<<grid, dim3(64), 0, st>>>(A);
             k_pair_tri<XMAP_ADJUST_COSINE, 7><<<grid, dim3(64), 0, st>>>(A);
         }
         XM_LAUNCH_CHECK();
