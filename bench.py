@@ -182,7 +182,7 @@ def main():
                                  "launch_ms": paths_ms, "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
                                  "note": "latency/random-access bound: 32 B double-double read-modify-write per path"},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(r, attrs, args.method)
         print(json.dumps(out), flush=True)
     if dist:

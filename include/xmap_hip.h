@@ -80,6 +80,7 @@ int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *
  * all retrieve_path_info (core/baselinerSim.py:97-113) needs per co-rating:
  *   ua_item[e] = user_item[e] | ge<<31,  ia_user[p] = item_user[p] | ge<<31. */
 int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info /*[I][4]*/,
+                    double *norms /*[2][I] dense copies of norm2 / adjnorm2, may be NULL*/,
                     int32_t *ua_item /*[nnz]*/, int32_t *ia_user /*[nnz]*/);
 
 /* Work decomposition for the pair kernel: unit = (item i, hash partition q of its partner space),
@@ -138,7 +139,7 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
                    int64_t *h_counts /*[2]*/);
 int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64_t *uq_ptr, int32_t *uq_item,
                     int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c);
-int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *info,
+int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
                     const void *rc, const void *ub, const int32_t *Q,
                     const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,

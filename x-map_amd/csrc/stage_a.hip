@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_csc_fill(long long U, const long long *
 
 // one wave per item: lane-strided partial sums, fixed butterfly reduction (deterministic)
 __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr, const int *iuser, const float *irating,
-                                                    const double *u_avg, double *info, int *ia_user) {
+                                                    const double *u_avg, double *info, double *norms, int *ia_user) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
     int lane = lane_id();
@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
         info[(size_t)i * 4 + 1] = sqrt(q);
         info[(size_t)i * 4 + 2] = sqrt(a2);
         info[(size_t)i * 4 + 3] = 1.0 * n;
+        if (norms) {   // dense copies of the two norms: 8 B per item stays L2-resident for the per-pair gathers
+            norms[i] = sqrt(q);
+            norms[(size_t)I + i] = sqrt(a2);
+        }
     }
     for (long long p = p0 + lane; p < p1; p += 64) {
         unsigned ge = ((double)irating[p] >= avg) ? 0x80000000u : 0u;
@@ -404,14 +408,14 @@ int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *
     return XMAP_OK;
 }
 
-int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info, int32_t *ua_item,
-                    int32_t *ia_user) {
+int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info, double *norms,
+                    int32_t *ua_item, int32_t *ia_user) {
     XM_ARG(R && u_avg && info && ua_item && ia_user);
     XM_ARG(R->nnz < 0x7fffffffLL);
     hipStream_t st = (hipStream_t)stream;
     if (R->n_items > 0) {
         k_item_stats<<<dim3((unsigned)((R->n_items + 3) / 4)), dim3(256), 0, st>>>(
-            R->n_items, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, ia_user);
+            R->n_items, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, norms, ia_user);
         XM_LAUNCH_CHECK();
     }
     if (R->nnz > 0) {

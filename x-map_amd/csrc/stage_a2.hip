@@ -208,7 +208,7 @@ struct TriArgs {
     const long long *iptr;
     const RaterRec *rc;      // [nnz] rater records in CSC order
     const int2 *ub;          // [nnz] weight-sorted profiles: (item | flag, rating bits)
-    const double *u_avg; const double *info;
+    const double *u_avg; const double *nrm;   // nrm: dense [I] norm of the method (norm2 | adjnorm2)
     int cap;
     // light
     const int *Q; const uint8_t *small; const int *uq_item; const int *uq_q; long long unit_lo, unit_hi;
@@ -229,8 +229,7 @@ struct TriArgs {
 // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207) for one accumulated pair
 template <int METHOD>
 __device__ __forceinline__ bool finish_pair(const TriArgs &A, int i, int j, int n, int m, double dot, double &simv) {
-    const int c1 = (METHOD == XMAP_COSINE) ? 1 : 2;
-    const double np = A.info[(size_t)i * 4 + c1] * A.info[(size_t)j * 4 + c1];
+    const double np = A.nrm[i] * A.nrm[j];
     const double cs = (np != 0.0) ? 1.0 * dot / np : 0.0;
     const int mn = n < A.cap ? n : A.cap;
     simv = 1.0 * cs * (double)mn / (double)A.cap;
@@ -334,12 +333,7 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
     const int p1 = uniform((int)A.iptr[i + 1]);
     const int g = lane / GRP, sub = lane % GRP;
     int ovf = 0;
-#ifdef XM_EXP_NOWALK     // timing experiment only
-    const int p1w = p0;
-#else
-    const int p1w = p1;
-#endif
-    for (int base = p0; base < p1w; base += 64) {
+    for (int base = p0; base < p1; base += 64) {
         const int p = base + lane;
         int e0 = 0, pw = 0;
         float r = 0.f;
@@ -418,10 +412,6 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
         if (lane == 0) atomicOr(&A.counters[2], 1ull);
         return;
     }
-#ifdef XM_EXP_NOAPPEND   // timing experiment only
-    if (key[lane] == 12345u) A.rowcnt[0] = 1;
-    return;
-#endif
     append_pairs(A, i, SLOTS_,
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             uint32_t kj = key[s];
@@ -671,7 +661,7 @@ int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64
     return XMAP_OK;
 }
 
-int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *info,
+int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
                     const void *rc, const void *ub, const int32_t *Q,
                     const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
@@ -679,7 +669,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
                     int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/) {
-    XM_ARG(R && u_avg && info && rc && ub);
+    XM_ARG(R && u_avg && norms && rc && ub);
     XM_ARG(Q && small && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && rowcnt_h && d_shards && d_counters);
     XM_ARG(coo_cap >= COO_SHARDS);
@@ -696,7 +686,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     TriArgs A;
     memset(&A, 0, sizeof(A));
     A.iptr = (const long long *)R->item_ptr; A.rc = (const RaterRec *)rc; A.ub = (const int2 *)ub;
-    A.u_avg = u_avg; A.info = info; A.cap = cap;
+    A.u_avg = u_avg; A.nrm = norms + (method == XMAP_COSINE ? 0 : (size_t)R->n_items); A.cap = cap;
     A.Q = Q; A.small = small; A.uq_item = uq_item; A.uq_q = uq_q; A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     A.hid = hid; A.hlist = hlist; A.CH = ctl; A.uc_item = uc_item; A.uc_c = uc_c;
     A.uc_ptr = (const long long *)uc_ptr; A.C = C;

@@ -678,10 +678,6 @@ struct Path2Args {
 
 // merge a lane's register sums into the start's row (distinct ends per call)
 __device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, double s_hi, double s_lo, double c_hi, double c_lo) {
-#ifdef XM_EXP_NOFLUSH   // timing experiment only: no row traffic (results are wrong)
-    if (s_hi == 123.456) W.nt++;
-    return;
-#endif
     bool first = false;
     if (active) {
         double *a = W.acc + (size_t)end * 4;
@@ -860,7 +856,6 @@ __global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
         const int self = (A.cls[start] == 2) ? 1 : 0;   // head 0 = the start itself (target_path, extender.py:160-163)
         const long long nH = self + (r1 - r0);          // heads >= self: start in NN(x') (longest_path, :164-167)
         for (long long h = 0; h < nH; h++) {
-#ifndef XM_EXP_NOHEADS
             if (G == 1 || ent % G == c) {
                 const bool has_e1 = h >= self;
                 const int xp = has_e1 ? A.rnn_idx[r0 + h - self] : start;
@@ -869,7 +864,6 @@ __global__ __launch_bounds__(256) void k_paths2(Path2Args B) {
                                             A.rnn_val[(r0 + h - self) * 3 + 2]);
                 head_S(A, W, xp, has_e1, e1);
             }
-#endif
             ent++;
         }
         const long long nbatch = (nH + 63) / 64;

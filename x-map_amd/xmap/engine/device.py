@@ -146,9 +146,10 @@ class Engine(object):
         u_norm = self._empty(max(R.n_users, 1), torch.float64)
         check(lib.xmap_user_stats(st, C.byref(R.c), vp(u_avg), vp(u_norm)))
         info = self._zeros((max(R.n_items, 1), 4), torch.float64)
+        self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
         ua_item = self._empty(max(R.nnz, 1), torch.int32)
         ia_user = self._empty(max(R.nnz, 1), torch.int32)
-        check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(ua_item), vp(ia_user)))
+        check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user)))
         return u_avg, u_norm, info, ua_item, ia_user
 
     def plan(self, slot_target=640):
@@ -318,7 +319,7 @@ class Engine(object):
 
             def run(phases):
                 check(lib.xmap_sim2_pairs(
-                    st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(L.rc), vp(L.ub), vp(L.Q), vp(L.small),
+                    st, C.byref(R.c), m, int(cap), vp(u_avg), vp(self.norms), vp(L.rc), vp(L.ub), vp(L.Q), vp(L.small),
                     vp(L.uq_item),
                     vp(L.uq_q), i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,

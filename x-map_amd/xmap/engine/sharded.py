@@ -112,7 +112,8 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
         S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
-        light_local = 2 * int(L.Wp[L.uq_item[lo:hi].long()].sum().item()) if hi > lo else 0
+        it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
+        light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
     # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
     # ranges balanced by the exact per-start path counts
     with eng.timed("stage_b"):
