@@ -265,6 +265,15 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
 int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end,
                          const double *xs_val, int32_t *n_cand, int32_t *top_end, double *top_val);
 
+/* ---- dense item-factor variant (BASELINE.json configs[4]; no counterpart in the reference) --------------------
+ * xsim(t, s) = cosine of K-dimensional item factors: a dense (n_t x K) x (K x n_s) contraction on the fp32 matrix
+ * cores (v_mfma_f32_32x32x2_f32; the accumulation is the k-ordered fmaf chain, bit for bit) with the per-row top-k
+ * by (|sim| desc, source index asc) fused behind it.  normalize: Fn = F / ||F|| (norm in fp64).  top_k <= 64,
+ * dim in {64, 128}.  out_idx/out_val: [n_t][top_k], unused entries -1 / 0. */
+int xmap_dense_normalize(void *stream, int32_t n, int32_t dim, const float *F, float *Fn);
+int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const float *Ft, const float *Fs, int32_t top_k,
+                    int32_t *out_idx, float *out_val);
+
 /* ---- stage C: generator_pipeline (utils/assist.py:136-150) ---------------------------------- */
 
 /* Generator.cross_private_mapping / cross_nonprivate_mapping (core/generator.py:27-111) + map_to_dict

@@ -643,3 +643,47 @@ void xo_alter_free(XoAlter *A) {
     if (!A) return;
     free(A->user); free(A->item); free(A->rating); free(A->time); free(A);
 }
+
+/* ------------------------------------------------------------------ dense item-factor variant
+ * BASELINE.json configs[4] ("no reference counterpart; oracle = the defining arithmetic").
+ * PARITY UNPINNED against the reference by construction: the reference has no dense path, so there is nothing to
+ * capture vectors from.  The arithmetic is defined here and the HIP path must reproduce it bit for bit:
+ *   Fn[i][k] = (float)((double)F[i][k] / sqrt(sum_k (double)F[i][k]^2))   (sum in k order; all-zero row -> zeros)
+ *   sim(t,s) = fmaf chain over k ascending in fp32, starting from +0
+ *   top-k per target row by (|sim| desc, source index asc); unused entries idx -1, val 0. */
+void xo_dense_normalize(int32_t n, int32_t K, const float *F, float *Fn) {
+    for (int32_t i = 0; i < n; i++) {
+        double q = 0.0;
+        for (int32_t k = 0; k < K; k++) { double x = (double)F[(size_t)i * K + k]; q += x * x; }
+        double nrm = sqrt(q);
+        for (int32_t k = 0; k < K; k++)
+            Fn[(size_t)i * K + k] = (nrm > 0.0) ? (float)((double)F[(size_t)i * K + k] / nrm) : 0.f;
+    }
+}
+
+static int dense_better(float va, int32_t ia, float vb, int32_t ib) {
+    float aa = fabsf(va), ab = fabsf(vb);
+    return (aa > ab) || (aa == ab && ia < ib);
+}
+
+void xo_dense_topk(int32_t n_t, int32_t n_s, int32_t K, const float *Ft, const float *Fs, int32_t top_k,
+                   int32_t *out_idx, float *out_val, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int32_t i = 0; i < n_t; i++) {
+        int32_t *oi = out_idx + (size_t)i * top_k;
+        float *ov = out_val + (size_t)i * top_k;
+        int cnt = 0;
+        for (int32_t j = 0; j < n_s; j++) {
+            float acc = 0.f;
+            for (int32_t k = 0; k < K; k++) acc = fmaf(Ft[(size_t)i * K + k], Fs[(size_t)j * K + k], acc);
+            if (cnt == top_k && !dense_better(acc, j, ov[cnt - 1], oi[cnt - 1])) continue;
+            int p = (cnt < top_k) ? cnt++ : top_k - 1;     /* sorted insertion */
+            while (p > 0 && dense_better(acc, j, ov[p - 1], oi[p - 1])) { ov[p] = ov[p - 1]; oi[p] = oi[p - 1]; p--; }
+            ov[p] = acc; oi[p] = j;
+        }
+        for (int p = cnt; p < top_k; p++) { oi[p] = -1; ov[p] = 0.f; }
+    }
+}

@@ -203,3 +203,24 @@ def alterego(T, map_src2tgt):
                n_target_rows=int(a.n_target_rows), n_profiles=int(a.n_profiles))
     lib().xo_alter_free(h)
     return out
+
+
+# ---------------------------------------------------------------------- dense item-factor variant (parity unpinned)
+def dense_normalize(F):
+    F = np.ascontiguousarray(F, np.float32)
+    out = np.empty_like(F)
+    lib().xo_dense_normalize(C.c_int32(F.shape[0]), C.c_int32(F.shape[1]), _p(F, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def dense_topk(Fn_t, Fn_s, top_k, nthreads=4):
+    """Top-k of the fp32 fmaf-chain dot of the (already normalised) factor rows, by (|v| desc, idx asc)."""
+    Fn_t = np.ascontiguousarray(Fn_t, np.float32)
+    Fn_s = np.ascontiguousarray(Fn_s, np.float32)
+    n_t, K = Fn_t.shape
+    idx = np.empty((n_t, top_k), np.int32)
+    val = np.empty((n_t, top_k), np.float32)
+    lib().xo_dense_topk(C.c_int32(n_t), C.c_int32(Fn_s.shape[0]), C.c_int32(K), _p(Fn_t, C.c_float),
+                        _p(Fn_s, C.c_float), C.c_int32(top_k), _p(idx, C.c_int32), _p(val, C.c_float),
+                        C.c_int(nthreads))
+    return idx, val

@@ -604,6 +604,51 @@ class Engine(object):
         E.start_range = (0, I) if start_range is None else tuple(start_range)
         return E
 
+    # ------------------------------------------------------------------ dense item-factor variant
+    def dense_topk(self, F_t, F_s, top_k):
+        """Row-wise top-k of cosine(F_t[i], F_s[j]) by (|sim| desc, j asc) on the fp32 matrix cores.
+        F_t [n_t, K], F_s [n_s, K]: host or device float32.  Returns (idx int32 [n_t, k], val float32 [n_t, k])."""
+        st = _stream(self.dev)
+        to = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, np.float32))).to(
+            self.dev, torch.float32).contiguous()
+        Ft, Fs = to(F_t), to(F_s)
+        n_t, K = Ft.shape
+        n_s = Fs.shape[0]
+        Fnt, Fns = torch.empty_like(Ft), torch.empty_like(Fs)
+        with self.timed("dense_normalize"):
+            check(lib.xmap_dense_normalize(st, i32(n_t), i32(K), vp(Ft), vp(Fnt)))
+            check(lib.xmap_dense_normalize(st, i32(n_s), i32(K), vp(Fs), vp(Fns)))
+        idx = self._empty((max(n_t, 1), top_k), torch.int32)
+        val = self._empty((max(n_t, 1), top_k), torch.float32)
+        with self.timed("dense_topk"):
+            check(lib.xmap_dense_topk(st, i32(n_t), i32(n_s), i32(K), vp(Fnt), vp(Fns), i32(top_k), vp(idx), vp(val)))
+        return idx[:n_t], val[:n_t]
+
+    def dense_extend(self, F, top_k):
+        """Dense replacement of stages A+B (BASELINE configs[4]): F [I, K] item factors; target-side items ("T:" in
+        iid) are the starts, source-side items ("S:" in iid) the candidates.  Returns an ExtResult with the same
+        candidate arrays extend() produces, so select() / alterego() run unchanged."""
+        R = self.R
+        I = R.n_items
+        F = (F if torch.is_tensor(F) else torch.from_numpy(np.ascontiguousarray(F, np.float32))).to(self.dev)
+        tgt = torch.nonzero((R.flags[:I] & 2) != 0).flatten()
+        src = torch.nonzero((R.flags[:I] & 1) != 0).flatten()
+        idx, val = self.dense_topk(F[tgt], F[src], top_k)
+        E = ExtResult()
+        E.k = top_k
+        E.dense_idx, E.dense_val, E.tgt, E.src = idx, val, tgt, src
+        E.n_cand = self._zeros(max(I, 1), torch.int32)
+        E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=self.dev)
+        E.top_val = self._zeros((max(I, 1), abi.TOPC), torch.float64)
+        c = min(abi.TOPC, top_k)
+        valid = idx >= 0
+        E.n_cand[tgt] = valid.sum(dim=1).to(torch.int32)
+        ends = torch.where(valid[:, :c], src[idx[:, :c].clamp(min=0).long()].to(torch.int32),
+                           torch.full_like(idx[:, :c], -1))
+        E.top_end[tgt, :c] = ends
+        E.top_val[tgt, :c] = val[:, :c].double()
+        return E
+
     # ------------------------------------------------------------------ stage C
     def select(self, E, private, picks=None):
         R = self.R
