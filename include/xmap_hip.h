@@ -269,10 +269,14 @@ int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, c
  * xsim(t, s) = cosine of K-dimensional item factors: a dense (n_t x K) x (K x n_s) contraction on the fp32 matrix
  * cores (v_mfma_f32_32x32x2_f32; the accumulation is the k-ordered fmaf chain, bit for bit) with the per-row top-k
  * by (|sim| desc, source index asc) fused behind it.  normalize: Fn = F / ||F|| (norm in fp64).  top_k <= 64,
- * dim in {64, 128}.  out_idx/out_val: [n_t][top_k], unused entries -1 / 0. */
+ * dim in {64, 128}.  out_idx/out_val: [n_t][top_k], unused entries -1 / 0.  The (row block x source tile) work grid
+ * is cut into one equal share per resident workgroup; a row block whose tiles fall into several shares is ranked in
+ * pieces that a merge kernel folds.  xmap_dense_layout (host only) returns the pieces per row the scratch
+ * part_idx/part_val [n_t][n_pieces][top_k] must hold (1: scratch unused, may be NULL). */
 int xmap_dense_normalize(void *stream, int32_t n, int32_t dim, const float *F, float *Fn);
+int xmap_dense_layout(int32_t n_t, int32_t n_s, int32_t *n_pieces);
 int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const float *Ft, const float *Fs, int32_t top_k,
-                    int32_t *out_idx, float *out_val);
+                    int32_t n_pieces, int32_t *part_idx, float *part_val, int32_t *out_idx, float *out_val);
 
 /* ---- stage C: generator_pipeline (utils/assist.py:136-150) ---------------------------------- */
 

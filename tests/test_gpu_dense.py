@@ -54,6 +54,18 @@ def test_dense_topk_bit_exact(n_t, n_s, K, k):
     assert np.all((idx >= 0).sum(1) == min(k, n_s))
 
 
+@pytest.mark.parametrize("n_t,n_s", [(600, 9000), (70, 40000), (5000, 3000)])
+def test_dense_pieces(n_t, n_s):
+    """Sizes at which a row block's source tiles fall into several workgroup shares (pieces + merge)."""
+    from oracle import xmap_oracle as xo
+    eng, _ = engine()
+    Ft, Fs = factors(41, n_t, 64, dup=n_t // 10), factors(42, n_s, 64, dup=n_s // 5)
+    idx, val = eng.dense_topk(Ft, Fs, 50)
+    oi, ov = xo.dense_topk(xo.dense_normalize(Ft), xo.dense_normalize(Fs), 50)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(val.cpu().numpy().view(np.uint32), ov.view(np.uint32))
+
+
 def test_dense_normalize_matches_oracle_and_fp64():
     import torch
     from oracle import xmap_oracle as xo

@@ -4,26 +4,33 @@
 // n_t x n_s similarity matrix (1.6e11 B at 200k x 200k) never exists in memory.
 //
 //   k_dense_normalize : Fn = F / ||F||  (norm in fp64, k order), one thread per row
-//   k_dense_topk      : workgroup = 8 waves = 256 target rows; wave w keeps the A fragments of its 32 rows for the
-//                       whole K in registers (K/2 VGPRs), the source items stream through LDS in tiles of 32 rows
-//                       (register-prefetched, padded rows: conflict-free ds_read_b32), one v_mfma_f32_32x32x2_f32
-//                       per k pair -> a 32x32 tile of similarities per wave and tile.  An MFMA f32 accumulation
-//                       is bit for bit the k-ordered fmaf chain, which is what the oracle computes.
-//                       Epilogue: each of the 16 accumulator registers holds one row's 32 columns on 32 lanes;
-//                       values that beat the row's current k-th best (|sim| desc, index asc) are inserted into
-//                       the row's unsorted top-k list in LDS (replace-the-worst, worst found by a wave min);
-//                       rows are private to a wave, so no workgroup barrier is needed for the lists.
+//   k_dense_topk      : workgroup = 4 waves = 128 target rows, two workgroups per CU (one wave of each per SIMD, so
+//                       one workgroup's ranking and barriers hide behind the other's MFMAs).  Wave w keeps the A
+//                       fragments of its 32 rows for the whole K in registers (K/2 VGPRs); the source items stream
+//                       through a double-buffered LDS stage of 2 x 32 rows (padded rows: conflict-free
+//                       ds_read_b32; one barrier per 64 source items); one v_mfma_f32_32x32x2_f32 per k pair gives
+//                       a 32x32 tile of similarities per wave and tile.  An MFMA f32 accumulation is bit for bit
+//                       the k-ordered fmaf chain, which is what the oracle computes.
+//                       Ranking: the 32 top-k lists of a wave live in registers, one VGPR pair (value, index) per
+//                       row with one list entry per lane (k <= 64).  Each lane also keeps, per accumulator
+//                       register, the |sim| of its row's worst kept entry; a tile's values are compared against
+//                       it in registers (one ballot per accumulator register), the few that pass replace the worst
+//                       entry (v_cndmask at the worst lane) and a DPP min-reduction gives the new bound.  No LDS or
+//                       memory traffic for the lists until the final write.
+//   k_dense_merge     : folds the partial lists when the source items were split over several workgroups.
 // MFMA-bound by design: 2 K n_t n_s flop against the 157 TFLOP/s fp32 matrix peak.
 #include "common.h"
 
 namespace xmap {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int D_WAVES = 8;       // waves per workgroup: two per SIMD, so one wave's epilogue hides behind the other's MFMAs
+constexpr int D_WAVES = 4;       // waves per workgroup
 constexpr int D_ROWS = 32 * D_WAVES;   // target rows per workgroup (32 per wave)
 constexpr int D_THREADS = 64 * D_WAVES;
-constexpr int D_TILE = 32;       // source items per tile
+constexpr int D_TILE = 32;       // source items per MFMA tile
+constexpr int D_GROUP = 2;       // tiles per LDS stage (one barrier per stage)
 constexpr int D_TOPK = 64;       // list capacity per row (k <= 64: one lane per entry)
 
 __global__ __launch_bounds__(256) void k_dense_normalize(int n, int K, const float *F, float *Fn) {
@@ -36,26 +43,54 @@ __global__ __launch_bounds__(256) void k_dense_normalize(int n, int K, const flo
         Fn[(size_t)i * K + k] = (nrm > 0.0) ? (float)((double)F[(size_t)i * K + k] / nrm) : 0.f;
 }
 
-// (|v|, idx) order: a is better than b
-__device__ __forceinline__ bool d_better(float va, int ia, float vb, int ib) {
-    const float aa = fabsf(va), ab = fabsf(vb);
-    return (aa > ab) || (aa == ab && ia < ib);
+// (|v|, idx) order packed in one word: larger key = better candidate (|v| desc, then idx asc)
+__device__ __forceinline__ unsigned long long d_key(float v, int idx) {
+    return ((unsigned long long)__float_as_uint(fabsf(v)) << 32) | (unsigned)(~idx);
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// wave-wide minimum, uniform result: four DPP steps inside the rows of 16 lanes, then the four row results
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = min(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = min(v, dpp_u32<0x141>(v));   // row_half_mirror
+    v = min(v, dpp_u32<0x140>(v));   // row_mirror
+    const unsigned a = (unsigned)rl32((int)v, 0), b = (unsigned)rl32((int)v, 16);
+    const unsigned c = (unsigned)rl32((int)v, 32), d = (unsigned)rl32((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// The work is the grid of (row block of 128 target rows) x (tile of 32 source items), linearised row block major and
+// cut into equal shares, one per workgroup; the grid is one residency of the chip (2 workgroups per CU), so there is
+// no tail round.  A share crosses row-block boundaries: each (row block, tile range) segment is ranked into its own
+// list ("piece" = number of share boundaries since the row block's first tile) and written sorted to
+// out[(row * n_pieces + piece) * k ...]; k_dense_merge folds a row's pieces.
 template <int K>
-__global__ __launch_bounds__(D_THREADS) void k_dense_topk(int n_t, int n_s, const float *Ft, const float *Fs, int k,
-                                                    int *out_idx, float *out_val) {
-    __shared__ float Bs[D_TILE][K + 1];
-    __shared__ float Lval[D_ROWS][D_TOPK];
-    __shared__ int Lidx[D_ROWS][D_TOPK];
-    __shared__ int Lcnt[D_ROWS];
-    __shared__ float Wval[D_ROWS];     // the row's current worst kept entry (valid once the list is full)
-    __shared__ int Widx[D_ROWS];
-    __shared__ int Wpos[D_ROWS];
+__global__ __launch_bounds__(D_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, const float *Ft, const float *Fs, int k,
+                  int *out_idx, float *out_val) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][D_GROUP * D_TILE][K + 4];   // row stride K+4: conflict-free ds_read_b128
 
     const int w = threadIdx.x >> 6, lane = lane_id();
-    const int row0 = blockIdx.x * D_ROWS + w * 32;
-    for (int r = lane; r < 32; r += 64) { Lcnt[w * 32 + r] = 0; }
+#if defined(D_CLOCK) || defined(D_TRACE)
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+#endif
+    const long long total = (long long)((n_t + D_ROWS - 1) / D_ROWS) * n_tiles;
+    const long long w_lo = blockIdx.x * share;
+    const long long w_hi = min(total, w_lo + share);
+    for (long long at = w_lo; at < w_hi;) {
+    const int rb = (int)(at / n_tiles);
+    const int t0 = (int)(at - (long long)rb * n_tiles);
+    const int t1 = (int)min((long long)n_tiles, t0 + (w_hi - at));
+    const int piece = (int)(blockIdx.x - ((long long)rb * n_tiles) / share);
+    at += t1 - t0;
+    const int row0 = rb * D_ROWS + w * 32;
+    const int s_lo = t0 * D_TILE;
+    const int s_hi = min(n_s, t1 * D_TILE);
     // A fragments: lane l holds A[i = l&31][k = 2 kk + (l>>5)]
     float a[K / 2];
     {
@@ -64,94 +99,212 @@ __global__ __launch_bounds__(D_THREADS) void k_dense_topk(int n_t, int n_s, cons
         for (int kk = 0; kk < K / 2; kk++)
             a[kk] = (i < n_t) ? Ft[(size_t)i * K + 2 * kk + (lane >> 5)] : 0.f;
     }
-    // tile staging: in step q thread t moves float q*D_THREADS + t of the 32 x K tile (coalesced loads, conflict-free stores)
-    constexpr int PER = D_TILE * K / D_THREADS;
-    float pre[PER];
-    auto fetch = [&](int c0) {
+    // The lists: register pair q = 2 r + h holds the list of the row that accumulator register r carries on the lanes
+    // of half h (row (r&3) + 8 (r>>2) + 4 h of the wave's 32), entry p on lane p.  Empty entries are (0, -1): they
+    // have the smallest key, so "replace the worst" also fills the list.  Lanes >= k hold (+inf, -2): never the worst.
+    float Lv[32];
+    int Li[32];
 #pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int e = q * D_THREADS + threadIdx.x;
-            const int jr = e / K, kc = e % K;
-            const int j = c0 + jr;
-            pre[q] = (j < n_s) ? Fs[(size_t)j * K + kc] : 0.f;
+    for (int q = 0; q < 32; q++) { Lv[q] = lane < k ? 0.f : __builtin_inff(); Li[q] = lane < k ? -1 : -2; }
+    // thr[r]: |value| of the worst kept entry of the row accumulator register r carries on this lane's half (+inf for
+    // rows past n_t: nothing enters)
+    float thr[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        thr[r] = (row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) < n_t) ? 0.f : __builtin_inff();
+
+    // staging: global -> LDS directly (global_load_lds_dword: lane i of a wave-load fills LDS dword base + i, the
+    // global address is per lane).  A row of the stage holds the even k first and the odd k behind them, so lane
+    // (j, h) finds its operands B[k = 2 kk + h][j] for 4 consecutive kk in one ds_read_b128; the permutation is done
+    // on the global side (lane i of the load for half q reads k = 2 i + q).  Wave w moves rows 8w .. 8w+7 of a tile.
+    // Columns past s_hi are never ranked, so their rows only need a valid address (clamped), not zeros.
+    auto fetch = [&](int buf, int t, int c0) {
+#pragma unroll
+        for (int jj = 0; jj < D_TILE / D_WAVES; jj++) {
+            const int jr = w * (D_TILE / D_WAVES) + jj;
+            const int j = min(c0 + jr, n_s - 1);
+            const float *src = Fs + (size_t)j * K;
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int part = 0; part < K / 128 + (K < 128); part++) {
+                    if (K >= 128 || lane < K / 2)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(src + 2 * (part * 64 + lane) + q),
+                            (__attribute__((address_space(3))) void *)&Bs[buf][t * D_TILE + jr][q * (K / 2) + part * 64], 4, 0, 0);
+                }
         }
     };
-    fetch(0);
-    for (int c0 = 0; c0 < n_s; c0 += D_TILE) {
-        __syncthreads();   // previous tile fully consumed
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int e = q * D_THREADS + threadIdx.x;
-            Bs[e / K][e % K] = pre[q];
-        }
-        __syncthreads();
-        if (c0 + D_TILE < n_s) fetch(c0 + D_TILE);   // overlaps with the MFMA loop below
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < K / 2; kk++) {
-            const float b = Bs[lane & 31][2 * kk + (lane >> 5)];   // B[k = 2kk + (l>>5)][j = l&31]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc, 0, 0, 0);
-        }
-        // epilogue: register r holds row (r&3) + 8 (r>>2) + 4 (l>>5) of the wave's 32, column l&31
+    // ranking of one 32 x 32 tile
+    auto rank_tile = [&](const f32x16 &acc, int c0) {
         const int j = c0 + (lane & 31);
+        const bool jv = j < s_hi;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int rl = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int gi = blockIdx.x * D_ROWS + rl;
             const float v = acc[r];
-            bool cand = (gi < n_t) && (j < n_s);
-            if (cand && Lcnt[rl] >= k) cand = d_better(v, j, Wval[rl], Widx[rl]);
-            unsigned long long m = __ballot(cand);
-            while (m) {   // insert the candidates one by one (all lanes cooperate on one row's list)
+            unsigned long long m = __ballot(jv && fabsf(v) >= thr[r]);
+            while (m) {   // the candidates one by one, all lanes cooperating on the candidate's row
                 const int l = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const int rr = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                const bool h = l >= 32;
                 const float cv = rlf(v, l);
                 const int cj = c0 + (l & 31);
-                int cnt = Lcnt[rr];
-                if (cnt < k) {
-                    if (lane == 0) { Lval[rr][cnt] = cv; Lidx[rr][cnt] = cj; Lcnt[rr] = cnt + 1; }
-                    cnt++;
-                    if (cnt < k) continue;
-                } else {
-                    // a later candidate of the same ballot may no longer beat the updated worst
-                    if (!d_better(cv, cj, Wval[rr], Widx[rr])) continue;
-                    if (lane == 0) { Lval[rr][Wpos[rr]] = cv; Lidx[rr][Wpos[rr]] = cj; }
+                const float tb = rlf(thr[r], l);   // the row's current bound (an earlier candidate may have raised it)
+                const float ca = fabsf(cv);
+                if (ca < tb) continue;
+                float lv = h ? Lv[2 * r + 1] : Lv[2 * r];
+                int li = h ? Li[2 * r + 1] : Li[2 * r];
+                // the worst entry: |value| == bound; among several the empty ones first, then the largest index
+                const unsigned long long eq = __ballot(__float_as_uint(fabsf(lv)) == __float_as_uint(tb));
+                int pos = __ffsll((long long)eq) - 1;
+                if (eq & (eq - 1)) {
+                    const unsigned long long em = __ballot(li == -1);
+                    if (em) {
+                        pos = __ffsll((long long)em) - 1;
+                    } else {
+                        unsigned best = 0;
+                        for (unsigned long long e2 = eq; e2; e2 &= e2 - 1) {
+                            const int b = __ffsll((long long)e2) - 1;
+                            const unsigned ib = (unsigned)rl32(li, b);
+                            if (ib >= best) { best = ib; pos = b; }
+                        }
+                    }
                 }
-                // list is full: find its worst entry (lane per entry, wave min in the (|v|, idx) order)
-                float wv = 0.f; int wi = -1, wp = lane;
-                bool have = lane < k;
-                if (have) { wv = Lval[rr][lane]; wi = Lidx[rr][lane]; }
-#pragma unroll
-                for (int s = 32; s >= 1; s >>= 1) {
-                    const float ov = __shfl_xor(wv, s, 64);
-                    const int oi = __shfl_xor(wi, s, 64), op = __shfl_xor(wp, s, 64);
-                    const int oh = __shfl_xor((int)have, s, 64);
-                    if (oh && (!have || d_better(wv, wi, ov, oi))) { wv = ov; wi = oi; wp = op; have = true; }
-                }
-                if (lane == 0) { Wval[rr] = wv; Widx[rr] = wi; Wpos[rr] = wp; }
+                if (ca == tb && (unsigned)cj > (unsigned)rl32(li, pos)) continue;   // equal |value|: smaller index wins
+                if (lane == pos) { lv = cv; li = cj; }
+                if (h) { Lv[2 * r + 1] = lv; Li[2 * r + 1] = li; } else { Lv[2 * r] = lv; Li[2 * r] = li; }
+                const float nb = __uint_as_float(wave_min_u32(__float_as_uint(fabsf(lv))));
+                if ((lane >= 32) == h) thr[r] = nb;
             }
         }
-    }
-    // sort every row's list by (|v| desc, idx asc): rank by counting, lane per entry
-    for (int r = 0; r < 32; r++) {
-        const int rl = w * 32 + r;
-        const int gi = blockIdx.x * D_ROWS + rl;
-        if (gi >= n_t) break;
-        const int cnt = Lcnt[rl];
-        float v = 0.f; int id = 0x7fffffff;
-        if (lane < cnt) { v = Lval[rl][lane]; id = Lidx[rl][lane]; }
-        int rank = 0;
-        for (int o = 0; o < cnt; o++) {
-            const float ov = rlf(v, o);
-            const int oi = rl32(id, o);
-            rank += (lane < cnt && o != lane && d_better(ov, oi, v, id)) ? 1 : 0;
+    };
+
+    const int n_tiles = (s_hi - s_lo + D_TILE - 1) / D_TILE;
+    const int n_groups = (n_tiles + D_GROUP - 1) / D_GROUP;
+#pragma unroll
+    for (int t = 0; t < D_GROUP; t++) fetch(0, t, s_lo + t * D_TILE);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the LDS-direct loads have landed
+    __syncthreads();
+    for (int g = 0; g < n_groups; g++) {
+        const int buf = g & 1;
+        const bool more = g + 1 < n_groups;
+#pragma unroll
+        for (int t = 0; t < D_GROUP; t++) {
+            const int c0 = s_lo + (g * D_GROUP + t) * D_TILE;
+            // the same tile of the next stage, into the buffer that was last read before the previous barrier
+            if (more) fetch(buf ^ 1, t, c0 + D_GROUP * D_TILE);
+            if (c0 < s_hi) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                const f32x4 *brow = (const f32x4 *)&Bs[buf][t * D_TILE + (lane & 31)][(lane >> 5) * (K / 2)];
+                f32x4 x = brow[0];
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int c = 0; c < K / 8; c++) {   // 4 k pairs per ds_read_b128, the next one in flight
+                    const f32x4 nx = brow[c + 1 < K / 8 ? c + 1 : c];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 0], x[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 1], x[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 2], x[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 3], x[3], acc, 0, 0, 0);
+                    x = nx;
+                    // the next ds_read_b128 goes out behind the first of these MFMAs: the wait for this chunk's
+                    // operands (lgkmcnt(0): the LDS-direct loads make the compiler count conservatively) then sits
+                    // before the new read is issued, and that read has three MFMAs to land
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+#ifdef D_NORANK
+                { float sacc = 0.f;
+#pragma unroll
+                  for (int r = 0; r < 16; r++) sacc += acc[r];
+                  if (sacc == 123.456f) out_val[0] = sacc; }
+#else
+                rank_tile(acc, c0);
+#endif
+            }
         }
-        if (lane < cnt) { out_idx[(size_t)gi * k + rank] = id; out_val[(size_t)gi * k + rank] = v; }
-        if (lane >= cnt && lane < k) { out_idx[(size_t)gi * k + lane] = -1; out_val[(size_t)gi * k + lane] = 0.f; }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
     }
+    // write every row's list sorted by (|v| desc, idx asc): rank by counting, lane per entry
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int r = q >> 1, h = q & 1;
+        const int gi = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (gi < n_t) {
+            const float v = Lv[q];
+            const int id = Li[q];
+            const bool valid = id >= 0;
+            const int cnt = __popcll(__ballot(valid));
+            const unsigned long long key = valid ? d_key(v, id) : 0ull;
+            int rank = 0;
+            for (int o = 0; o < k; o++) {
+                const unsigned long long ok = ((unsigned long long)(unsigned)rl32((int)(key >> 32), o) << 32) |
+                                              (unsigned)rl32((int)(key & 0xffffffffull), o);
+                rank += (ok > key) ? 1 : 0;
+            }
+            const size_t base = ((size_t)gi * n_pieces + piece) * k;
+            if (valid) { out_idx[base + rank] = id; out_val[base + rank] = v; }
+            if (lane >= cnt && lane < k) { out_idx[base + lane] = -1; out_val[base + lane] = 0.f; }
+        }
+    }
+    }   // segments
+#ifdef D_TRACE
+    if (threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *tr = (unsigned long long *)out_val;
+        tr[blockIdx.x * 4 + 0] = rt0; tr[blockIdx.x * 4 + 1] = wall_clock64(); tr[blockIdx.x * 4 + 2] = hw; tr[blockIdx.x * 4 + 3] = xcc;
+    }
+#endif
+#ifdef D_CLOCK
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("shader clocks %llu, 100 MHz ticks %llu -> %.0f MHz\n", __builtin_readcyclecounter() - clk0,
+               wall_clock64() - rt0, (double)(__builtin_readcyclecounter() - clk0) / (double)(wall_clock64() - rt0) * 100.0);
+#endif
+}
+
+// fold the n_split sorted partial lists of a row (wave per row): a candidate's final rank is the sum over the lists of
+// the number of better entries, found by binary search (keys are unique; padding has key 0)
+constexpr int D_MAXSPLIT = 16;
+__global__ __launch_bounds__(256) void k_dense_merge(int n_t, int n_tiles, long long share, int n_pieces, int k,
+                                                     const int *p_idx, const float *p_val, int *out_idx, float *out_val) {
+    __shared__ unsigned long long keys[4][D_MAXSPLIT * D_TOPK];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= n_t) return;
+    const long long rb = row / D_ROWS;
+    const int ns = (int)(((rb + 1) * n_tiles - 1) / share - (rb * n_tiles) / share) + 1;   // pieces this row block has
+    const int n = ns * k;
+    const int *pi = p_idx + (size_t)row * n_pieces * k;
+    const float *pv = p_val + (size_t)row * n_pieces * k;
+    int total = 0;
+    for (int c = lane; c < n; c += 64) {
+        const int id = pi[c];
+        keys[wv][c] = id >= 0 ? d_key(pv[c], id) : 0ull;
+        total += id >= 0;
+    }
+    total = (int)wave_sum_ll(total);
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < n; c += 64) {
+        const unsigned long long key = keys[wv][c];
+        if (key == 0ull) continue;
+        int rank = 0;
+        for (int s = 0; s < ns && rank < k; s++) {   // entries of list s that are better: lower bound in a descending list
+            const unsigned long long *L = keys[wv] + s * k;
+            int lo = 0, hi = k;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (L[mid] > key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) { out_idx[(size_t)row * k + rank] = pi[c]; out_val[(size_t)row * k + rank] = pv[c]; }
+    }
+    for (int p = (total < k ? total : k) + lane; p < k; p += 64) { out_idx[(size_t)row * k + p] = -1; out_val[(size_t)row * k + p] = 0.f; }
 }
 
 }  // namespace xmap
@@ -168,8 +321,39 @@ int xmap_dense_normalize(void *stream, int32_t n, int32_t dim, const float *F, f
     return XMAP_OK;
 }
 
+// share of the (row block x tile) grid per workgroup and the largest number of pieces a row block is cut into
+static void dense_layout(int n_t, int n_s, int &n_tiles, long long &share, int &n_wg, int &n_pieces) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    n_tiles = (n_s + D_TILE - 1) / D_TILE;
+    if (n_tiles < 1) n_tiles = 1;
+    const long long n_rb = (n_t + D_ROWS - 1) / D_ROWS;
+    const long long total = n_rb * n_tiles;
+    share = (total + 2LL * cus - 1) / (2LL * cus);
+    const long long cap = (n_tiles + D_MAXSPLIT - 3) / (D_MAXSPLIT - 2);   // at most D_MAXSPLIT pieces per row block
+    if (share < cap) share = cap;
+    if (share < 16) share = 16;
+    n_wg = (int)((total + share - 1) / share);
+    n_pieces = 1;
+    for (long long rb = 0; rb < n_rb; rb++) {
+        const int p = (int)(((rb + 1) * n_tiles - 1) / share - (rb * n_tiles) / share) + 1;
+        if (p > n_pieces) n_pieces = p;
+    }
+}
+
+int xmap_dense_layout(int32_t n_t, int32_t n_s, int32_t *n_pieces) {
+    XM_ARG(n_pieces && n_t >= 0 && n_s >= 0);
+    int n_tiles, n_wg;
+    long long share;
+    int np = 1;
+    dense_layout(n_t, n_s, n_tiles, share, n_wg, np);
+    *n_pieces = np;
+    return XMAP_OK;
+}
+
 int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const float *Ft, const float *Fs, int32_t top_k,
-                    int32_t *out_idx, float *out_val) {
+                    int32_t n_pieces, int32_t *part_idx, float *part_val, int32_t *out_idx, float *out_val) {
     XM_ARG(Ft && Fs && out_idx && out_val && n_t >= 0 && n_s >= 0);
     XM_ARG(top_k >= 1 && top_k <= D_TOPK);
     if (dim != 128 && dim != 64) {
@@ -177,11 +361,25 @@ int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const f
         return XMAP_ERR_ARG;
     }
     if (n_t == 0) return XMAP_OK;
-    dim3 grid((unsigned)((n_t + D_ROWS - 1) / D_ROWS)), block(D_THREADS);
+    int n_tiles, n_wg, need;
+    long long share;
+    dense_layout(n_t, n_s, n_tiles, share, n_wg, need);
+    if (n_pieces < need || (need > 1 && !(part_idx && part_val))) {
+        set_error("dense variant: scratch for %d pieces per row needed (xmap_dense_layout), %d given", need, n_pieces);
+        return XMAP_ERR_CAPACITY;
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (dim == 128) k_dense_topk<128><<<grid, block, 0, st>>>(n_t, n_s, Ft, Fs, top_k, out_idx, out_val);
-    else k_dense_topk<64><<<grid, block, 0, st>>>(n_t, n_s, Ft, Fs, top_k, out_idx, out_val);
+    int32_t *pi = need == 1 ? out_idx : part_idx;
+    float *pv = need == 1 ? out_val : part_val;
+    dim3 grid((unsigned)n_wg), block(D_THREADS);
+    if (dim == 128) k_dense_topk<128><<<grid, block, 0, st>>>(n_t, n_s, n_tiles, share, need, Ft, Fs, top_k, pi, pv);
+    else k_dense_topk<64><<<grid, block, 0, st>>>(n_t, n_s, n_tiles, share, need, Ft, Fs, top_k, pi, pv);
     XM_LAUNCH_CHECK();
+    if (need > 1) {
+        k_dense_merge<<<dim3((unsigned)((n_t + 3) / 4)), dim3(256), 0, st>>>(n_t, n_tiles, share, need, top_k, pi, pv,
+                                                                               out_idx, out_val);
+        XM_LAUNCH_CHECK();
+    }
     return XMAP_OK;
 }
 }

@@ -620,8 +620,14 @@ class Engine(object):
             check(lib.xmap_dense_normalize(st, i32(n_s), i32(K), vp(Fs), vp(Fns)))
         idx = self._empty((max(n_t, 1), top_k), torch.int32)
         val = self._empty((max(n_t, 1), top_k), torch.float32)
+        npc = C.c_int32(1)
+        check(lib.xmap_dense_layout(i32(n_t), i32(n_s), C.byref(npc)))
+        n_pieces = int(npc.value)
+        pidx = self._empty((max(n_t, 1), n_pieces, top_k), torch.int32) if n_pieces > 1 else None
+        pval = self._empty((max(n_t, 1), n_pieces, top_k), torch.float32) if n_pieces > 1 else None
         with self.timed("dense_topk"):
-            check(lib.xmap_dense_topk(st, i32(n_t), i32(n_s), i32(K), vp(Fnt), vp(Fns), i32(top_k), vp(idx), vp(val)))
+            check(lib.xmap_dense_topk(st, i32(n_t), i32(n_s), i32(K), vp(Fnt), vp(Fns), i32(top_k), i32(n_pieces),
+                                      vp(pidx), vp(pval), vp(idx), vp(val)))
         return idx[:n_t], val[:n_t]
 
     def dense_extend(self, F, top_k):
