@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 CAP = 50                # parameters.yaml:18
 
 
@@ -74,6 +75,69 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4):
     return out
 
 
+def bench_dense(args, rank, world, local, dist):
+    """--workload dense: BASELINE.json configs[4], 200k x 200k item factors of dimension 128, top-k 50.  The target
+    rows are split over the ranks (no exchange: every rank ranks its rows against all source items)."""
+    from xmap.engine import device, synth
+    dev = "cuda:%d" % local
+    n_t = n_s = 200000
+    K, k = 128, args.k or 50
+    r = synth.make_two_domain(3, 60, 30, 30, overlap=0.5)      # an Engine needs a ratings handle; unused here
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev))
+    g = torch.Generator(device=dev).manual_seed(1)
+    Ft = torch.randn(n_t, K, device=dev, generator=g)
+    Fs = torch.randn(n_s, K, device=dev, generator=g)
+    lo, hi = rank * n_t // world, (rank + 1) * n_t // world
+    for _ in range(args.warmup):
+        eng.dense_topk(Ft[lo:hi], Fs, k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    eng.timers = {}
+    t0 = time.time()
+    for _ in range(args.steps):
+        eng.dense_topk(Ft[lo:hi], Fs, k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.time() - t0
+    tm = eng.timer_ms()
+    if dist:
+        wt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        wall = float(wt.item())
+    if rank == 0:
+        ms = float(np.mean(tm["dense_topk"]))
+        flop = 2.0 * K * (hi - lo) * n_s
+        ach = flop / (ms * 1e-3) / 1e12
+        out = {"metric": "dense_item_sim_pairs_per_s", "value": float(n_t) * n_s * args.steps / wall, "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "dense 128-d item factors 200k x 200k, top-k=%d (BASELINE configs[4])" % k,
+                          "parallelism": "target rows sharded over %d GPU(s)" % world},
+               "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+               "roofline": {"bound": "mfma", "kernel": "k_dense_topk", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("k_dense_topk"),
+                            "algorithmic_flop_per_launch": flop, "launch_ms": ms}}
+        if not args.no_cpu and world == 1:
+            from oracle import xmap_oracle as xo
+            rows, threads = 64, 4
+            a, b = xo.dense_normalize(Ft[:rows].cpu().numpy()), xo.dense_normalize(Fs.cpu().numpy())
+            t0 = time.time()
+            xo.dense_topk(a, b, k, nthreads=threads)
+            dt = time.time() - t0
+            while dt < 5.0 and rows < 4096:
+                rows *= 4
+                a = xo.dense_normalize(Ft[:rows].cpu().numpy())
+                t0 = time.time()
+                xo.dense_topk(a, b, k, nthreads=threads)
+                dt = time.time() - t0
+            out["cpu_baseline"] = dict(value=rows * float(n_s) / dt, unit="pairs/s", cores=threads, kind="port",
+                                       sample="oracle dense top-k on target rows [0,%d) x all %d sources: %.1f s, OpenMP %d threads"
+                                              % (rows, n_s, dt, threads))
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +169,12 @@ def main():
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
 
+    if args.workload == "dense":
+        bench_dense(args, rank, world, local, dist)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from xmap.engine import device, sharded
     wl = workloads()[args.workload]
     k = args.k or wl["k"]

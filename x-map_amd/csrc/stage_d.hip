@@ -4,13 +4,16 @@
 // n_t x n_s similarity matrix (1.6e11 B at 200k x 200k) never exists in memory.
 //
 //   k_dense_normalize : Fn = F / ||F||  (norm in fp64, k order), one thread per row
-//   k_dense_topk      : workgroup = 4 waves = 128 target rows, two workgroups per CU (one wave of each per SIMD, so
-//                       one workgroup's ranking and barriers hide behind the other's MFMAs).  Wave w keeps the A
+//   k_dense_topk      : one workgroup of 8 waves = 256 target rows per CU, two waves per SIMD.  Wave w keeps the A
 //                       fragments of its 32 rows for the whole K in registers (K/2 VGPRs); the source items stream
-//                       through a double-buffered LDS stage of 2 x 32 rows (padded rows: conflict-free
-//                       ds_read_b32; one barrier per 64 source items); one v_mfma_f32_32x32x2_f32 per k pair gives
-//                       a 32x32 tile of similarities per wave and tile.  An MFMA f32 accumulation is bit for bit
-//                       the k-ordered fmaf chain, which is what the oracle computes.
+//                       through a double-buffered LDS stage of 4 x 32 rows, filled by LDS-direct global loads
+//                       (one barrier per 128 source items); a wave multiplies two 32x32 tiles at a time (two
+//                       independent accumulator chains of v_mfma_f32_32x32x2_f32, operands by ds_read_b128 issued
+//                       one group ahead).  An MFMA f32 accumulation is bit for bit the k-ordered fmaf chain, which
+//                       is what the oracle computes.
+//                       The barriers keep all waves on the same stage, so the two waves of a SIMD would multiply
+//                       together and rank together; waves 4..7 therefore rank a tile pair BEFORE the next pair's
+//                       MFMAs and waves 0..3 AFTER their own: one wave's ranking runs under the other's MFMAs.
 //                       Ranking: the 32 top-k lists of a wave live in registers, one VGPR pair (value, index) per
 //                       row with one list entry per lane (k <= 64).  Each lane also keeps, per accumulator
 //                       register, the |sim| of its row's worst kept entry; a tile's values are compared against
@@ -26,11 +29,11 @@ namespace xmap {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int D_WAVES = 4;       // waves per workgroup
+constexpr int D_WAVES = 8;       // waves per workgroup (two per SIMD)
 constexpr int D_ROWS = 32 * D_WAVES;   // target rows per workgroup (32 per wave)
 constexpr int D_THREADS = 64 * D_WAVES;
 constexpr int D_TILE = 32;       // source items per MFMA tile
-constexpr int D_GROUP = 2;       // tiles per LDS stage (one barrier per stage)
+constexpr int D_GROUP = 4;       // tiles per LDS stage (one barrier per stage), multiplied in pairs
 constexpr int D_TOPK = 64;       // list capacity per row (k <= 64: one lane per entry)
 
 __global__ __launch_bounds__(256) void k_dense_normalize(int n, int K, const float *F, float *Fn) {
@@ -64,10 +67,10 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return min(min(a, b), min(c, d));
 }
 
-// The work is the grid of (row block of 128 target rows) x (tile of 32 source items), linearised row block major and
-// cut into equal shares, one per workgroup; the grid is one residency of the chip (2 workgroups per CU), so there is
-// no tail round.  A share crosses row-block boundaries: each (row block, tile range) segment is ranked into its own
-// list ("piece" = number of share boundaries since the row block's first tile) and written sorted to
+// The work is the grid of (row block of 256 target rows) x (tile of 32 source items), linearised row block major and
+// cut into equal shares, one per workgroup; the grid is one residency of the chip (one workgroup per CU), so there
+// is no tail round.  A share crosses row-block boundaries: each (row block, tile range) segment is ranked into its
+// own list ("piece" = number of share boundaries since the row block's first tile) and written sorted to
 // out[(row * n_pieces + piece) * k ...]; k_dense_merge folds a row's pieces.
 template <int K>
 __global__ __launch_bounds__(D_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -76,8 +79,9 @@ void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, 
     __shared__ __attribute__((aligned(16))) float Bs[2][D_GROUP * D_TILE][K + 4];   // row stride K+4: conflict-free ds_read_b128
 
     const int w = threadIdx.x >> 6, lane = lane_id();
-#if defined(D_CLOCK) || defined(D_TRACE)
-    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    const bool late = w >= D_WAVES / 2;   // waves w and w + 4 share a SIMD (checked with HW_REG_HW_ID, build -DD_TRACE)
+#ifdef D_TRACE
+    const unsigned long long rt0 = wall_clock64();
 #endif
     const long long total = (long long)((n_t + D_ROWS - 1) / D_ROWS) * n_tiles;
     const long long w_lo = blockIdx.x * share;
@@ -100,12 +104,14 @@ void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, 
             a[kk] = (i < n_t) ? Ft[(size_t)i * K + 2 * kk + (lane >> 5)] : 0.f;
     }
     // The lists: register pair q = 2 r + h holds the list of the row that accumulator register r carries on the lanes
-    // of half h (row (r&3) + 8 (r>>2) + 4 h of the wave's 32), entry p on lane p.  Empty entries are (0, -1): they
-    // have the smallest key, so "replace the worst" also fills the list.  Lanes >= k hold (+inf, -2): never the worst.
+    // of half h (row (r&3) + 8 (r>>2) + 4 h of the wave's 32), entry p on lane p, SORTED by key (best on lane 0).
+    // Empty entries are (0, -1), the smallest key, so inserting into the sorted list also fills it; lanes >= k are
+    // scratch (the shift pushes the dropped entry there).
     float Lv[32];
     int Li[32];
 #pragma unroll
-    for (int q = 0; q < 32; q++) { Lv[q] = lane < k ? 0.f : __builtin_inff(); Li[q] = lane < k ? -1 : -2; }
+    for (int q = 0; q < 32; q++) { Lv[q] = 0.f; Li[q] = -1; }
+    const unsigned long long kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
     // thr[r]: |value| of the worst kept entry of the row accumulator register r carries on this lane's half (+inf for
     // rows past n_t: nothing enters)
     float thr[16];
@@ -116,154 +122,148 @@ void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, 
     // staging: global -> LDS directly (global_load_lds_dword: lane i of a wave-load fills LDS dword base + i, the
     // global address is per lane).  A row of the stage holds the even k first and the odd k behind them, so lane
     // (j, h) finds its operands B[k = 2 kk + h][j] for 4 consecutive kk in one ds_read_b128; the permutation is done
-    // on the global side (lane i of the load for half q reads k = 2 i + q).  Wave w moves rows 8w .. 8w+7 of a tile.
-    // Columns past s_hi are never ranked, so their rows only need a valid address (clamped), not zeros.
-    auto fetch = [&](int buf, int t, int c0) {
+    // on the global side (lane i of the load for half q reads k = 2 i + q).  Of the 128 rows of a stage wave w moves
+    // rows 16 w + 8 part .. + 7 in call `part` (0, 1).  Columns past s_hi are never ranked, so their rows only need
+    // a valid address (clamped), not zeros.
+    constexpr int FROWS = D_GROUP * D_TILE / D_WAVES / 2;
+    auto fetch = [&](int buf, int part, int cbase) {
 #pragma unroll
-        for (int jj = 0; jj < D_TILE / D_WAVES; jj++) {
-            const int jr = w * (D_TILE / D_WAVES) + jj;
-            const int j = min(c0 + jr, n_s - 1);
+        for (int jj = 0; jj < FROWS; jj++) {
+            const int jr = w * 2 * FROWS + part * FROWS + jj;
+            const int j = min(cbase + jr, n_s - 1);
             const float *src = Fs + (size_t)j * K;
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int part = 0; part < K / 128 + (K < 128); part++) {
-                    if (K >= 128 || lane < K / 2)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)(src + 2 * (part * 64 + lane) + q),
-                            (__attribute__((address_space(3))) void *)&Bs[buf][t * D_TILE + jr][q * (K / 2) + part * 64], 4, 0, 0);
-                }
+            for (int q = 0; q < 2; q++) {
+                if (K >= 128 || lane < K / 2)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * lane + q),
+                                                     (__attribute__((address_space(3))) void *)&Bs[buf][jr][q * (K / 2)], 4, 0, 0);
+            }
         }
     };
-    // ranking of one 32 x 32 tile
+    // ranking of one 32 x 32 tile.  insert(): the candidates of one row (the set bits of mm, lanes lane_base + bit),
+    // one by one, all lanes cooperating: position = number of kept entries with a larger key (one 64-bit compare +
+    // popcount), entries behind it move one lane up (DPP wave_shr:1), the candidate takes the gap, and the k-th
+    // entry is the new bound.
+    auto insert = [&](float &lv, int &li, float &th, unsigned mm, int lane_base, float v, int c0, bool upper) {
+        while (mm) {
+            const int l = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const float cv = rlf(v, lane_base + l);
+            const int cj = c0 + l;
+            const unsigned long long ckey = d_key(cv, cj);
+            const unsigned long long key = ((unsigned long long)(__float_as_uint(lv) & 0x7fffffffu) << 32) | (unsigned)(~li);
+            const int pos = __popcll(__ballot(key > ckey) & kmask);
+            if (pos >= k) continue;   // an earlier candidate of this tile raised the bar, or an index tie lost
+            const float sv = __uint_as_float(dpp_u32<0x138>(__float_as_uint(lv)));   // wave_shr:1
+            const int si = (int)dpp_u32<0x138>((unsigned)li);
+            lv = lane > pos ? sv : (lane == pos ? cv : lv);
+            li = lane > pos ? si : (lane == pos ? cj : li);
+            const float nb = fabsf(rlf(lv, k - 1));
+            if ((lane >= 32) == upper) th = nb;
+        }
+    };
     auto rank_tile = [&](const f32x16 &acc, int c0) {
         const int j = c0 + (lane & 31);
         const bool jv = j < s_hi;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float v = acc[r];
-            unsigned long long m = __ballot(jv && fabsf(v) >= thr[r]);
-            while (m) {   // the candidates one by one, all lanes cooperating on the candidate's row
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const bool h = l >= 32;
-                const float cv = rlf(v, l);
-                const int cj = c0 + (l & 31);
-                const float tb = rlf(thr[r], l);   // the row's current bound (an earlier candidate may have raised it)
-                const float ca = fabsf(cv);
-                if (ca < tb) continue;
-                float lv = h ? Lv[2 * r + 1] : Lv[2 * r];
-                int li = h ? Li[2 * r + 1] : Li[2 * r];
-                // the worst entry: |value| == bound; among several the empty ones first, then the largest index
-                const unsigned long long eq = __ballot(__float_as_uint(fabsf(lv)) == __float_as_uint(tb));
-                int pos = __ffsll((long long)eq) - 1;
-                if (eq & (eq - 1)) {
-                    const unsigned long long em = __ballot(li == -1);
-                    if (em) {
-                        pos = __ffsll((long long)em) - 1;
-                    } else {
-                        unsigned best = 0;
-                        for (unsigned long long e2 = eq; e2; e2 &= e2 - 1) {
-                            const int b = __ffsll((long long)e2) - 1;
-                            const unsigned ib = (unsigned)rl32(li, b);
-                            if (ib >= best) { best = ib; pos = b; }
-                        }
-                    }
-                }
-                if (ca == tb && (unsigned)cj > (unsigned)rl32(li, pos)) continue;   // equal |value|: smaller index wins
-                if (lane == pos) { lv = cv; li = cj; }
-                if (h) { Lv[2 * r + 1] = lv; Li[2 * r + 1] = li; } else { Lv[2 * r] = lv; Li[2 * r] = li; }
-                const float nb = __uint_as_float(wave_min_u32(__float_as_uint(fabsf(lv))));
-                if ((lane >= 32) == h) thr[r] = nb;
+            const unsigned long long m = __ballot(jv && fabsf(v) >= thr[r]);
+#ifdef D_NOINSERT
+            if (m == 0x123456789abcull) out_val[1] = 1.f;
+#else
+            if (m) {
+                insert(Lv[2 * r], Li[2 * r], thr[r], (unsigned)m, 0, v, c0, false);
+                insert(Lv[2 * r + 1], Li[2 * r + 1], thr[r], (unsigned)(m >> 32), 32, v, c0, true);
             }
+#endif
         }
     };
 
-    const int n_tiles = (s_hi - s_lo + D_TILE - 1) / D_TILE;
-    const int n_groups = (n_tiles + D_GROUP - 1) / D_GROUP;
-#pragma unroll
-    for (int t = 0; t < D_GROUP; t++) fetch(0, t, s_lo + t * D_TILE);
+    const int n_groups = ((s_hi - s_lo + D_TILE - 1) / D_TILE + D_GROUP - 1) / D_GROUP;
+    fetch(0, 0, s_lo);
+    fetch(0, 1, s_lo);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the LDS-direct loads have landed
     __syncthreads();
-    for (int g = 0; g < n_groups; g++) {
+    f32x16 acc0, acc1;
+    bool pend = false;    // acc0/acc1 hold a multiplied pair that is not ranked yet (tiles at pend_c0, pend_c0 + 32)
+    int pend_c0 = 0;
+    // one pass more than there are stages: the late waves rank their last pair in it
+    for (int g = 0; g <= n_groups; g++) {
         const int buf = g & 1;
         const bool more = g + 1 < n_groups;
-#pragma unroll
-        for (int t = 0; t < D_GROUP; t++) {
-            const int c0 = s_lo + (g * D_GROUP + t) * D_TILE;
-            // the same tile of the next stage, into the buffer that was last read before the previous barrier
-            if (more) fetch(buf ^ 1, t, c0 + D_GROUP * D_TILE);
-            if (c0 < s_hi) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[r] = 0.f;
-                const f32x4 *brow = (const f32x4 *)&Bs[buf][t * D_TILE + (lane & 31)][(lane >> 5) * (K / 2)];
-                f32x4 x = brow[0];
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-                for (int c = 0; c < K / 8; c++) {   // 4 k pairs per ds_read_b128, the next one in flight
-                    const f32x4 nx = brow[c + 1 < K / 8 ? c + 1 : c];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 0], x[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 1], x[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 2], x[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + 3], x[3], acc, 0, 0, 0);
-                    x = nx;
-                    // the next ds_read_b128 goes out behind the first of these MFMAs: the wait for this chunk's
-                    // operands (lgkmcnt(0): the LDS-direct loads make the compiler count conservatively) then sits
-                    // before the new read is issued, and that read has three MFMAs to land
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                }
+#pragma nounroll
+        for (int p = 0; p < D_GROUP / 2; p++) {
+            const int c0 = s_lo + (g * D_GROUP + 2 * p) * D_TILE;
+            // the next stage, into the buffer that was last read before the previous barrier
+            if (more) fetch(buf ^ 1, p, s_lo + (g + 1) * D_GROUP * D_TILE);
+#pragma nounroll
+            for (int sub = 0; sub < 2; sub++) {
+                if ((sub == 0) == late && pend) {
 #ifdef D_NORANK
-                { float sacc = 0.f;
+                    float sacc = 0.f;
 #pragma unroll
-                  for (int r = 0; r < 16; r++) sacc += acc[r];
-                  if (sacc == 123.456f) out_val[0] = sacc; }
+                    for (int r = 0; r < 16; r++) sacc += acc0[r] + acc1[r];
+                    if (sacc == 123.456f) out_val[0] = sacc;
 #else
-                rank_tile(acc, c0);
+                    rank_tile(acc0, pend_c0);
+                    rank_tile(acc1, pend_c0 + D_TILE);
 #endif
+                    pend = false;
+                }
+                if (sub == 0 && g < n_groups && c0 < s_hi) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+                    const f32x4 *b0 = (const f32x4 *)&Bs[buf][2 * p * D_TILE + (lane & 31)][(lane >> 5) * (K / 2)];
+                    const f32x4 *b1 = (const f32x4 *)&Bs[buf][(2 * p + 1) * D_TILE + (lane & 31)][(lane >> 5) * (K / 2)];
+                    f32x4 x0 = b0[0], x1 = b1[0];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int c = 0; c < K / 8; c++) {   // 4 k pairs per ds_read_b128 and tile
+                        const f32x4 n0 = b0[c + 1 < K / 8 ? c + 1 : c], n1 = b1[c + 1 < K / 8 ? c + 1 : c];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + i], x0[i], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + i], x1[i], acc1, 0, 0, 0);
+                        }
+                        x0 = n0; x1 = n1;
+                        // the next two ds_read_b128 go out behind the first of these MFMAs: the wait for this
+                        // chunk's operands (lgkmcnt(0): the LDS-direct loads make the compiler count
+                        // conservatively) then sits before the new reads are issued, and they have 7 MFMAs to land
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+                    }
+                    pend = true;
+                    pend_c0 = c0;
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
     }
-    // write every row's list sorted by (|v| desc, idx asc): rank by counting, lane per entry
+    // the lists are sorted: entry p of a row goes to position p
 #pragma unroll
     for (int q = 0; q < 32; q++) {
         const int r = q >> 1, h = q & 1;
         const int gi = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (gi < n_t) {
-            const float v = Lv[q];
-            const int id = Li[q];
-            const bool valid = id >= 0;
-            const int cnt = __popcll(__ballot(valid));
-            const unsigned long long key = valid ? d_key(v, id) : 0ull;
-            int rank = 0;
-            for (int o = 0; o < k; o++) {
-                const unsigned long long ok = ((unsigned long long)(unsigned)rl32((int)(key >> 32), o) << 32) |
-                                              (unsigned)rl32((int)(key & 0xffffffffull), o);
-                rank += (ok > key) ? 1 : 0;
-            }
+        if (gi < n_t && lane < k) {
             const size_t base = ((size_t)gi * n_pieces + piece) * k;
-            if (valid) { out_idx[base + rank] = id; out_val[base + rank] = v; }
-            if (lane >= cnt && lane < k) { out_idx[base + lane] = -1; out_val[base + lane] = 0.f; }
+            const bool valid = Li[q] >= 0;
+            out_idx[base + lane] = valid ? Li[q] : -1;
+            out_val[base + lane] = valid ? Lv[q] : 0.f;
         }
     }
     }   // segments
 #ifdef D_TRACE
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         unsigned long long *tr = (unsigned long long *)out_val;
-        tr[blockIdx.x * 4 + 0] = rt0; tr[blockIdx.x * 4 + 1] = wall_clock64(); tr[blockIdx.x * 4 + 2] = hw; tr[blockIdx.x * 4 + 3] = xcc;
+        const size_t o = ((size_t)blockIdx.x * D_WAVES + w) * 4;
+        tr[o + 0] = rt0; tr[o + 1] = wall_clock64(); tr[o + 2] = hw; tr[o + 3] = xcc;
     }
-#endif
-#ifdef D_CLOCK
-    if (blockIdx.x == 7 && threadIdx.x == 0)
-        printf("shader clocks %llu, 100 MHz ticks %llu -> %.0f MHz\n", __builtin_readcyclecounter() - clk0,
-               wall_clock64() - rt0, (double)(__builtin_readcyclecounter() - clk0) / (double)(wall_clock64() - rt0) * 100.0);
 #endif
 }
 
@@ -330,7 +330,7 @@ static void dense_layout(int n_t, int n_s, int &n_tiles, long long &share, int &
     if (n_tiles < 1) n_tiles = 1;
     const long long n_rb = (n_t + D_ROWS - 1) / D_ROWS;
     const long long total = n_rb * n_tiles;
-    share = (total + 2LL * cus - 1) / (2LL * cus);
+    share = (total + cus - 1) / cus;   // one workgroup per CU
     const long long cap = (n_tiles + D_MAXSPLIT - 3) / (D_MAXSPLIT - 2);   // at most D_MAXSPLIT pieces per row block
     if (share < cap) share = cap;
     if (share < 16) share = 16;
