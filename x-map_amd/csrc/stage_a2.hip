@@ -12,8 +12,8 @@
 //   k_hist / k_threshold / k_mark_heavy : rater-count histogram -> #items at least as heavy (bound on a row's
 //                                         distinct partners) and the set H of at most HMAX items with more
 //                                         than CH raters (dense ids)
-//   k_sort_profiles : per-user sort by weight, emits the rater records of every item (atomic cursors) and
-//                     W+_i = number of contributions of row i
+//   k_sort_profiles : per-user sort by weight (4 short profiles per wave)
+//   k_rater_records : the rater records of every item; W+_i = number of contributions of row i (k_plan2)
 //   k_plan2 / k_fill_units2 : light units (item, hash partition), heavy units (item in H, chunk of CH raters)
 //   k_pair_tri      : light rows; wave-private LDS hash table as in stage_a.hip, rater records instead of a
 //                     dependent row_ptr hop, prefix-only profile reads; appends kept pairs to a half-COO
@@ -83,57 +83,97 @@ __global__ __launch_bounds__(256) void k_mark_heavy(int I, const long long *iptr
 
 struct RaterRec { int e0; int pos_ge; float rating; int user; };   // 16 B: one rater of an item
 
-// one wave per user: private copy of the profile sorted heaviest first, (index | flag, rating) interleaved.
-// Profiles of up to 64 ratings (virtually all) are sorted in registers with a 64-lane bitonic network; longer ones
-// fall back to a serial insertion sort by lane 0 (ub_key is its scratch).
+// private copy of every profile sorted heaviest first, (index | flag, rating) interleaved.  One wave per 4 users:
+// profiles of up to 16 ratings (90 % at BASELINE configs[1]) are sorted four at a time, one per 16-lane group, by a
+// bitonic network cut off at the longest of the four (the xor-shuffles never leave a group); the others follow one
+// by one on the whole wave (network cut off at the profile's length), profiles above 64 ratings by a serial
+// insertion sort on lane 0 (ub_key is its scratch).
+__device__ __forceinline__ void sort_entry(const int *uitem, const float *urating, const long long *iptr,
+                                           const double *info, long long e, unsigned long long &key, int &px, int &py) {
+    const int it = uitem[e];
+    const float r = urating[e];
+    key = wkey((int)(iptr[it + 1] - iptr[it]), it);
+    const unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;   // rating >= item average
+    px = (int)((unsigned)it | ge);
+    py = __float_as_int(r);
+}
+
+// descending bitonic network over groups of `width` lanes (width a power of two <= 64, uniform); pos = lane in group
+__device__ __forceinline__ void bitonic_desc(int width, int pos, unsigned long long &key, int &px, int &py) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+        if (k2 <= width)
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned long long ok = __shfl_xor(key, j, 64);
+            const int ox = __shfl_xor(px, j, 64), oy = __shfl_xor(py, j, 64);
+            const bool desc = (pos & k2) == 0;
+            const bool lower = (pos & j) == 0;
+            const bool take_other = (lower == desc) ? (ok > key) : (ok < key);
+            if (take_other) { key = ok; px = ox; py = oy; }
+        }
+    }
+}
+
+__device__ __forceinline__ int pow2_at_least(int d) {
+    int w = 2;
+    while (w < d) w <<= 1;
+    return w;
+}
+
 __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long long *uptr, const int *uitem,
                                                        const float *urating, const long long *iptr, const double *info,
                                                        unsigned long long *ub_key, int2 *ub) {
-    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= U) return;
+    const long long u0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (u0 >= U) return;
     const int lane = lane_id();
-    const long long a = uptr[u], b = uptr[u + 1];
-    const int d = (int)(b - a);
-    if (d <= 64) {
-        unsigned long long key = 0ull;   // pads sort last
-        int px = 0, py = 0;
-        if (lane < d) {
-            const int it = uitem[a + lane];
-            const float r = urating[a + lane];
-            key = wkey((int)(iptr[it + 1] - iptr[it]), it);
-            const unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;   // rating >= item average
-            px = (int)((unsigned)it | ge);
-            py = __float_as_int(r);
-        }
+    const int g = lane >> 4, gl = lane & 15;
+    {   // the short profiles, one per 16-lane group
+        const long long u = u0 + g;
+        long long a = 0;
+        int d = 0;
+        if (u < U) { a = uptr[u]; d = (int)(uptr[u + 1] - a); }
+        const bool small = d <= 16;
+        int wmax = small ? d : 0;
 #pragma unroll
-        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-            for (int j = k2 >> 1; j > 0; j >>= 1) {
-                const unsigned long long ok = __shfl_xor(key, j, 64);
-                const int ox = __shfl_xor(px, j, 64), oy = __shfl_xor(py, j, 64);
-                const bool desc = (lane & k2) == 0;
-                const bool lower = (lane & j) == 0;
-                const bool take_other = (lower == desc) ? (ok > key) : (ok < key);
-                if (take_other) { key = ok; px = ox; py = oy; }
-            }
+        for (int m = 32; m >= 16; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m, 64));
+        wmax = rl32(wmax, 0);
+        if (wmax > 0) {
+            unsigned long long key = 0ull;   // pads sort last
+            int px = 0, py = 0;
+            if (small && gl < d) sort_entry(uitem, urating, iptr, info, a + gl, key, px, py);
+            bitonic_desc(pow2_at_least(wmax), gl, key, px, py);
+            if (small && gl < d) ub[a + gl] = make_int2(px, py);
         }
-        if (lane < d) ub[a + lane] = make_int2(px, py);
-        return;
     }
-    if (lane) return;
-    for (int p = 0; p < d; p++) {   // insertion sort by descending weight key
-        int it = uitem[a + p];
-        float r = urating[a + p];
-        unsigned long long key = wkey((int)(iptr[it + 1] - iptr[it]), it);
-        int q = p;
-        while (q > 0 && ub_key[a + q - 1] < key) {
-            ub_key[a + q] = ub_key[a + q - 1];
-            ub[a + q] = ub[a + q - 1];
-            q--;
+    for (int q = 0; q < 4; q++) {   // the longer ones on the whole wave
+        const long long u = u0 + q;
+        if (u >= U) break;
+        const long long a = uptr[u];
+        const int d = (int)(uptr[u + 1] - a);
+        if (d <= 16) continue;
+        if (d <= 64) {
+            unsigned long long key = 0ull;
+            int px = 0, py = 0;
+            if (lane < d) sort_entry(uitem, urating, iptr, info, a + lane, key, px, py);
+            bitonic_desc(pow2_at_least(d), lane, key, px, py);
+            if (lane < d) ub[a + lane] = make_int2(px, py);
+            continue;
         }
-        unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;
-        ub_key[a + q] = key;
-        ub[a + q] = make_int2((int)((unsigned)it | ge), __float_as_int(r));
+        if (lane) continue;
+        for (int p = 0; p < d; p++) {   // insertion sort by descending weight key
+            unsigned long long key;
+            int px, py;
+            sort_entry(uitem, urating, iptr, info, a + p, key, px, py);
+            int t = p;
+            while (t > 0 && ub_key[a + t - 1] < key) {
+                ub_key[a + t] = ub_key[a + t - 1];
+                ub[a + t] = ub[a + t - 1];
+                t--;
+            }
+            ub_key[a + t] = key;
+            ub[a + t] = make_int2(px, py);
+        }
     }
 }
 
@@ -611,7 +651,7 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
         XM_LAUNCH_CHECK();
     }
     if (R->n_users > 0) {
-        k_sort_profiles<<<dim3((unsigned)((R->n_users + 3) / 4)), dim3(256), 0, st>>>(
+        k_sort_profiles<<<dim3((unsigned)((R->n_users + 15) / 16)), dim3(256), 0, st>>>(
             R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->item_ptr, info,
             (unsigned long long *)ub_key, (int2 *)ub);
         XM_LAUNCH_CHECK();
