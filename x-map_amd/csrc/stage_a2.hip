@@ -86,14 +86,14 @@ struct RaterRec { int e0; int pos_ge; float rating; int user; };   // 16 B: one 
 // private copy of every profile sorted heaviest first, (index | flag, rating) interleaved.  One wave per 4 users:
 // profiles of up to 16 ratings (90 % at BASELINE configs[1]) are sorted four at a time, one per 16-lane group, by a
 // bitonic network cut off at the longest of the four (the xor-shuffles never leave a group); the others follow one
-// by one on the whole wave (network cut off at the profile's length), profiles above 64 ratings by a serial
-// insertion sort on lane 0 (ub_key is its scratch).
+// by one on the whole wave (network cut off at the profile's length), profiles above 64 ratings by counting ranks.
 __device__ __forceinline__ void sort_entry(const int *uitem, const float *urating, const long long *iptr,
                                            const double *info, long long e, unsigned long long &key, int &px, int &py) {
     const int it = uitem[e];
     const float r = urating[e];
-    key = wkey((int)(iptr[it + 1] - iptr[it]), it);
-    const unsigned ge = ((double)r >= info[(size_t)it * 4]) ? 0x80000000u : 0u;   // rating >= item average
+    const double2 an = *(const double2 *)(info + (size_t)it * 4), nn = *(const double2 *)(info + (size_t)it * 4 + 2);
+    key = wkey((int)nn.y, it);                                      // info[it] = (avg, norm, adjnorm, n): one 32-B record
+    const unsigned ge = ((double)r >= an.x) ? 0x80000000u : 0u;   // rating >= item average
     px = (int)((unsigned)it | ge);
     py = __float_as_int(r);
 }
@@ -115,6 +115,8 @@ __device__ __forceinline__ void bitonic_desc(int width, int pos, unsigned long l
     }
 }
 
+constexpr int SORT_LDS = 1024;   // keys of a long profile staged in LDS (8 KB per wave)
+
 __device__ __forceinline__ int pow2_at_least(int d) {
     int w = 2;
     while (w < d) w <<= 1;
@@ -124,6 +126,7 @@ __device__ __forceinline__ int pow2_at_least(int d) {
 __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long long *uptr, const int *uitem,
                                                        const float *urating, const long long *iptr, const double *info,
                                                        unsigned long long *ub_key, int2 *ub) {
+    __shared__ unsigned long long lkeys[4][SORT_LDS];
     const long long u0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     if (u0 >= U) return;
     const int lane = lane_id();
@@ -160,19 +163,23 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
             if (lane < d) ub[a + lane] = make_int2(px, py);
             continue;
         }
-        if (lane) continue;
-        for (int p = 0; p < d; p++) {   // insertion sort by descending weight key
+        // longer than a wave: rank by counting.  The keys (unique: one item once per profile) are staged in LDS
+        // (or, past SORT_LDS of them, in the ub_key scratch) and every entry counts the heavier ones.
+        unsigned long long *keys = d <= SORT_LDS ? lkeys[threadIdx.x >> 6] : ub_key + a;
+        for (int p = lane; p < d; p += 64) {
             unsigned long long key;
             int px, py;
             sort_entry(uitem, urating, iptr, info, a + p, key, px, py);
-            int t = p;
-            while (t > 0 && ub_key[a + t - 1] < key) {
-                ub_key[a + t] = ub_key[a + t - 1];
-                ub[a + t] = ub[a + t - 1];
-                t--;
-            }
-            ub_key[a + t] = key;
-            ub[a + t] = make_int2(px, py);
+            keys[p] = key;
+        }
+        __threadfence_block();
+        for (int p = lane; p < d; p += 64) {
+            unsigned long long key;
+            int px, py;
+            sort_entry(uitem, urating, iptr, info, a + p, key, px, py);
+            int rank = 0;
+            for (int o = 0; o < d; o++) rank += keys[o] > key;
+            ub[a + rank] = make_int2(px, py);
         }
     }
 }
