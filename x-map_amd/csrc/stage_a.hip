@@ -43,20 +43,67 @@ __global__ __launch_bounds__(256) void k_user_stats(long long U, const long long
 
 // CSC (item -> raters) from the CSR: count, scan, fill.  The order of an item's raters is whatever the cursor
 // atomics produce -- every consumer sums exactly (integer-valued or double-double), so no order is needed.
+// Popular items (8e4 raters at BASELINE configs[1]) would serialise that many atomics on one word, which is what
+// bounds a naive version (~90 same-address atomics per microsecond): every workgroup therefore first counts its
+// entries in a direct-mapped LDS cache of CSC_SLOTS (item, count) slots and goes to memory once per occupied slot;
+// entries whose slot is taken by another item use the global word directly.
+constexpr int CSC_SLOTS = 4096;
+constexpr int CSC_CHUNK = 8192;    // entries per workgroup of the count kernel
+constexpr int CSC_USERS = 512;     // users per workgroup of the fill kernel
+__device__ __forceinline__ int csc_slot(int it) { return (int)(mix32((uint32_t)it) & (CSC_SLOTS - 1)); }
+
 __global__ __launch_bounds__(256) void k_csc_count(long long nnz, const int *uitem, int *cnt) {
-    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz) atomicAdd(&cnt[uitem[e]], 1);
+    __shared__ int tag[CSC_SLOTS], loc[CSC_SLOTS];
+    for (int t = threadIdx.x; t < CSC_SLOTS; t += 256) { tag[t] = -1; loc[t] = 0; }
+    __syncthreads();
+    const long long e0 = (long long)blockIdx.x * CSC_CHUNK;
+    for (int q = threadIdx.x; q < CSC_CHUNK; q += 256) {
+        const long long e = e0 + q;
+        if (e >= nnz) break;
+        const int it = uitem[e];
+        const int sl = csc_slot(it);
+        const int old = atomicCAS(&tag[sl], -1, it);
+        if (old == -1 || old == it) atomicAdd(&loc[sl], 1); else atomicAdd(&cnt[it], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CSC_SLOTS; t += 256)
+        if (loc[t]) atomicAdd(&cnt[tag[t]], loc[t]);
 }
+
+// wave per user (the rater id is the user), CSC_USERS users per workgroup
 __global__ __launch_bounds__(256) void k_csc_fill(long long U, const long long *uptr, const int *uitem, const float *urating,
                                                   const long long *iptr, int *cur, int *iuser, float *irating) {
-    long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= U) return;
-    for (long long e = uptr[u] + lane_id(); e < uptr[u + 1]; e += 64) {
-        const int it = uitem[e];
-        const long long p = iptr[it] + atomicAdd(&cur[it], 1);
-        iuser[p] = (int)u;
-        irating[p] = urating[e];
+    __shared__ int tag[CSC_SLOTS], loc[CSC_SLOTS], base[CSC_SLOTS];
+    for (int t = threadIdx.x; t < CSC_SLOTS; t += 256) { tag[t] = -1; loc[t] = 0; }
+    __syncthreads();
+    const long long u0 = (long long)blockIdx.x * CSC_USERS;
+    const long long u1 = min(U, u0 + CSC_USERS);
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    // pass 1: claim slots, count this workgroup's entries per cached item
+    for (long long u = u0 + w; u < u1; u += 4)
+        for (long long e = uptr[u] + lane; e < uptr[u + 1]; e += 64) {
+            const int it = uitem[e];
+            const int sl = csc_slot(it);
+            const int old = atomicCAS(&tag[sl], -1, it);
+            if (old == -1 || old == it) atomicAdd(&loc[sl], 1);
+        }
+    __syncthreads();
+    // pass 2: one range of the item's segment per occupied slot
+    for (int t = threadIdx.x; t < CSC_SLOTS; t += 256) {
+        if (loc[t]) base[t] = atomicAdd(&cur[tag[t]], loc[t]);
+        loc[t] = 0;
     }
+    __syncthreads();
+    // pass 3: positions inside the reserved ranges (LDS counter), or straight from the global cursor
+    for (long long u = u0 + w; u < u1; u += 4)
+        for (long long e = uptr[u] + lane; e < uptr[u + 1]; e += 64) {
+            const int it = uitem[e];
+            const int sl = csc_slot(it);
+            const int off = (tag[sl] == it) ? base[sl] + atomicAdd(&loc[sl], 1) : atomicAdd(&cur[it], 1);
+            const long long p = iptr[it] + off;
+            iuser[p] = (int)u;
+            irating[p] = urating[e];
+        }
 }
 
 // one wave per item: lane-strided partial sums, fixed butterfly reduction (deterministic)
@@ -67,12 +114,50 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
     int lane = lane_id();
     long long p0 = iptr[i], p1 = iptr[i + 1];
     double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
-    for (long long p = p0 + lane; p < p1; p += 64) {
-        double r = (double)irating[p];
-        double d = r - u_avg[iuser[p]];
-        s += r;
-        q += r * r;
-        dd_add(a2, a2lo, d * d);   // exact sum of the fp64 squares (order-independent)
+    if (p1 - p0 <= 64 * 8) {
+        for (long long p = p0 + lane; p < p1; p += 64) {
+            double r = (double)irating[p];
+            double d = r - u_avg[iuser[p]];
+            s += r;
+            q += r * r;
+            dd_add(a2, a2lo, d * d);   // exact sum of the fp64 squares (order-independent)
+        }
+    } else {
+        // popular items (up to 1e5 raters): 8 independent accumulators keep 8 gathers in flight per lane instead of
+        // a chain of 1300 dependent round trips; the partials are merged exactly below
+        constexpr int UN = 8;
+        double su[UN], qu[UN], ah[UN], al[UN];
+#pragma unroll
+        for (int t = 0; t < UN; t++) { su[t] = 0.0; qu[t] = 0.0; ah[t] = 0.0; al[t] = 0.0; }
+        for (long long p = p0 + lane; p < p1; p += 64 * UN) {
+            float rr[UN];
+            int uu[UN];
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                const long long pp = p + 64 * t;
+                rr[t] = pp < p1 ? irating[pp] : 0.f;
+                uu[t] = pp < p1 ? iuser[pp] : -1;
+            }
+            double av[UN];
+#pragma unroll
+            for (int t = 0; t < UN; t++) av[t] = uu[t] >= 0 ? u_avg[uu[t]] : 0.0;
+#pragma unroll
+            for (int t = 0; t < UN; t++) {
+                if (uu[t] < 0) continue;
+                const double r = (double)rr[t];
+                const double d = r - av[t];
+                su[t] += r;
+                qu[t] += r * r;
+                dd_add(ah[t], al[t], d * d);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < UN; t++) {
+            s += su[t];
+            q += qu[t];
+            dd_add(a2, a2lo, ah[t]);
+            dd_add(a2, a2lo, al[t]);
+        }
     }
     s = wave_sum(s);
     q = wave_sum(q);
@@ -383,14 +468,14 @@ int xmap_build_csc(void *stream, int64_t n_users, int32_t n_items, int64_t nnz, 
     hipStream_t st = (hipStream_t)stream;
     XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
     if (nnz > 0) {
-        k_csc_count<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st>>>(nnz, user_item, cnt);
+        k_csc_count<<<dim3((unsigned)((nnz + CSC_CHUNK - 1) / CSC_CHUNK)), dim3(256), 0, st>>>(nnz, user_item, cnt);
         XM_LAUNCH_CHECK();
     }
     int rc = xmap_exclusive_scan_i32_to_i64(stream, cnt, item_ptr, n_items, nullptr);
     if (rc) return rc;
     XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
     if (nnz > 0) {
-        k_csc_fill<<<dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st>>>(
+        k_csc_fill<<<dim3((unsigned)((n_users + CSC_USERS - 1) / CSC_USERS)), dim3(256), 0, st>>>(
             n_users, (const long long *)user_ptr, user_item, user_rating, (const long long *)item_ptr, cnt, item_user,
             item_rating);
         XM_LAUNCH_CHECK();
