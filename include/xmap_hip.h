@@ -78,10 +78,11 @@ int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *
 /* BaselinerSim.get_universal_item_info (core/baselinerSim.py:40-82): info[i] = (avg, norm2, adjnorm2, n).
  * Also emits the stage-A private copies of the index arrays with bit 31 = (rating >= item avg), which is
  * all retrieve_path_info (core/baselinerSim.py:97-113) needs per co-rating:
- *   ua_item[e] = user_item[e] | ge<<31,  ia_user[p] = item_user[p] | ge<<31. */
+ *   ua_item[e] = user_item[e] | ge<<31,  ia_user[p] = item_user[p] | ge<<31.
+ * Only the complete-rows formulation (xmap_sim_count / xmap_sim_fill) reads them: pass both NULL to skip them. */
 int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info /*[I][4]*/,
                     double *norms /*[2][I] dense copies of norm2 / adjnorm2, may be NULL*/,
-                    int32_t *ua_item /*[nnz]*/, int32_t *ia_user /*[nnz]*/);
+                    int32_t *ua_item /*[nnz] or NULL*/, int32_t *ia_user /*[nnz] or NULL*/);
 
 /* Work decomposition for the pair kernel: unit = (item i, hash partition q of its partner space),
  * Q[i] = ceil(min(W_i, I-1) / slot_target), W_i = sum over raters of (profile length - 1).

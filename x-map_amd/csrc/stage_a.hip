@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
             norms[(size_t)I + i] = sqrt(a2);
         }
     }
+    if (!ia_user) return;   // the flag-packed copies are read by the complete-rows formulation only
     for (long long p = p0 + lane; p < p1; p += 64) {
         unsigned ge = ((double)irating[p] >= avg) ? 0x80000000u : 0u;
         ia_user[p] = (int)((unsigned)iuser[p] | ge);
@@ -495,7 +496,7 @@ int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *
 
 int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info, double *norms,
                     int32_t *ua_item, int32_t *ia_user) {
-    XM_ARG(R && u_avg && info && ua_item && ia_user);
+    XM_ARG(R && u_avg && info && ((ua_item != nullptr) == (ia_user != nullptr)));
     XM_ARG(R->nnz < 0x7fffffffLL);
     hipStream_t st = (hipStream_t)stream;
     if (R->n_items > 0) {
@@ -503,7 +504,7 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
             R->n_items, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, norms, ia_user);
         XM_LAUNCH_CHECK();
     }
-    if (R->nnz > 0) {
+    if (R->nnz > 0 && ua_item) {
         k_pack_user_side<<<dim3((unsigned)((R->nnz + 255) / 256)), dim3(256), 0, st>>>(
             R->nnz, R->user_item, R->user_rating, info, ua_item);
         XM_LAUNCH_CHECK();

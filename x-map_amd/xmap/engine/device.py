@@ -137,8 +137,9 @@ class Engine(object):
                                      vp(R.user_rating), vp(cnt), vp(R.item_ptr), vp(R.item_user), vp(R.item_rating)))
         R.csc_ready = True
 
-    def stats(self):
-        """A2 + A3: CSC layout, user info, item info and the flag-packed index copies."""
+    def stats(self, packed=False):
+        """A2 + A3: CSC layout, user info, item info and (packed=True: the complete-rows formulation needs them)
+        the flag-packed index copies."""
         R = self.R
         st = _stream(self.dev)
         self.build_csc()
@@ -147,8 +148,8 @@ class Engine(object):
         check(lib.xmap_user_stats(st, C.byref(R.c), vp(u_avg), vp(u_norm)))
         info = self._zeros((max(R.n_items, 1), 4), torch.float64)
         self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
-        ua_item = self._empty(max(R.nnz, 1), torch.int32)
-        ia_user = self._empty(max(R.nnz, 1), torch.int32)
+        ua_item = self._empty(max(R.nnz, 1), torch.int32) if packed else None
+        ia_user = self._empty(max(R.nnz, 1), torch.int32) if packed else None
         check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user)))
         return u_avg, u_norm, info, ua_item, ia_user
 
@@ -186,9 +187,9 @@ class Engine(object):
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
-        if stats is None:
+        if stats is None or stats[3] is None:
             with self.timed("stats"):
-                stats = self.stats()
+                stats = self.stats(packed=True)
         u_avg, u_norm, info, ua_item, ia_user = stats
         I = R.n_items
         while True:
