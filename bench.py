@@ -68,6 +68,12 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4):
     t0 = time.time()
     S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, rows))
     dt = time.time() - t0
+    if dt < 0.5 * target_s and rows < I:      # the low rows are the cheap ones: take the whole stage when it is short
+        xo.sim_free(S)
+        rows = I
+        t0 = time.time()
+        S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, rows))
+        dt = time.time() - t0
     out = dict(value=S.n_eval / dt, unit="pairs/s", cores=threads, kind="port",
                sample="oracle stage A (item-item sim) on item rows [0,%d) of %d: %d pairs in %.1f s, OpenMP %d threads"
                       % (rows, I, S.n_eval, dt, threads))
@@ -219,13 +225,15 @@ def main():
 
     if rank == 0:
         D, Dk, P, nnz, I = res["n_eval"], res["n_kept"], res["n_contrib"], r.nnz, r.n_items
-        # Stage-A dominant kernel: k_pair_tri (one launch per step).  Algorithmic bytes per launch (SURVEY.md 8d,
+        # Stage-A dominant kernel: k_pair_tri (one logical pass per step: one launch per LDS table class).  Algorithmic bytes per launch (SURVEY.md 8d,
         # DESIGN.md 4): 8 B per directed co-rating contribution it processes + CSR and rater records read once
         # (16 B per rating) + item stats (32 B per item) + the kept pairs it emits (24 B per unordered pair).
         tri_ms = float(np.mean(tm.get("pair_tri", [0.0])))
         bytes_tri = 8.0 * res["n_contrib_light"] + 16.0 * nnz + 32.0 * I + 12.0 * res["n_kept_local"]
         ach = bytes_tri / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
-        # Stage-B dominant kernel: k_paths.  Compulsory HBM bytes are the knn tables + the outputs (SURVEY.md 8d:
+        # SURVEY.md 8d states the whole-stage figure too: B_A = 8 P + 16 nnz + 32 I + 20 D' over t_A
+        bytes_a = 8.0 * P + 16.0 * nnz + 32.0 * I + 20.0 * Dk
+        # Stage-B dominant kernel: k_paths2.  Compulsory HBM bytes are the knn tables + the outputs (SURVEY.md 8d:
         # 12 E + 12 N_out); it is latency / random-access bound, paths/s is the figure of merit.
         paths_ms = float(np.mean(tm.get("paths", [0.0])))
         bytes_paths = 12.0 * res["knn_entries"] + 12.0 * res["n_out"]
@@ -244,11 +252,14 @@ def main():
             "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
             "roofline": {"bound": "hbm", "kernel": "k_pair_tri", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_pair_tri"),
-                         "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms},
-            "roofline_stage_b": {"bound": "hbm", "kernel": "k_paths", "achieved": bytes_paths / (paths_ms * 1e-3) / 1e9
+                         "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms,
+                         "stage_a_whole": {"algorithmic_bytes": bytes_a, "ms": stage["stage_a"],
+                                           "achieved": bytes_a / t_a / 1e9 if t_a > 0 else 0.0,
+                                           "frac": bytes_a / t_a / 1e9 / HBM_PEAK_GBS if t_a > 0 else 0.0}},
+            "roofline_stage_b": {"bound": "hbm", "kernel": "k_paths2", "achieved": bytes_paths / (paths_ms * 1e-3) / 1e9
                                  if paths_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (bytes_paths / (paths_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if paths_ms > 0 else 0.0,
-                                 "traffic": pmc_traffic("k_paths"), "algorithmic_bytes_per_launch": bytes_paths,
+                                 "traffic": pmc_traffic("k_paths2"), "algorithmic_bytes_per_launch": bytes_paths,
                                  "launch_ms": paths_ms, "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
                                  "note": "latency/random-access bound: 32 B double-double read-modify-write per path"},
         }
