@@ -1,6 +1,7 @@
 """HBM bytes per launch from two rocprofv3 PMC passes -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic).
 
-    python profiles/make_pmc_traffic.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <tag>
+    python profiles/make_pmc_traffic.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <tag> \
+           [<dense FETCH_SIZE csv> <dense WRITE_SIZE csv>]      (passes of `bench.py --workload dense`)
 
 The passes are `rocprofv3 --pmc FETCH_SIZE ...` and `rocprofv3 --pmc WRITE_SIZE ...` of `python3 bench.py --steps 1
 --warmup 0 --no-cpu` (separate runs, one row per dispatch).  Counter values are KiB.  gfx950 correction
@@ -25,8 +26,11 @@ def per_kernel(path, counter):
     return acc
 
 
-def main(fetch_csv, write_csv, tag):
+def main(fetch_csv, write_csv, tag, dense_fetch=None, dense_write=None):
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    if dense_fetch:
+        f.update(per_kernel(dense_fetch, "FETCH_SIZE"))
+        w.update(per_kernel(dense_write, "WRITE_SIZE"))
     raw = {k: {"FETCH_SIZE_bytes": f.get(k, 0.0), "WRITE_SIZE_bytes": w.get(k, 0.0)} for k in sorted(set(f) | set(w))
            if k.startswith("k_")}
     tot = lambda pred: sum(2.0 * v["FETCH_SIZE_bytes"] + v["WRITE_SIZE_bytes"] for k, v in raw.items() if pred(k))
@@ -51,4 +55,4 @@ def main(fetch_csv, write_csv, tag):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])

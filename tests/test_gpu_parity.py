@@ -200,6 +200,41 @@ def test_edge_cases(dev):
     assert int(E.bb.sum()) == 0 and E.n_out == 0
 
 
+@pytest.mark.parametrize("method", METHODS)
+def test_long_profiles_and_popular_items(dev, method):
+    """Profiles of up to 1100 ratings (all three profile-sort paths: packed 16-lane groups, one wave, counted ranks
+    through LDS and through the scratch array) and items rated by most users (LDS-privatised CSC build, heavy rows)."""
+    from oracle import xmap_oracle as xo
+    from xmap.engine import synth
+    r = synth.make_two_domain(21, 600, 1500, 1500, overlap=0.5, mu=4.0, sigma=1.6)
+    d = np.diff(r.user_ptr)
+    assert d.max() > 1024 and (d > 64).sum() > 100 and (d <= 16).sum() > 10
+    attrs = r.item_attrs()
+    eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs)
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
+    So = xo.item_sim(T, method, CAP, nthreads=8)
+    orow, ocol = csr_to_pairs(So.row_ptr, So.col)
+    for S in (eng.item_sim(method, CAP), eng.item_sim_tri(method, CAP, ch_min=64), eng.item_sim(method, CAP, algo="rows")):
+        assert S.n_eval == So.n_eval and S.n_contrib == So.n_contrib
+        rows, cols, sim, mutu, nij = _sorted_sim(S)
+        assert np.array_equal(rows, orow) and np.array_equal(cols, ocol)
+        assert np.array_equal(mutu, So.mutu) and np.array_equal(nij, So.nij)
+        assert np.array_equal(S.info.cpu().numpy(), So.info)
+        assert np.array_equal(sim, So.sim)
+    # the on-device CSC is a permutation of the ratings grouped by item
+    R = eng.R
+    ip = R.item_ptr.cpu().numpy()
+    assert np.array_equal(np.diff(ip), np.bincount(r.item, minlength=r.n_items))
+    iu, ir = R.item_user.cpu().numpy(), R.item_rating.cpu().numpy()
+    users = np.repeat(np.arange(r.n_users), d)
+    o = np.lexsort((users, r.item))
+    for i in (0, int(np.argmax(np.diff(ip))), r.n_items - 1):
+        a, b = ip[i], ip[i + 1]
+        q = np.argsort(iu[a:b])
+        assert np.array_equal(iu[a:b][q], users[o][a:b]) and np.array_equal(ir[a:b][q], r.rating[o][a:b])
+    xo.sim_free(So)
+
+
 def test_determinism_and_partitions(dev):
     """two runs give identical bytes; the result does not depend on the table partitioning."""
     from xmap.engine import synth

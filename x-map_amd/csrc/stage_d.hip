@@ -3,7 +3,7 @@
 // (n_t x K) x (K x n_s) contraction on the fp32 matrix cores with the per-row top-k fused behind it, so the
 // n_t x n_s similarity matrix (1.6e11 B at 200k x 200k) never exists in memory.
 //
-//   k_dense_normalize : Fn = F / ||F||  (norm in fp64, k order), one thread per row
+//   k_dense_normalize : Fn = F / ||F||  (norm in fp64, k order), rows staged through LDS
 //   k_dense_topk      : one workgroup of 8 waves = 256 target rows per CU, two waves per SIMD.  Wave w keeps the A
 //                       fragments of its 32 rows for the whole K in registers (K/2 VGPRs); the source items stream
 //                       through a double-buffered LDS stage of 4 x 32 rows, filled by LDS-direct global loads
@@ -36,14 +36,27 @@ constexpr int D_TILE = 32;       // source items per MFMA tile
 constexpr int D_GROUP = 4;       // tiles per LDS stage (one barrier per stage), multiplied in pairs
 constexpr int D_TOPK = 64;       // list capacity per row (k <= 64: one lane per entry)
 
-__global__ __launch_bounds__(256) void k_dense_normalize(int n, int K, const float *F, float *Fn) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double q = 0.0;
-    for (int k = 0; k < K; k++) { double x = (double)F[(size_t)i * K + k]; q += x * x; }
-    const double nrm = sqrt(q);
-    for (int k = 0; k < K; k++)
-        Fn[(size_t)i * K + k] = (nrm > 0.0) ? (float)((double)F[(size_t)i * K + k] / nrm) : 0.f;
+// 64 rows per workgroup: coalesced load into LDS, one thread per row sums the squares in k order (fp64; the order is
+// part of the definition the oracle pins), coalesced write of the quotients
+constexpr int DN_ROWS = 64;
+template <int K>
+__global__ __launch_bounds__(256) void k_dense_normalize(int n, const float *F, float *Fn) {
+    __shared__ float T[DN_ROWS][K + 1];
+    __shared__ double nrm[DN_ROWS];
+    const int r0 = blockIdx.x * DN_ROWS;
+    const int rows = min(DN_ROWS, n - r0);
+    for (int e = threadIdx.x; e < rows * K; e += 256) T[e / K][e % K] = F[(size_t)r0 * K + e];
+    __syncthreads();
+    if (threadIdx.x < rows) {
+        double q = 0.0;
+        for (int k = 0; k < K; k++) { const double x = (double)T[threadIdx.x][k]; q += x * x; }
+        nrm[threadIdx.x] = sqrt(q);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * K; e += 256) {
+        const double d = nrm[e / K];
+        Fn[(size_t)r0 * K + e] = (d > 0.0) ? (float)((double)T[e / K][e % K] / d) : 0.f;
+    }
 }
 
 // (|v|, idx) order packed in one word: larger key = better candidate (|v| desc, then idx asc)
@@ -314,9 +327,15 @@ using namespace xmap;
 extern "C" {
 
 int xmap_dense_normalize(void *stream, int32_t n, int32_t dim, const float *F, float *Fn) {
-    XM_ARG(F && Fn && n >= 0 && dim > 0);
+    XM_ARG(F && Fn && n >= 0);
+    if (dim != 128 && dim != 64) {
+        set_error("dense variant: factor dimension %d not built (64 and 128 are)", dim);
+        return XMAP_ERR_ARG;
+    }
     if (n == 0) return XMAP_OK;
-    k_dense_normalize<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(n, dim, F, Fn);
+    dim3 grid((unsigned)((n + DN_ROWS - 1) / DN_ROWS)), block(256);
+    if (dim == 128) k_dense_normalize<128><<<grid, block, 0, (hipStream_t)stream>>>(n, F, Fn);
+    else k_dense_normalize<64><<<grid, block, 0, (hipStream_t)stream>>>(n, F, Fn);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
