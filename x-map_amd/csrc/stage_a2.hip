@@ -33,6 +33,10 @@ constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr int SMALL_BOUND = 96;          // rows with at most this many partners use the 128-slot table
 constexpr int MID_BOUND = 384;           // ... at most this many: the 512-slot table
 
+constexpr int N_CLASSES = 4;
+// table class (1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024) -> position in the class-major unit list
+__host__ __device__ __forceinline__ int class_rank(int cls) { return cls == 0 ? 0 : (cls == 2 ? 1 : (cls == 3 ? 2 : 3)); }
+
 __device__ __forceinline__ unsigned long long wkey(int n, int item) {
     return ((unsigned long long)(unsigned)n << 32) | (unsigned)item;
 }
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, con
 // light rows: Q partitions; heavy rows (in H): chunks of CH raters.  One wave per item sums W+ = the prefix lengths.
 __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const RaterRec *rc, const long long *pre,
                                                int HB, const int *hid, const int *CH, int target, int *Q, int *C,
-                                               uint8_t *small, unsigned long long *Wp) {
+                                               uint8_t *small, unsigned long long *Wp, int *Qcat) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
     const int lane = lane_id();
@@ -236,16 +240,22 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     Q[i] = q;
     C[i] = c;
     // table class: 1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024
-    small[i] = (q != 1) ? 0 : (bound <= SMALL_BOUND ? 1 : (bound <= 2 * SMALL_BOUND ? 3 : (bound <= MID_BOUND ? 2 : 0)));
+    const int cls = (q != 1) ? 0 : (bound <= SMALL_BOUND ? 1 : (bound <= 2 * SMALL_BOUND ? 3 : (bound <= MID_BOUND ? 2 : 0)));
+    small[i] = (uint8_t)cls;
     Wp[i] = (unsigned long long)w;
+    // the light units are listed class-major (largest tables first: their units run longest), so that each table
+    // class is one contiguous range of units: Qcat[rank][i] (zero-initialised) is what the unit scan runs over
+    Qcat[(size_t)class_rank(cls) * I + i] = q;
 }
 
-__global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Q, const long long *uq_ptr, int *uq_item, int *uq_q,
+__global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Qcat, const long long *uq_ptr, int *uq_item, int *uq_q,
                                                      const int *C, const long long *uc_ptr, int *uc_item, int *uc_c) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= I) return;
-    long long b = uq_ptr[i];
-    for (int k = 0; k < Q[i]; k++) { uq_item[b + k] = i; uq_q[b + k] = k; }
+    const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (long long)N_CLASSES * I) return;
+    const int i = (int)(x % I);
+    long long b = uq_ptr[x];
+    for (int k = 0; k < Qcat[x]; k++) { uq_item[b + k] = i; uq_q[b + k] = k; }
+    if (x >= I) return;
     b = uc_ptr[i];
     for (int k = 0; k < C[i]; k++) { uc_item[b + k] = i; uc_c[b + k] = k; }
 }
@@ -295,11 +305,11 @@ constexpr int HEAVY_SHARDS = 64;
 // finalise(s, j, n, m, sim, occupied) -> keep.  Pass 1 finalises every slot once (the result is parked by `park`),
 // pass 2 writes the kept ones.
 template <typename Fin, typename Park, typename Get>
-__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slots, Fin fin, Park park, Get get) {
+__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begin, int n_slots, Fin fin, Park park, Get get) {
     const int lane = lane_id();
-    const int shard = blockIdx.x & (COO_SHARDS - 1);
+    const int shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (COO_SHARDS - 1);
     int kept = 0, occ = 0;
-    for (int s0 = 0; s0 < n_slots; s0 += 64) {
+    for (int s0 = s_begin; s0 < n_slots; s0 += 64) {
         int j, n, m; double sv; bool o;
         bool keep = fin(s0 + lane, j, n, m, sv, o);
         park(s0 + lane, o, keep, sv);
@@ -319,7 +329,7 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int n_slot
         return;
     }
     base += (unsigned long long)shard * (unsigned long long)A.shard_cap;
-    for (int s0 = 0; s0 < n_slots; s0 += 64) {
+    for (int s0 = s_begin; s0 < n_slots; s0 += 64) {
         int j, n, m; double sv;
         bool keep = get(s0 + lane, j, n, m, sv);
         unsigned long long km = __ballot(keep);
@@ -342,37 +352,49 @@ __global__ __launch_bounds__(256) void k_fold_heavy(int n_heavy, const int *hlis
     if (t) atomicAdd(&rowcnt[hlist[h]], t);
 }
 
-// Light rows.  Eight raters are processed per step (8 lanes each): profile prefixes are short (half a
+// Light rows.  Eight raters are processed per wave and step (8 lanes each): profile prefixes are short (half a
 // profile on average), so one rater per step would leave most lanes idle and only one dependent load in
 // flight.  Lanes of different raters may meet on one partner: the counters use LDS atomics, the fp64 sum is
 // either an LDS atomic add (cosine: integer-exact, order irrelevant) or, for the double-double sum of
-// adjusted cosine, serialised per slot through a claim word (conflicts are rare).
+// adjusted cosine, serialised per slot (conflicts are rare): through a claim word inside one wave, through a lock
+// word when several waves share the table.
 constexpr int GRP = 8;                  // lanes per rater
-constexpr int NGRP = 64 / GRP;          // raters per step
+constexpr int NGRP = 64 / GRP;          // raters per wave and step
 
 // The table size is a template parameter: rows whose partner bound is <= SMALL_BOUND (the vast majority: items
 // with a handful of raters) run with 128 slots (3.5 KB of LDS, full occupancy, 8x cheaper init/finalise), rows up
-// to MID_BOUND with 512, the others with 1024.  Every launch covers all light units; a block whose row is of
-// another class exits at once.
-
-template <int METHOD, int LOG_SLOTS>
-__global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
+// to 2 SMALL_BOUND with 256, up to MID_BOUND with 512, the others with 1024.  The units are listed class-major, one
+// launch per class.  The big tables are few per CU (5 of 1024 slots fit in LDS) and their rows have the most
+// raters (158 on average at BASELINE configs[1], against 6 in the smallest class): NW waves share one table there
+// (4 for 1024 slots, 2 for 512), each taking every NW-th block of 64 raters, which keeps 20 waves per CU in flight
+// instead of 5.
+template <int METHOD, int LOG_SLOTS, int NW>
+__global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     constexpr int SLOTS_ = 1 << LOG_SLOTS;
+    constexpr bool ADJ = METHOD == XMAP_ADJUST_COSINE;
     __shared__ uint32_t key[SLOTS_];
     __shared__ unsigned long long cm[SLOTS_];     // n_ij (low 32) | mutuality (high 32)
     __shared__ double dot[SLOTS_];
-    __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? SLOTS_ : 1];
-    __shared__ unsigned short claim[METHOD == XMAP_ADJUST_COSINE ? SLOTS_ : 1];
+    __shared__ double dlo[ADJ ? SLOTS_ : 1];
+    __shared__ unsigned short claim[ADJ && NW == 1 ? SLOTS_ : 1];
+    __shared__ unsigned lockw[ADJ && NW > 1 ? SLOTS_ : 1];
+    __shared__ int s_ovf;
 
     const int lane = lane_id();
     const long long unit = A.unit_lo + blockIdx.x;
     if (unit >= A.unit_hi) return;
     const int i = uniform(A.uq_item[unit]);
     const int tcls = A.small[i];   // 1: 128 slots, 3: 256, 2: 512, 0: 1024
-    if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : 0)))) return;
-    for (int s = lane; s < SLOTS_; s += 64) {
+    if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : 0)))) return;   // not reached: class-major units
+    const int w = threadIdx.x >> 6;
+    for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
         key[s] = T_EMPTY; cm[s] = 0ull; dot[s] = 0.0;
-        if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
+        if (ADJ) dlo[s] = 0.0;
+        if (ADJ && NW > 1) lockw[s] = 0u;
+    }
+    if (NW > 1) {
+        if (threadIdx.x == 0) s_ovf = 0;
+        __syncthreads();
     }
     const int q = uniform(A.uq_q[unit]);
     const int Qi = uniform(A.Q[i]);
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
     const int p1 = uniform((int)A.iptr[i + 1]);
     const int g = lane / GRP, sub = lane % GRP;
     int ovf = 0;
-    for (int base = p0; base < p1; base += 64) {
+    for (int base = p0 + 64 * w; base < p1; base += 64 * NW) {
         const int p = base + lane;
         int e0 = 0, pw = 0;
         float r = 0.f;
@@ -435,31 +457,49 @@ __global__ __launch_bounds__(64) void k_pair_tri(TriArgs A) {
                     atomicAdd(&cm[h], inc);
                     if (METHOD == XMAP_COSINE) atomicAdd(&dot[h], (1.0 * ri) * (double)rj);   // integer-exact
                 }
-                if (METHOD == XMAP_ADJUST_COSINE) {
+                if (ADJ) {
                     const double term = (ri - a) * ((double)rj - a);
-                    // volatile: the claim word and the sums are shared between LANES of this wave; the compiler
-                    // must neither forward the claim store to the load nor hoist the sum loads out of the loop
-                    volatile unsigned short *vclaim = claim;
+                    // volatile: the sums are shared between lanes (and waves); the compiler must neither forward the
+                    // claim / lock store to the load nor hoist the sum loads out of the loop
                     volatile double *vhi = dot, *vlo = dlo;
                     bool pending = act;
-                    while (__ballot(pending)) {       // lanes that share a slot take turns
-                        if (pending) vclaim[h] = (unsigned short)lane;
-                        if (pending && vclaim[h] == (unsigned short)lane) {
-                            double hi = vhi[h], lo = vlo[h];
-                            dd_add(hi, lo, term);
-                            vhi[h] = hi; vlo[h] = lo;
-                            pending = false;
+                    if (NW == 1) {
+                        volatile unsigned short *vclaim = claim;
+                        while (__ballot(pending)) {       // lanes that share a slot take turns
+                            if (pending) vclaim[h] = (unsigned short)lane;
+                            if (pending && vclaim[h] == (unsigned short)lane) {
+                                double hi = vhi[h], lo = vlo[h];
+                                dd_add(hi, lo, term);
+                                vhi[h] = hi; vlo[h] = lo;
+                                pending = false;
+                            }
+                        }
+                    } else {
+                        while (__ballot(pending)) {       // a lock per slot: the holder releases in the same pass
+                            if (pending && atomicCAS(&lockw[h], 0u, 1u) == 0u) {
+                                double hi = vhi[h], lo = vlo[h];
+                                dd_add(hi, lo, term);
+                                vhi[h] = hi; vlo[h] = lo;
+                                __threadfence_block();
+                                atomicExch(&lockw[h], 0u);
+                                pending = false;
+                            }
                         }
                     }
                 }
             }
         }
     }
+    if (NW > 1) {
+        if (ovf) s_ovf = 1;
+        __syncthreads();          // all raters are in the table
+        ovf = s_ovf;
+    }
     if (__ballot(ovf)) {
-        if (lane == 0) atomicOr(&A.counters[2], 1ull);
+        if (threadIdx.x == 0) atomicOr(&A.counters[2], 1ull);
         return;
     }
-    append_pairs(A, i, SLOTS_,
+    append_pairs(A, i, w * (SLOTS_ / NW), (w + 1) * (SLOTS_ / NW),
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             uint32_t kj = key[s];
             o = kj != T_EMPTY;
@@ -570,7 +610,7 @@ __global__ __launch_bounds__(64) void k_heavy_merge(TriArgs A, int n_heavy) {
         cnt[s] = cn; mut[s] = mu; dot[s] = hi;
     }
     if (nc == 0) return;
-    append_pairs(A, i, HMAX,
+    append_pairs(A, i, 0, HMAX,
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             o = cnt[s] != 0;
             if (!o) return false;
@@ -682,42 +722,51 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
 
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp /*[I] out*/,
-                   int64_t *uq_ptr, int64_t *uc_ptr, int64_t *h_counts /*[2]: light units, heavy units*/) {
-    XM_ARG(R && rc && Wp && pre && hid && ctl && Q && C && small && uq_ptr && uc_ptr && h_counts);
+                   int32_t *Qcat /*[4 I]*/, int64_t *uq_ptr /*[4 I + 1]*/, int64_t *uc_ptr,
+                   int64_t *h_counts /*[7]: light units, heavy units, first unit of table class rank 0..3, light units*/) {
+    XM_ARG(R && rc && Wp && pre && hid && ctl && Q && C && small && Qcat && uq_ptr && uc_ptr && h_counts);
     XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
     hipStream_t st = (hipStream_t)stream;
     const int I = R->n_items;
+    XM_HIP(hipMemsetAsync(Qcat, 0, sizeof(int32_t) * (size_t)N_CLASSES * (size_t)(I > 0 ? I : 1), st));
     if (I > 0) {
         k_plan2<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(
             I, (const long long *)R->item_ptr, (const RaterRec *)rc, (const long long *)pre, (int)R->n_users + 2, hid, ctl,
-            slot_target, Q, C, small, (unsigned long long *)Wp);
+            slot_target, Q, C, small, (unsigned long long *)Wp, Qcat);
         XM_LAUNCH_CHECK();
     }
-    int rcode = xmap_exclusive_scan_i32_to_i64(stream, Q, uq_ptr, I, &h_counts[0]);
+    int rcode = xmap_exclusive_scan_i32_to_i64(stream, Qcat, uq_ptr, (int64_t)N_CLASSES * I, &h_counts[0]);
     if (rcode) return rcode;
-    return xmap_exclusive_scan_i32_to_i64(stream, C, uc_ptr, I, &h_counts[1]);
+    rcode = xmap_exclusive_scan_i32_to_i64(stream, C, uc_ptr, I, &h_counts[1]);
+    if (rcode) return rcode;
+    for (int c = 0; c < N_CLASSES; c++)    // class boundaries (the scan above has synchronised the stream)
+        XM_HIP(hipMemcpyAsync(&h_counts[2 + c], uq_ptr + (size_t)c * I, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    h_counts[2 + N_CLASSES] = h_counts[0];
+    return XMAP_OK;
 }
 
-int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Q, const int64_t *uq_ptr, int32_t *uq_item,
+int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const int64_t *uq_ptr, int32_t *uq_item,
                     int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c) {
-    XM_ARG(Q && uq_ptr && uq_item && uq_q && C && uc_ptr && uc_item && uc_c);
+    XM_ARG(Qcat && uq_ptr && uq_item && uq_q && C && uc_ptr && uc_item && uc_c);
     if (n_items == 0) return XMAP_OK;
-    k_fill_units2<<<dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        n_items, Q, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c);
+    k_fill_units2<<<dim3((unsigned)(((long long)N_CLASSES * n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        n_items, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
 
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
                     const void *rc, const void *ub, const int32_t *Q,
-                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
+                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, const int64_t *cls_ptr /*host [5]*/,
+                    int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
                     int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/) {
     XM_ARG(R && u_avg && norms && rc && ub);
-    XM_ARG(Q && small && uq_item && uq_q && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
+    XM_ARG(Q && small && uq_item && uq_q && cls_ptr && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && rowcnt_h && d_shards && d_counters);
     XM_ARG(coo_cap >= COO_SHARDS);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
@@ -747,19 +796,27 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         XM_LAUNCH_CHECK();
     }
     if ((phases & 2) && unit_hi > unit_lo) {
-        dim3 grid((unsigned)(unit_hi - unit_lo));
-        if (method == XMAP_COSINE) {
-            k_pair_tri<XMAP_COSINE, T_LOG_SLOTS><<<grid, dim3(64), 0, st>>>(A);
-            k_pair_tri<XMAP_COSINE, 9><<<grid, dim3(64), 0, st>>>(A);
-            k_pair_tri<XMAP_COSINE, 8><<<grid, dim3(64), 0, st>>>(A);
-            k_pair_tri<XMAP_COSINE, 7><<<grid, dim3(64), 0, st>>>(A);
-        } else {
-            k_pair_tri<XMAP_ADJUST_COSINE, T_LOG_SLOTS><<<grid, dim3(64), 0, st>>>(A);
-            k_pair_tri<XMAP_ADJUST_COSINE, 9><<<grid, dim3(64), 0, st>>>(A);
-            k_pair_tri<XMAP_ADJUST_COSINE, 8><<<grid, dim3(64), 0, st>>>(A);
-            k_pair_tri<XMAP_ADJUST_COSINE, 7><<<grid, dim3(64), 0, st>>>(A);
+        // one launch per table class: the class's units within [unit_lo, unit_hi)
+        for (int c = 0; c < N_CLASSES; c++) {
+            const long long lo = unit_lo > cls_ptr[c] ? unit_lo : cls_ptr[c];
+            const long long hi = unit_hi < cls_ptr[c + 1] ? unit_hi : cls_ptr[c + 1];
+            if (hi <= lo) continue;
+            A.unit_lo = lo; A.unit_hi = hi;
+            const dim3 grid((unsigned)(hi - lo));
+            if (method == XMAP_COSINE) {
+                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 4><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_COSINE, 9, 2><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_COSINE, 8, 1><<<grid, dim3(64), 0, st>>>(A);
+                else k_pair_tri<XMAP_COSINE, 7, 1><<<grid, dim3(64), 0, st>>>(A);
+            } else {
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1><<<grid, dim3(64), 0, st>>>(A);
+                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1><<<grid, dim3(64), 0, st>>>(A);
+            }
+            XM_LAUNCH_CHECK();
         }
-        XM_LAUNCH_CHECK();
+        A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     }
     if ((phases & 4) && n_heavy_units > 0 && n_heavy > 0) {
         if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);

@@ -276,18 +276,21 @@ class Engine(object):
         L.Q = self._zeros(max(I, 1), torch.int32)
         L.C = self._zeros(max(I, 1), torch.int32)
         L.small = self._zeros(max(I, 1), torch.uint8)
-        L.uq_ptr = self._zeros(I + 1, torch.int64)
+        L.Qcat = self._empty(4 * max(I, 1), torch.int32)
+        L.uq_ptr = self._zeros(4 * I + 1, torch.int64)     # light units class-major: [table class rank][item]
         L.uc_ptr = self._zeros(I + 1, torch.int64)
-        h = (C.c_int64 * 2)()
+        h = (C.c_int64 * 7)()
         with self.timed("tri_plan"):
             check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.rc), vp(L.pre), vp(L.hid),
-                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.Wp), vp(L.uq_ptr), vp(L.uc_ptr), h))
+                                     vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.Wp), vp(L.Qcat), vp(L.uq_ptr),
+                                     vp(L.uc_ptr), h))
             L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
+            L.cls_ptr = (C.c_int64 * 5)(*[int(h[2 + c]) for c in range(5)])
             L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
             L.uq_q = self._empty(max(L.n_light, 1), torch.int32)
             L.uc_item = self._empty(max(L.n_heavy_units, 1), torch.int32)
             L.uc_c = self._empty(max(L.n_heavy_units, 1), torch.int32)
-            check(lib.xmap_sim2_units(st, i32(I), vp(L.Q), vp(L.uq_ptr), vp(L.uq_item), vp(L.uq_q),
+            check(lib.xmap_sim2_units(st, i32(I), vp(L.Qcat), vp(L.uq_ptr), vp(L.uq_item), vp(L.uq_q),
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
@@ -322,7 +325,7 @@ class Engine(object):
                 check(lib.xmap_sim2_pairs(
                     st, C.byref(R.c), m, int(cap), vp(u_avg), vp(self.norms), vp(L.rc), vp(L.ub), vp(L.Q), vp(L.small),
                     vp(L.uq_item),
-                    vp(L.uq_q), i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
+                    vp(L.uq_q), L.cls_ptr, i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
                     vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
