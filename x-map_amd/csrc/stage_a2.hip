@@ -226,7 +226,13 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     const int lane = lane_id();
     const long long p0 = iptr[i], p1 = iptr[i + 1];
     long long w = 0;
-    for (long long p = p0 + lane; p < p1; p += 64) w += rc[p].pos_ge & 0x7fffffff;
+    for (long long p = p0 + lane; p < p1; p += 64 * 8) {   // 8 loads in flight per lane (popular items: 1e5 raters)
+        int v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = (p + 64 * t < p1) ? rc[p + 64 * t].pos_ge & 0x7fffffff : 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) w += v[t];
+    }
     w = wave_sum_ll(w);
     if (lane) return;
     long long n = p1 - p0;
@@ -596,17 +602,17 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
 }
 
 template <int METHOD>
-__global__ __launch_bounds__(64) void k_heavy_merge(TriArgs A, int n_heavy) {
+__global__ __launch_bounds__(256) void k_heavy_merge(TriArgs A, int n_heavy) {
     __shared__ uint32_t cnt[HMAX];
     __shared__ uint32_t mut[HMAX];
     __shared__ double dot[HMAX];
-    const int lane = lane_id();
     const int h = blockIdx.x;
     if (h >= n_heavy) return;
     const int i = A.hlist[h];
     const int nc = A.C[i];
     const long long u0 = A.uc_ptr[i];
-    for (int s = lane; s < HMAX; s += 64) {
+    // four waves per row: the most popular item has ~80 chunks of partials to fold
+    for (int s = threadIdx.x; s < HMAX; s += 256) {
         unsigned cn = 0, mu = 0;
         double hi = 0.0, lo = 0.0;
         for (int c = 0; c < nc; c++) {
@@ -623,7 +629,9 @@ __global__ __launch_bounds__(64) void k_heavy_merge(TriArgs A, int n_heavy) {
         cnt[s] = cn; mut[s] = mu; dot[s] = hi;
     }
     if (nc == 0) return;
-    append_pairs(A, i, 0, HMAX,
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    append_pairs(A, i, w * (HMAX / 4), (w + 1) * (HMAX / 4),
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             o = cnt[s] != 0;
             if (!o) return false;
@@ -832,8 +840,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     }
     if ((phases & 4) && n_heavy_units > 0 && n_heavy > 0) {
-        if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
-        else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(64), 0, st>>>(A, n_heavy);
+        if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, st>>>(A, n_heavy);
+        else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, st>>>(A, n_heavy);
         XM_LAUNCH_CHECK();
     }
     if ((phases & 16) && n_heavy > 0) {   // fold the heavy items' count replicas into rowcnt
