@@ -110,6 +110,17 @@ def main():
             out[key]["private" if private else "nonprivate"] = dict(
                 seed=seed, selected=sel,
                 predicted=[(u, [list(p) for p in lst]) for u, lst in pred], mae=mae)
+    # ---- RecommenderSim on non-integer ratings (AlterEgo ratings are means): pins the float behaviour of the
+    # similarity and of the leave-one-out local sensitivity (items with a single rater included)
+    frac = (0.0, 1.0 / 3.0, 0.5, 0.25, 2.0 / 3.0)
+    rows_f = [(u, i, float(np.float32(float(r) - frac[k % 5])) if float(r) > 1 else float(r), t)   # fp32 values: the
+              for k, (u, i, r, t) in enumerate(rows)]                                                  # engine's rating type
+    sim_tool = RecommenderSim("cosine_item", 50)
+    res = assist.recommender_calculate_sim_pipeline(sc, sim_tool, MiniRDD(rows_f, sc))
+    out["cosine_item_float"] = dict(
+        rows=[(u, i, r, mg.dt2ts(t)) for (u, i, r, t) in rows_f],
+        item_info=[(i, [float(x) for x in v]) for i, v in sorted(res[5].value.items())],
+        sim=[([a, b], [float(v[0]), float(v[1])]) for (a, b), v in res[6].collect()])
     path = os.path.join(OUT, "small_downstream.json.gz")
     with gzip.open(path, "wt") as f:
         json.dump(out, f)

@@ -687,3 +687,121 @@ void xo_dense_topk(int32_t n_t, int32_t n_s, int32_t K, const float *Ft, const f
         for (int p = cnt; p < top_k; p++) { oi[p] = -1; ov[p] = 0.f; }
     }
 }
+
+/* ------------------------------------------------------------------ RecommenderSim
+ * core/recommenderSim.py:65-133,188-195: item-item cosine over the AlterEgo profile with significance weighting and
+ * the per-pair leave-one-out LOCAL SENSITIVITY; both method names take the cosine branch (:190: "cosine_item" is a
+ * substring of "adjust_cosine_item").  For every directed pair (i, j) with co-raters C:
+ *   inner = sum_{u in C} r_ui r_uj            python sum() in co-rater order   -> canonical: exact sum, rounded once
+ *   norm  = np.sqrt(np.sum(r^2)) per item     (:41, pairwise)                  -> canonical: exact sum, rounded once
+ *   sim   = (cos(inner, nx ny) * min(n, cap)) / cap                            (:78-88,:124-126)
+ *   ls    = max over u in C of |w(cos(inner - r_ui r_uj, sqrt((nx^2 - r_ui^2) ny^2)), n-1) - sim| and the same with
+ *           sqrt(nx^2 (ny^2 - r_uj^2))                                         (:98-116); NaN propagates like np.max
+ * Only users with >= 2 ratings form pairs (:73-74).  Nothing is filtered.  Canonical sums differ from the
+ * reference's roundings by <= 1e-12 relative (tests assert rtol 1e-9 and the same NaN pattern). */
+typedef struct { int32_t I; int64_t *row_ptr; int32_t *col; double *sim; double *ls; int32_t *nij; double *norm; } XoRec;
+
+static double rec_weight(double cs, int32_t n, int cap) {
+    int32_t mn = n < cap ? n : cap;
+    return 1.0 * cs * (double)mn / (double)cap;
+}
+
+XoRec *xo_rec_sim(int cap, int64_t U, int32_t I, const int64_t *ptr, const int32_t *item, const float *rating) {
+    int64_t nnz = ptr[U];
+    XoRec *S = (XoRec *)calloc(1, sizeof(XoRec));
+    S->I = I;
+    S->norm = (double *)calloc((size_t)(I ? I : 1), sizeof(double));
+    {   /* exact sum of the squares per item */
+        double *hi = (double *)calloc((size_t)(I ? I : 1), sizeof(double)), *lo = (double *)calloc((size_t)(I ? I : 1), sizeof(double));
+        for (int64_t e = 0; e < nnz; e++) { double r = (double)rating[e]; dd_add(&hi[item[e]], &lo[item[e]], r * r); }
+        for (int32_t i = 0; i < I; i++) S->norm[i] = sqrt(hi[i]);
+        free(hi); free(lo);
+    }
+    int64_t *iptr = (int64_t *)calloc((size_t)I + 1, sizeof(int64_t));
+    for (int64_t e = 0; e < nnz; e++) iptr[item[e] + 1]++;
+    for (int32_t i = 0; i < I; i++) iptr[i + 1] += iptr[i];
+    int32_t *iuser = (int32_t *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
+    int64_t *ient = (int64_t *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int64_t));   /* the rating's own profile entry */
+    float *irat = (float *)malloc((size_t)(nnz ? nnz : 1) * sizeof(float));
+    {
+        int64_t *cur = (int64_t *)malloc((size_t)(I ? I : 1) * sizeof(int64_t));
+        memcpy(cur, iptr, (size_t)I * sizeof(int64_t));
+        for (int64_t u = 0; u < U; u++)
+            for (int64_t e = ptr[u]; e < ptr[u + 1]; e++) { int64_t p = cur[item[e]]++; iuser[p] = (int32_t)u; irat[p] = rating[e]; ient[p] = e; }
+        free(cur);
+    }
+    Arena A; memset(&A, 0, sizeof(A));
+    double *als = NULL; int64_t als_cap = 0;
+    S->row_ptr = (int64_t *)calloc((size_t)I + 1, sizeof(int64_t));
+    int32_t *cnt = (int32_t *)calloc((size_t)(I ? I : 1), sizeof(int32_t));
+    int32_t *pos = (int32_t *)calloc((size_t)(I ? I : 1), sizeof(int32_t));
+    int32_t *touched = (int32_t *)malloc((size_t)(I ? I : 1) * sizeof(int32_t));
+    int64_t bufcap = 1024;
+    int32_t *bj = (int32_t *)malloc(bufcap * sizeof(int32_t));
+    double *b0 = (double *)malloc(bufcap * sizeof(double)), *b1 = (double *)malloc(bufcap * sizeof(double));
+    double *g0 = (double *)malloc(bufcap * sizeof(double)), *g1 = (double *)malloc(bufcap * sizeof(double));
+    for (int32_t i = 0; i < I; i++) {
+        int64_t w = 0, nt = 0;
+        for (int64_t p = iptr[i]; p < iptr[i + 1]; p++) {
+            int32_t u = iuser[p];
+            if (ptr[u + 1] - ptr[u] < 2) continue;
+            for (int64_t e = ptr[u]; e < ptr[u + 1]; e++) {
+                int32_t j = item[e];
+                /* combinations(ratings, 2) pairs every two ENTRIES of a profile (:71): an AlterEgo profile can hold
+                 * an item twice (a pass-through rating and a mapped one), which yields (X, X) keys and two co-rating
+                 * entries per such user; only the entry itself is skipped */
+                if (e == ient[p]) continue;
+                if (w == bufcap) {
+                    bufcap *= 2;
+                    bj = (int32_t *)realloc(bj, bufcap * sizeof(int32_t));
+                    b0 = (double *)realloc(b0, bufcap * sizeof(double)); b1 = (double *)realloc(b1, bufcap * sizeof(double));
+                    g0 = (double *)realloc(g0, bufcap * sizeof(double)); g1 = (double *)realloc(g1, bufcap * sizeof(double));
+                }
+                bj[w] = j; b0[w] = (double)irat[p]; b1[w] = (double)rating[e]; w++;
+                if (cnt[j]++ == 0) touched[nt++] = j;
+            }
+        }
+        qsort(touched, (size_t)nt, sizeof(int32_t), cmp_i32);
+        int64_t off = 0;
+        for (int64_t t = 0; t < nt; t++) { pos[touched[t]] = (int32_t)off; off += cnt[touched[t]]; }
+        for (int64_t k = 0; k < w; k++) { int32_t q = pos[bj[k]]++; g0[q] = b0[k]; g1[q] = b1[k]; }
+        off = 0;
+        const double nx = S->norm[i];
+        for (int64_t t = 0; t < nt; t++) {
+            int32_t j = touched[t], n = cnt[j];
+            const double *r0 = g0 + off, *r1 = g1 + off;
+            off += n;
+            double hi = 0.0, lo = 0.0;
+            for (int32_t k = 0; k < n; k++) dd_add(&hi, &lo, r0[k] * r1[k]);
+            const double inner = hi, ny = S->norm[j];
+            const double np_ = nx * ny;
+            const double sim = rec_weight(np_ ? 1.0 * inner / np_ : 0.0, n, cap);
+            double ls = 0.0;
+            int isnan_ls = 0;
+            for (int32_t k = 0; k < n; k++) {
+                const double rest = inner - r0[k] * r1[k];
+                const double m1 = sqrt((nx * nx - r0[k] * r0[k]) * (ny * ny));
+                const double m2 = sqrt((nx * nx) * (ny * ny - r1[k] * r1[k]));
+                const double d1 = fabs(rec_weight(m1 != 0.0 ? 1.0 * rest / m1 : 0.0, n - 1, cap) - sim);   /* NaN != 0 */
+                const double d2 = fabs(rec_weight(m2 != 0.0 ? 1.0 * rest / m2 : 0.0, n - 1, cap) - sim);
+                if (d1 != d1 || d2 != d2) isnan_ls = 1;
+                if (d1 > ls) ls = d1;
+                if (d2 > ls) ls = d2;
+            }
+            if (isnan_ls) ls = NAN;
+            arena_push(&A, j, sim, 0, n);
+            if (A.n > als_cap) { als_cap = A.n * 2 + 1024; als = (double *)realloc(als, (size_t)als_cap * sizeof(double)); }
+            als[A.n - 1] = ls;
+            cnt[j] = 0; pos[j] = 0;
+        }
+        S->row_ptr[i + 1] = A.n;
+    }
+    S->col = A.col; S->sim = A.sim; S->nij = A.nij; S->ls = als;
+    free(A.mutu);
+    free(cnt); free(pos); free(touched); free(bj); free(b0); free(b1); free(g0); free(g1); free(iptr); free(iuser); free(irat); free(ient);
+    return S;
+}
+void xo_rec_free(XoRec *S) {
+    if (!S) return;
+    free(S->row_ptr); free(S->col); free(S->sim); free(S->ls); free(S->nij); free(S->norm); free(S);
+}

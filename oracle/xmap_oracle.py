@@ -224,3 +224,33 @@ def dense_topk(Fn_t, Fn_s, top_k, nthreads=4):
                         _p(Fn_s, C.c_float), C.c_int32(top_k), _p(idx, C.c_int32), _p(val, C.c_float),
                         C.c_int(nthreads))
     return idx, val
+
+
+# ---------------------------------------------------------------------- RecommenderSim
+class _XoRec(C.Structure):
+    _fields_ = [("I", C.c_int32), ("row_ptr", C.POINTER(C.c_int64)), ("col", C.POINTER(C.c_int32)),
+                ("sim", C.POINTER(C.c_double)), ("ls", C.POINTER(C.c_double)), ("nij", C.POINTER(C.c_int32)),
+                ("norm", C.POINTER(C.c_double))]
+
+
+class Rec(object):
+    pass
+
+
+def rec_sim(user_ptr, item, rating, n_items, cap):
+    """RecommenderSim.calculate_sim (cosine branch) in index space: CSR by first item of (col, sim, ls, n_ij) + norms."""
+    L = lib()
+    L.xo_rec_sim.restype = C.POINTER(_XoRec)
+    user_ptr = np.ascontiguousarray(user_ptr, np.int64)
+    item = np.ascontiguousarray(item, np.int32)
+    rating = np.ascontiguousarray(rating, np.float32)
+    p = L.xo_rec_sim(C.c_int(int(cap)), C.c_int64(len(user_ptr) - 1), C.c_int32(int(n_items)), _p(user_ptr, C.c_int64),
+                     _p(item, C.c_int32), _p(rating, C.c_float))
+    c = p.contents
+    R = Rec()
+    R.row_ptr = _arr(c.row_ptr, n_items + 1, np.int64)
+    D = int(R.row_ptr[-1])
+    R.col, R.sim, R.ls, R.nij = _arr(c.col, D, np.int32), _arr(c.sim, D, np.float64), _arr(c.ls, D, np.float64), _arr(c.nij, D, np.int32)
+    R.norm = _arr(c.norm, n_items, np.float64)
+    L.xo_rec_free(p)
+    return R

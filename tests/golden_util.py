@@ -57,3 +57,26 @@ class Golden(object):
 def csr_to_pairs(row_ptr, col):
     rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
     return rows, col.astype(np.int64)
+
+
+def rows_to_csr(rows):
+    """(uid, iid, rating, ts)* -> (uids, iids, user_ptr, item, rating) with users in order of first appearance and items
+    in lexicographic id order (the index space of the engine and of the oracle)."""
+    import numpy as np
+    uids, useen = [], {}
+    for r in rows:
+        if r[0] not in useen:
+            useen[r[0]] = len(uids)
+            uids.append(r[0])
+    iids = sorted({r[1] for r in rows})
+    iidx = {s: k for k, s in enumerate(iids)}
+    per = [[] for _ in uids]
+    for r in rows:
+        per[useen[r[0]]].append((iidx[r[1]], float(r[2])))
+    ptr = np.zeros(len(uids) + 1, np.int64)
+    item, rating = [], []
+    for k, prof in enumerate(per):
+        ptr[k + 1] = ptr[k] + len(prof)
+        item += [p[0] for p in prof]
+        rating += [p[1] for p in prof]
+    return uids, iids, ptr, np.array(item, np.int32), np.array(rating, np.float32)

