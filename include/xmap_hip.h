@@ -137,11 +137,12 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]*/, int32_t *hid /*[I]*/, int32_t *hlist /*[1024]*/,
                      uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] x 8 B: item|flag, rating*/,
-                     void *rc /*[nnz] x 16 B rater records in CSC order*/, int32_t *h_ctl /*[2]*/);
+                     void *rc /*[nnz] x 16 B rater records in CSC order*/,
+                     int32_t dups /*1: a profile may hold an item more than once (AlterEgo rows)*/, int32_t *h_ctl /*[2]*/);
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small /*[I]*/,
                    uint64_t *Wp /*[I] out: contributions per row*/, int32_t *Qcat /*[4 I]*/, int64_t *uq_ptr /*[4 I + 1]*/,
-                   int64_t *uc_ptr /*[I + 1]*/, int64_t *h_counts /*[7], host*/);
+                   int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int64_t *h_counts /*[7], host*/);
 int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const int64_t *uq_ptr, int32_t *uq_item,
                     int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c);
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
@@ -151,13 +152,21 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
-                    int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
+                    int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij,
+                    double *coo_ls /*NULL, or the RecommenderSim variant (below)*/, int32_t *rowcnt,
                     int32_t *rowcnt_h /*[64][1024] scratch*/, int64_t *d_shards /*[2][4096]*/,
                     int64_t *d_counters /*[4]*/);
 int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
-                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *row_ptr,
-                      int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist, int32_t *col, double *sim,
-                      int32_t *mutu, int32_t *nij);
+                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_ls /*or NULL*/,
+                      const int64_t *row_ptr, int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist,
+                      int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *ls /*or NULL*/);
+/* RecommenderSim.calculate_sim (core/recommenderSim.py:65-133,188-195; both method names take the cosine branch, :190)
+ * is the same pair machinery over the AlterEgo rows: call xmap_item_stats with u_avg = 0 (adjnorm is then the exact
+ * norm), xmap_sim2_layout with dups = 1 and ch_min > n_users (no heavy set), xmap_sim2_plan with dups = 1, and
+ * xmap_sim2_pairs with method XMAP_ADJUST_COSINE (exact double-double sums), u_avg = 0 and coo_ls != NULL: nothing is
+ * filtered, an item held twice by a user pairs with itself (one entry, both orders counted), and coo_ls receives the
+ * leave-one-out local sensitivity of every pair (second walk over the raters with the final inner product; NaN
+ * propagates like np.max).  xmap_sim2_scatter then mirrors (col, sim, n_ij, ls); mutu is unused (0). */
 
 /* ---- stage B: extender_pipeline (utils/assist.py:80-133) ---------------------------------- */
 

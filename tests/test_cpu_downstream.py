@@ -80,6 +80,7 @@ def test_recommender_stages_match_reference(gold, method):
     test = [(u, [(i, r, dt(t)) for (i, r, t) in prof]) for u, prof in gold["downstream_input"]["test"]]
     g = gold[method]
     sim_tool = RecommenderSim(method, 50)
+    sim_tool.calculate_sim = sim_tool.calculate_sim_host     # the per-pair Python statement (the product runs it on the GPU)
     res = recommender_calculate_sim_pipeline(sc, sim_tool, sc.parallelize(rows))
     user_based, item_based, ubd, ibd, uinfo, iinfo, sim = res
     assert sorted((k, [float(x) for x in v]) for k, v in iinfo.value.items()) == [(k, v) for k, v in g["item_info"]]

@@ -1,0 +1,163 @@
+"""RecommenderSim on the GPU: weighted cosine + leave-one-out local sensitivity over AlterEgo rows,
+against the reference's own output (tests/golden/small_downstream.json.gz) and, bit for bit, against the CPU oracle."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import rows_to_csr
+
+pytestmark = pytest.mark.gpu
+REC_RTOL = 1e-9   # exact sums (inner product, squared norms) vs the reference's python sum() / np.sum roundings
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_downstream.json.gz")
+
+
+def _engine(ptr, item, rating, iids):
+    import torch
+    assert torch.cuda.is_available()
+    from xmap.engine import device, ids
+    attrs = ids.item_attrs(iids)
+    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), attrs, "cuda:0")
+    return device.Engine(R)
+
+
+def _pairs(S, n_items):
+    rp = S.row_ptr.cpu().numpy()
+    rows = np.repeat(np.arange(n_items, dtype=np.int64), np.diff(rp))
+    col = S.col.cpu().numpy().astype(np.int64)
+    o = np.lexsort((col, rows))
+    return rows[o], col[o], S.sim.cpu().numpy()[o], S.ls.cpu().numpy()[o], S.nij.cpu().numpy()[o]
+
+
+def _oracle_pairs(R, n_items):
+    rows = np.repeat(np.arange(n_items, dtype=np.int64), np.diff(R.row_ptr))
+    return rows, R.col.astype(np.int64), R.sim, R.ls, R.nij
+
+
+@pytest.mark.parametrize("key,rows_key", [("cosine_item", None), ("cosine_item_float", "rows")])
+def test_rec_sim_golden(key, rows_key):
+    from oracle import xmap_oracle as xo
+    with gzip.open(GOLD, "rt") as f:
+        g = json.load(f)
+    rows = g[key][rows_key] if rows_key else g["downstream_input"]["rows"]
+    uids, iids, ptr, item, rating = rows_to_csr(rows)
+    eng = _engine(ptr, item, rating, iids)
+    S = eng.rec_sim(50)
+    r, c, sim, ls, nij = _pairs(S, len(iids))
+    got = {(iids[a], iids[b]): (s, l) for a, b, s, l in zip(r, c, sim, ls)}
+    want = {(a, b): (v[0], v[1]) for (a, b), v in g[key]["sim"]}
+    assert set(got) == set(want) and len(got) == len(r)
+    assert any(a == b for a, b in want)          # an item held twice by a user pairs with itself
+    for kk, (s, l) in want.items():
+        gs, gl = got[kk]
+        assert np.isnan(l) == np.isnan(gl)
+        assert gs == pytest.approx(s, rel=REC_RTOL, abs=1e-15)
+        if not np.isnan(l):
+            assert gl == pytest.approx(l, rel=REC_RTOL, abs=1e-13)
+    O = xo.rec_sim(ptr, item, rating, len(iids), 50)
+    orow, ocol, osim, ols, onij = _oracle_pairs(O, len(iids))
+    assert np.array_equal(r, orow) and np.array_equal(c, ocol) and np.array_equal(nij, onij)
+    assert np.array_equal(sim.view(np.uint64), osim.view(np.uint64))
+    assert np.array_equal(ls.view(np.uint64), ols.view(np.uint64))
+    assert np.array_equal(S.norm.cpu().numpy(), O.norm)
+
+
+def _alterego_rows(seed, users, items):
+    """AlterEgo rows of a synthetic two-domain case straight from the GPU hot path (private mapping, k = 5)."""
+    import torch
+    from xmap.engine import device, synth
+    r = synth.make_two_domain(seed, users, items, items, overlap=0.4)
+    R = device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), "cuda:0")
+    eng = device.Engine(R)
+    S = eng.item_sim("cosine", 50)
+    E = eng.extend(S, 5)
+    _, _, mp = eng.select(E, True)
+    G = eng.alterego(mp)
+    u, it, ra = G.user.cpu().numpy(), G.item.cpu().numpy(), G.rating.cpu().numpy()
+    o = np.argsort(u, kind="stable")
+    return u[o], it[o], ra[o], r
+
+
+@pytest.mark.parametrize("users,items", [(3000, 600), (20000, 3000)])
+def test_rec_sim_vs_oracle_on_alterego_rows(users, items):
+    from oracle import xmap_oracle as xo
+    u, it, ra, r = _alterego_rows(7, users, items)
+    # make sure items held twice by a user (a pass-through and a mapped rating of one target item) are present, also
+    # three times, also in long profiles: every 7th user repeats its first (and every 21st also its last) item
+    first = np.r_[True, u[1:] != u[:-1]]
+    last = np.r_[u[1:] != u[:-1], True]
+    ex = np.nonzero(first & (u % 7 == 0))[0]
+    ex2 = np.nonzero(last & (u % 21 == 0))[0]
+    u = np.concatenate([u, u[ex], u[ex], u[ex2]])
+    it = np.concatenate([it, it[ex], it[ex], it[ex2]])
+    ra = np.concatenate([ra, ra[ex] * 0.5, ra[ex] * 0.75 + 0.125, ra[ex2] - 0.25]).astype(np.float32)
+    o = np.argsort(u, kind="stable")
+    u, it, ra = u[o], it[o], ra[o]
+    uu, uinv = np.unique(u, return_inverse=True)
+    ii, iinv = np.unique(it, return_inverse=True)
+    ptr = np.zeros(len(uu) + 1, np.int64)
+    np.cumsum(np.bincount(uinv, minlength=len(uu)), out=ptr[1:])
+    item, rating = iinv.astype(np.int32), ra.astype(np.float32)
+    # duplicates (a pass-through and a mapped rating of the same target item) and non-integer means are present
+    dup = sum(len(set(item[ptr[k]:ptr[k + 1]])) < ptr[k + 1] - ptr[k] for k in range(len(uu)))
+    assert dup > 0 and np.any(rating != np.round(rating))
+    all_ids = r.item_ids()
+    iids = [all_ids[x] for x in ii]
+    eng = _engine(ptr, item, rating, iids)
+    O = xo.rec_sim(ptr, item, rating, len(ii), 50)
+    for slot_target in (640, 24):           # 24: rows cut into many hash partitions
+        S = eng.rec_sim(50, slot_target=slot_target)
+        a, b, sim, ls, nij = _pairs(S, len(ii))
+        orow, ocol, osim, ols, onij = _oracle_pairs(O, len(ii))
+        assert np.array_equal(a, orow) and np.array_equal(b, ocol) and np.array_equal(nij, onij)
+        assert np.array_equal(sim.view(np.uint64), osim.view(np.uint64))
+        assert np.array_equal(ls.view(np.uint64), ols.view(np.uint64))
+    # symmetry: the reference emits both directions with the same values
+    key = a * len(ii) + b
+    rev = b * len(ii) + a
+    o1, o2 = np.argsort(key), np.argsort(rev)
+    assert np.array_equal(key[o1], rev[o2])
+    assert np.array_equal(sim[o1].view(np.uint64), sim[o2].view(np.uint64))
+    assert np.array_equal(ls[o1].view(np.uint64), ls[o2].view(np.uint64))
+
+
+def test_recommender_pipeline_api():
+    """recommender_calculate_sim_pipeline -> recommender_privacy_pipeline -> recommender_prediction_pipeline driven
+    like twodomain_demo.py:107-121; the similarity stage runs on the GPU, the result is the reference's up to the
+    rounding of the exact sums."""
+    import datetime
+    from pyspark import SparkContext, SparkConf
+    from xmap.core.recommenderSim import RecommenderSim
+    from xmap.core.recommenderPrivacy import RecommenderPrivacy
+    from xmap.core.recommenderPrediction import RecommenderPrediction
+    from xmap.utils.assist import (recommender_calculate_sim_pipeline, recommender_privacy_pipeline,
+                                   recommender_prediction_pipeline)
+    from xmap.engine.session import RecSimRDD
+    with gzip.open(GOLD, "rt") as f:
+        g = json.load(f)
+    dt = lambda ts: datetime.datetime.utcfromtimestamp(int(ts))
+    sc = SparkContext(conf=SparkConf())
+    rows = [(u, i, r, dt(t)) for (u, i, r, t) in g["downstream_input"]["rows"]]
+    test = [(u, [(i, r, dt(t)) for (i, r, t) in prof]) for u, prof in g["downstream_input"]["test"]]
+    method = "cosine_item"
+    sim_tool = RecommenderSim(method, 50)
+    user_based, item_based, ubd, ibd, uinfo, iinfo, sim = recommender_calculate_sim_pipeline(sc, sim_tool, sc.parallelize(rows))
+    assert isinstance(sim, RecSimRDD)
+    got = dict((k, v) for k, v in sim.collect())
+    want = {(a, b): v for (a, b), v in g[method]["sim"]}
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert got[k][0] == pytest.approx(v[0], rel=REC_RTOL, abs=1e-15) and got[k][1] == pytest.approx(v[1], rel=REC_RTOL, abs=1e-13)
+    # downstream consumers (host-side, as in the reference) accept the handle
+    sel = recommender_privacy_pipeline(RecommenderPrivacy(10, 0.6, 0.1), sim, False).collect()
+    want_sel = dict((i, lst) for i, lst in g[method]["nonprivate"]["selected"])
+    assert set(i for i, _ in sel) == set(want_sel)
+    same = sum([n for n, _ in lst] == [n for n, _ in want_sel[i]] for i, lst in sel)
+    assert same >= 0.9 * len(sel)          # neighbour lists agree except where equal similarities tie differently
+    pred_tool = RecommenderPrediction(0.03, method)
+    mae = recommender_prediction_pipeline(pred_tool, sim_tool, sc.parallelize(test), sc.broadcast(dict(sel)), ubd, ibd, uinfo, iinfo)
+    ref = [float(x) for x in g[method]["nonprivate"]["mae"].split(";")]
+    ours = [float(x) for x in mae.split(";")]
+    assert np.allclose(ours, ref, atol=0.02)

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
             if (lane < d) ub[a + lane] = make_int2(px, py);
             continue;
         }
-        // longer than a wave: rank by counting.  The keys (unique: one item once per profile) are staged in LDS
+        // longer than a wave: rank by counting.  The keys are staged in LDS
         // (or, past SORT_LDS of them, in the ub_key scratch) and every entry counts the heavier ones.
         unsigned long long *keys = d <= SORT_LDS ? lkeys[threadIdx.x >> 6] : ub_key + a;
         for (int p = lane; p < d; p += 64) {
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
             unsigned long long key;
             int px, py;
             sort_entry(uitem, urating, iptr, info, a + p, key, px, py);
-            int rank = 0;
-            for (int o = 0; o < d; o++) rank += keys[o] > key;
+            int rank = 0;   // equal keys (an item twice in one profile: AlterEgo rows) keep their order
+            for (int o = 0; o < d; o++) rank += (keys[o] > key) || (keys[o] == key && o < p);
             ub[a + rank] = make_int2(px, py);
         }
     }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
 // one thread per CSC entry (item i, its p-th rater u): position of i in u's sorted profile = number of heavier
 // co-rated items = length of the prefix this rater contributes.  No atomics; raters stay in ascending user order.
 __global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, const long long *iptr, const int *iuser,
-                                                       const long long *uptr, const int2 *ub, RaterRec *rc) {
+                                                       const long long *uptr, const int2 *ub, RaterRec *rc, int *taken) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nnz) return;
     // item of CSC entry p: binary search in iptr
@@ -206,8 +206,15 @@ __global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, con
     RaterRec r;
     r.e0 = (int)a; r.pos_ge = 0; r.rating = 0.f; r.user = u;
     for (long long e = a; e < b; e++) {
-        const int2 v = ub[e];
+        int2 v = ub[e];
         if ((v.x & 0x7fffffff) == i) {
+            // A profile may hold the item more than once (AlterEgo rows: a pass-through and a mapped rating); the
+            // copies are adjacent in the sorted profile and the item then has as many CSC entries for this user:
+            // each takes one copy (`taken`, zeroed, non-NULL only when the caller allows duplicates).
+            if (taken && e + 1 < b && (ub[e + 1].x & 0x7fffffff) == i) {
+                e += atomicAdd(&taken[e], 1);
+                v = ub[e];
+            }
             const int pos = (b - a >= 2) ? (int)(e - a) : 0;   // users with >= 2 ratings only (baselinerSim.py:184-185)
             r.pos_ge = (int)((unsigned)pos | ((unsigned)v.x & 0x80000000u));
             r.rating = __int_as_float(v.y);
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, con
 
 // light rows: Q partitions; heavy rows (in H): chunks of CH raters.  One wave per item sums W+ = the prefix lengths.
 __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const RaterRec *rc, const long long *pre,
-                                               int HB, const int *hid, const int *CH, int target, int *Q, int *C,
+                                               int HB, const int *hid, const int *CH, int target, int dups, int *Q, int *C,
                                                uint8_t *small, unsigned long long *Wp, int *Qcat) {
     int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= I) return;
@@ -237,7 +244,8 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     if (lane) return;
     long long n = p1 - p0;
     long long ge = I - pre[n < HB - 1 ? n : HB - 1];   // #{items with at least as many raters}
-    long long bound = w < ge - 1 ? w : ge - 1;
+    const long long others = ge - 1 + (dups ? 1 : 0);   // with duplicate items a row can pair with itself
+    long long bound = w < others ? w : others;
     int q = 0, c = 0;
     if (w > 0) {
         if (hid[i] >= 0) c = (int)((n + *CH - 1) / *CH);
@@ -284,6 +292,7 @@ struct TriArgs {
     unsigned long long *shard_cur;  // [COO_SHARDS] cursors
     unsigned long long *shard_occ;  // [COO_SHARDS] unordered pairs evaluated
     int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
+    double *coo_aux;                // optional 6th column (RecommenderSim: local sensitivity)
     int *rowcnt;
     int *rowcnt_h;                  // [HEAVY_SHARDS][HMAX] replicas for the heavy items
     unsigned long long *counters;   // [2] table overflow, [3] COO overflow
@@ -310,8 +319,9 @@ constexpr int HEAVY_SHARDS = 64;
 
 // finalise(s, j, n, m, sim, occupied) -> keep.  Pass 1 finalises every slot once (the result is parked by `park`),
 // pass 2 writes the kept ones.
-template <typename Fin, typename Park, typename Get>
-__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begin, int n_slots, Fin fin, Park park, Get get) {
+template <typename Fin, typename Park, typename Get, typename Aux>
+__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begin, int n_slots, Fin fin, Park park, Get get,
+                                             Aux aux) {
     const int lane = lane_id();
     const int shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (COO_SHARDS - 1);
     int kept = 0, occ = 0;
@@ -342,8 +352,10 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begi
         if (keep) {
             long long p = (long long)base + __popcll(km & lanemask_lt());
             A.coo_i[p] = i; A.coo_j[p] = j; A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
+            if (A.coo_aux) A.coo_aux[p] = aux(s0 + lane);
             const int hj = A.hid[j];
-            if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
+            if (j == i) {}   // a row paired with itself (RecommenderSim) has no mirror entry
+            else if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
             else atomicAdd(&A.rowcnt[j], 1);
         }
         base += __popcll(km);
@@ -374,7 +386,20 @@ constexpr int NGRP = 64 / GRP;          // raters per wave and step
 // raters (158 on average at BASELINE configs[1], against 6 in the smallest class): NW waves share one table there
 // (4 for 1024 slots, 2 for 512), each taking every NW-th block of 64 raters, which keeps 20 waves per CU in flight
 // instead of 5.
-template <int METHOD, int LOG_SLOTS, int NW>
+// LS (RecommenderSim, core/recommenderSim.py:90-133): nothing is filtered, a row may pair with itself (an item twice
+// in one profile), and every pair also gets its leave-one-out local sensitivity, which needs the FINAL inner product
+// and count of the pair: after the accumulation pass the slots are finalised in LDS and the raters are walked a
+// second time, each co-rating looking its slot up and raising the slot's maximum (bit pattern of a non-negative
+// double, NaN above everything: np.max propagates NaN).
+__device__ __forceinline__ double weighted(double cs, int n, int cap) {
+    const int mn = n < cap ? n : cap;
+    return 1.0 * cs * (double)mn / (double)cap;
+}
+__device__ __forceinline__ unsigned long long ls_key(double d) {
+    return (d != d) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(d);
+}
+
+template <int METHOD, int LOG_SLOTS, int NW, bool LS>
 __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     constexpr int SLOTS_ = 1 << LOG_SLOTS;
     constexpr bool ADJ = METHOD == XMAP_ADJUST_COSINE;
@@ -384,7 +409,10 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     __shared__ double dlo[ADJ ? SLOTS_ : 1];
     __shared__ unsigned short claim[ADJ && NW == 1 ? SLOTS_ : 1];
     __shared__ unsigned lockw[ADJ && NW > 1 ? SLOTS_ : 1];
+    __shared__ double s_ny[LS ? SLOTS_ : 1];              // LS: norm of the partner
+    __shared__ unsigned long long s_ls[LS ? SLOTS_ : 1];  // LS: running maximum (ls_key)
     __shared__ int s_ovf;
+    static_assert(!LS || ADJ, "the local-sensitivity pass keeps the similarity in dlo[]");
 
     const int lane = lane_id();
     const long long unit = A.unit_lo + blockIdx.x;
@@ -408,94 +436,104 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     const int p1 = uniform((int)A.iptr[i + 1]);
     const int g = lane / GRP, sub = lane % GRP;
     int ovf = 0;
-    for (int base = p0 + 64 * w; base < p1; base += 64 * NW) {
-        const int p = base + lane;
-        int e0 = 0, pw = 0;
-        float r = 0.f;
-        double au = 0.0;
-        if (p < p1) {
-            const RaterRec rr = A.rc[p];
-            e0 = rr.e0; pw = rr.pos_ge; r = rr.rating;
-            if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[rr.user];
-        }
-        const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
-        // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
-        int nb0 = 0, nb1 = 0, npw = 0, njw = 0;
-        float nrj = 0.f;
-        {
-            const int t = g;
-            nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
-            nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
-            if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
-        }
-        for (int t0 = 0; t0 < nr; t0 += NGRP) {
-            const int t = t0 + g;                    // this lane group's rater
-            const int b0 = nb0, b1 = nb1, pwt = npw;
-            int jw = njw;
-            float rj = nrj;
-            if (t0 + NGRP < nr) {
-                const int tn = t + NGRP;
-                nb0 = __shfl(e0, tn, 64); npw = __shfl(pw, tn, 64);
-                nb1 = (tn < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
+
+    // walk(body): every co-rating of this unit's raters (those of hash partition q); body(act, j, jw, rj, ri, a, gei)
+    // runs once per lane and inner step.  Wave w takes every NW-th block of 64 raters.
+    auto walk = [&](auto &&body) {
+        for (int base = p0 + 64 * w; base < p1; base += 64 * NW) {
+            const int p = base + lane;
+            int e0 = 0, pw = 0;
+            float r = 0.f;
+            double au = 0.0;
+            if (p < p1) {
+                const RaterRec rr = A.rc[p];
+                e0 = rr.e0; pw = rr.pos_ge; r = rr.rating;
+                if (ADJ) au = A.u_avg[rr.user];
+            }
+            const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
+            // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
+            int nb0 = 0, nb1 = 0, npw = 0, njw = 0;
+            float nrj = 0.f;
+            {
+                const int t = g;
+                nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
+                nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
                 if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
             }
-            const double ri = (double)__shfl(r, t, 64);
-            const double a = (METHOD == XMAP_ADJUST_COSINE) ? __shfl(au, t, 64) : 0.0;
-            const unsigned gei = ((unsigned)pwt) >> 31;
-            for (int e = b0 + sub; __ballot(e < b1); e += GRP) {
-                bool act = e < b1;
-                if (act && e >= b0 + GRP) { const int2 v = A.ub[e]; jw = v.x; rj = __int_as_float(v.y); }
-                const int j = jw & 0x7fffffff;
-                if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
-                uint32_t h = 0;
-                if (act) {
-                    h = ((uint32_t)j * 0x9E3779B1u) >> (32 - LOG_SLOTS);
-                    int probes = 0;
-                    for (;;) {
-                        uint32_t prev = atomicCAS(&key[h], T_EMPTY, (uint32_t)j);
-                        if (prev == T_EMPTY || prev == (uint32_t)j) break;
-                        h = (h + 1) & (SLOTS_ - 1);
-                        if (++probes >= SLOTS_) { act = false; ovf = 1; break; }
+            for (int t0 = 0; t0 < nr; t0 += NGRP) {
+                const int t = t0 + g;                    // this lane group's rater
+                const int b0 = nb0, b1 = nb1, pwt = npw;
+                int jw = njw;
+                float rj = nrj;
+                if (t0 + NGRP < nr) {
+                    const int tn = t + NGRP;
+                    nb0 = __shfl(e0, tn, 64); npw = __shfl(pw, tn, 64);
+                    nb1 = (tn < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
+                    if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
+                }
+                const double ri = (double)__shfl(r, t, 64);
+                const double a = ADJ ? __shfl(au, t, 64) : 0.0;
+                const unsigned gei = ((unsigned)pwt) >> 31;
+                for (int e = b0 + sub; __ballot(e < b1); e += GRP) {
+                    bool act = e < b1;
+                    if (act && e >= b0 + GRP) { const int2 v = A.ub[e]; jw = v.x; rj = __int_as_float(v.y); }
+                    const int j = jw & 0x7fffffff;
+                    if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
+                    body(act, j, jw, rj, ri, a, gei);
+                }
+            }
+        }
+    };
+
+    // pass 1: accumulate n_ij, mutuality and the dot product per partner
+    walk([&](bool act, int j, int jw, float rj, double ri, double a, unsigned gei) {
+        uint32_t h = 0;
+        if (act) {
+            h = ((uint32_t)j * 0x9E3779B1u) >> (32 - LOG_SLOTS);
+            int probes = 0;
+            for (;;) {
+                uint32_t prev = atomicCAS(&key[h], T_EMPTY, (uint32_t)j);
+                if (prev == T_EMPTY || prev == (uint32_t)j) break;
+                h = (h + 1) & (SLOTS_ - 1);
+                if (++probes >= SLOTS_) { act = false; ovf = 1; break; }
+            }
+        }
+        if (act) {
+            const unsigned long long inc = 1ull | (((((unsigned)jw) >> 31) == gei) ? (1ull << 32) : 0ull);
+            atomicAdd(&cm[h], inc);
+            if (METHOD == XMAP_COSINE) atomicAdd(&dot[h], (1.0 * ri) * (double)rj);   // integer-exact
+        }
+        if (ADJ) {
+            const double term = (ri - a) * ((double)rj - a);
+            // volatile: the sums are shared between lanes (and waves); the compiler must neither forward the
+            // claim / lock store to the load nor hoist the sum loads out of the loop
+            volatile double *vhi = dot, *vlo = dlo;
+            bool pending = act;
+            if (NW == 1) {
+                volatile unsigned short *vclaim = claim;
+                while (__ballot(pending)) {       // lanes that share a slot take turns
+                    if (pending) vclaim[h] = (unsigned short)lane;
+                    if (pending && vclaim[h] == (unsigned short)lane) {
+                        double hi = vhi[h], lo = vlo[h];
+                        dd_add(hi, lo, term);
+                        vhi[h] = hi; vlo[h] = lo;
+                        pending = false;
                     }
                 }
-                if (act) {
-                    const unsigned long long inc = 1ull | (((((unsigned)jw) >> 31) == gei) ? (1ull << 32) : 0ull);
-                    atomicAdd(&cm[h], inc);
-                    if (METHOD == XMAP_COSINE) atomicAdd(&dot[h], (1.0 * ri) * (double)rj);   // integer-exact
-                }
-                if (ADJ) {
-                    const double term = (ri - a) * ((double)rj - a);
-                    // volatile: the sums are shared between lanes (and waves); the compiler must neither forward the
-                    // claim / lock store to the load nor hoist the sum loads out of the loop
-                    volatile double *vhi = dot, *vlo = dlo;
-                    bool pending = act;
-                    if (NW == 1) {
-                        volatile unsigned short *vclaim = claim;
-                        while (__ballot(pending)) {       // lanes that share a slot take turns
-                            if (pending) vclaim[h] = (unsigned short)lane;
-                            if (pending && vclaim[h] == (unsigned short)lane) {
-                                double hi = vhi[h], lo = vlo[h];
-                                dd_add(hi, lo, term);
-                                vhi[h] = hi; vlo[h] = lo;
-                                pending = false;
-                            }
-                        }
-                    } else {
-                        while (__ballot(pending)) {       // a lock per slot: the holder releases in the same pass
-                            if (pending && atomicCAS(&lockw[h], 0u, 1u) == 0u) {
-                                double hi = vhi[h], lo = vlo[h];
-                                dd_add(hi, lo, term);
-                                vhi[h] = hi; vlo[h] = lo;
-                                __threadfence_block();
-                                atomicExch(&lockw[h], 0u);
-                                pending = false;
-                            }
-                        }
+            } else {
+                while (__ballot(pending)) {       // a lock per slot: the holder releases in the same pass
+                    if (pending && atomicCAS(&lockw[h], 0u, 1u) == 0u) {
+                        double hi = vhi[h], lo = vlo[h];
+                        dd_add(hi, lo, term);
+                        vhi[h] = hi; vlo[h] = lo;
+                        __threadfence_block();
+                        atomicExch(&lockw[h], 0u);
+                        pending = false;
                     }
                 }
             }
         }
-    }
+    });
     if (NW > 1) {
         if (ovf) s_ovf = 1;
         __syncthreads();          // all raters are in the table
@@ -503,6 +541,60 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     }
     if (__ballot(ovf)) {
         if (threadIdx.x == 0) atomicOr(&A.counters[2], 1ull);
+        return;
+    }
+    if (LS) {
+        // finalise the slots: an item paired with itself was met once per user holding it twice, the reference lists
+        // both orders (recommenderSim.py:71-72): count and inner product double (exactly)
+        const double nx = A.nrm[i];
+        for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
+            const uint32_t kj = key[s];
+            if (kj == T_EMPTY) continue;
+            int n = (int)(cm[s] & 0xffffffffull);
+            double inner = dot[s];
+            if ((int)kj == i) { n *= 2; inner *= 2.0; }
+            const double ny = A.nrm[kj];
+            const double np = nx * ny;
+            cm[s] = (unsigned long long)(unsigned)n;
+            dot[s] = inner;
+            dlo[s] = weighted((np != 0.0) ? 1.0 * inner / np : 0.0, n, A.cap);   // NaN != 0: divides, like the reference
+            s_ny[s] = ny;
+            s_ls[s] = 0ull;
+        }
+        if (NW > 1) __syncthreads();
+        // pass 2: leave-one-out variants (recommenderSim.py:98-116)
+        walk([&](bool act, int j, int jw, float rj, double ri, double a, unsigned gei) {
+            if (!act) return;
+            uint32_t h = ((uint32_t)j * 0x9E3779B1u) >> (32 - LOG_SLOTS);
+            while (key[h] != (uint32_t)j) h = (h + 1) & (SLOTS_ - 1);
+            const double inner = dot[h], sim = dlo[h], ny = s_ny[h];
+            const int n = (int)cm[h];
+            const double r0 = ri, r1 = (double)rj;
+            const double rest = inner - r0 * r1;
+            const double m1 = sqrt((nx * nx - r0 * r0) * (ny * ny));
+            const double m2 = sqrt((nx * nx) * (ny * ny - r1 * r1));
+            const double d1 = fabs(weighted((m1 != 0.0) ? 1.0 * rest / m1 : 0.0, n - 1, A.cap) - sim);
+            const double d2 = fabs(weighted((m2 != 0.0) ? 1.0 * rest / m2 : 0.0, n - 1, A.cap) - sim);
+            const unsigned long long k1 = ls_key(d1), k2 = ls_key(d2);
+            atomicMax(&s_ls[h], k1 > k2 ? k1 : k2);
+        });
+        if (NW > 1) __syncthreads();
+        append_pairs(A, i, w * (SLOTS_ / NW), (w + 1) * (SLOTS_ / NW),
+            [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
+                const uint32_t kj = key[s];
+                o = kj != T_EMPTY;
+                if (!o) return false;
+                j = (int)kj; n = (int)cm[s]; m = 0; sv = dlo[s];
+                return true;
+            },
+            [&](int s, bool o, bool keep, double sv) {},
+            [&](int s, int &j, int &n, int &m, double &sv) {
+                const uint32_t kj = key[s];
+                if (kj == T_EMPTY) return false;
+                j = (int)kj; n = (int)cm[s]; m = 0; sv = dlo[s];
+                return true;
+            },
+            [&](int s) { return __longlong_as_double((long long)s_ls[s]); });
         return;
     }
     append_pairs(A, i, w * (SLOTS_ / NW), (w + 1) * (SLOTS_ / NW),
@@ -523,7 +615,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             unsigned long long c = cm[s];
             j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32); sv = dot[s];
             return true;
-        });
+        },
+        [&](int s) { return 0.0; });
 }
 
 // rows of H: chunk c of the raters, dense table over H (partners of a heavy row are heavier, hence in H)
@@ -645,25 +738,30 @@ __global__ __launch_bounds__(256) void k_heavy_merge(TriArgs A, int n_heavy) {
             if (cnt[s] == 0) return false;
             j = A.hlist[s]; n = (int)cnt[s]; m = (int)mut[s]; sv = dot[s];
             return true;
-        });
+        },
+        [&](int s) { return 0.0; });
 }
 
 // Mirror the half COO into the CSR.  Records of one unit are contiguous and share the lighter item i, so the
 // i-side cursor is bumped once per run of equal i inside a wave and those writes are coalesced; the j-side
 // (heavier item) writes are scattered.
 __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, const int *coo_j, const double *coo_sim,
-                                                 const int *coo_mutu, const int *coo_nij, const long long *row_ptr,
-                                                 int *fill, int *col, double *sim, int *mutu, int *nij) {
+                                                 const int *coo_mutu, const int *coo_nij, const double *coo_aux,
+                                                 const long long *row_ptr, int *fill, int *col, double *sim, int *mutu,
+                                                 int *nij, double *aux) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = lane_id();
     const bool act = r < n;
     int i = -1 - lane, j = 0, m = 0, nn = 0;   // inactive lanes: unique fake rows
-    double s = 0.0;
+    double s = 0.0, x = 0.0;
     bool valid = false;
     if (act) {
         int ii = coo_i[r];
         valid = ii >= 0;
-        if (valid) { i = ii; j = coo_j[r]; s = coo_sim[r]; m = coo_mutu[r]; nn = coo_nij[r]; }
+        if (valid) {
+            i = ii; j = coo_j[r]; s = coo_sim[r]; m = coo_mutu[r]; nn = coo_nij[r];
+            if (coo_aux) x = coo_aux[r];
+        }
     }
     const int prev = __shfl_up(i, 1, 64);
     const bool leader = (lane == 0) || (prev != i);
@@ -679,8 +777,12 @@ __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, 
     if (valid) {
         const long long a = row_ptr[i] + base + (lane - lead);
         col[a] = j; sim[a] = s; mutu[a] = m; nij[a] = nn;
-        const long long b = row_ptr[j] + atomicAdd(&fill[j], 1);
-        col[b] = i; sim[b] = s; mutu[b] = m; nij[b] = nn;
+        if (aux) aux[a] = x;
+        if (j != i) {   // (a row paired with itself -- RecommenderSim -- is one entry)
+            const long long b = row_ptr[j] + atomicAdd(&fill[j], 1);
+            col[b] = i; sim[b] = s; mutu[b] = m; nij[b] = nn;
+            if (aux) aux[b] = x;
+        }
     }
 }
 
@@ -693,7 +795,7 @@ extern "C" {
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]: CH, n_heavy*/, int32_t *hid, int32_t *hlist /*[1024]*/,
                      uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] 8 B*/, void *rc /*[nnz] 16 B*/,
-                     int32_t *h_ctl /*[2]*/) {
+                     int32_t dups, int32_t *h_ctl /*[2]*/) {
     XM_ARG(R && info && hist && pre && ctl && hid && hlist && ub_key && ub && rc && ch_min >= 64);
     XM_ARG(R->nnz < 0x7fffffffLL && R->n_users < 0x7ffffff0LL);
     hipStream_t st = (hipStream_t)stream;
@@ -725,9 +827,12 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
         XM_LAUNCH_CHECK();
     }
     if (R->nnz > 0) {
+        // profiles that may hold an item twice: the sort is done with ub_key, which then serves as the (zeroed) copy
+        // counters of k_rater_records
+        if (dups) XM_HIP(hipMemsetAsync(ub_key, 0, sizeof(int32_t) * (size_t)R->nnz, st));
         k_rater_records<<<dim3((unsigned)((R->nnz + 255) / 256)), dim3(256), 0, st>>>(
             I, R->nnz, (const long long *)R->item_ptr, R->item_user, (const long long *)R->user_ptr, (const int2 *)ub,
-            (RaterRec *)rc);
+            (RaterRec *)rc, dups ? (int *)ub_key : nullptr);
         XM_LAUNCH_CHECK();
     }
     if (h_ctl) {
@@ -743,7 +848,7 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
 
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp /*[I] out*/,
-                   int32_t *Qcat /*[4 I]*/, int64_t *uq_ptr /*[4 I + 1]*/, int64_t *uc_ptr,
+                   int32_t *Qcat /*[4 I]*/, int64_t *uq_ptr /*[4 I + 1]*/, int64_t *uc_ptr, int32_t dups,
                    int64_t *h_counts /*[7]: light units, heavy units, first unit of table class rank 0..3, light units*/) {
     XM_ARG(R && rc && Wp && pre && hid && ctl && Q && C && small && Qcat && uq_ptr && uc_ptr && h_counts);
     XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
@@ -753,7 +858,7 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
     if (I > 0) {
         k_plan2<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(
             I, (const long long *)R->item_ptr, (const RaterRec *)rc, (const long long *)pre, (int)R->n_users + 2, hid, ctl,
-            slot_target, Q, C, small, (unsigned long long *)Wp, Qcat);
+            slot_target, dups, Q, C, small, (unsigned long long *)Wp, Qcat);
         XM_LAUNCH_CHECK();
     }
     int rcode = xmap_exclusive_scan_i32_to_i64(stream, Qcat, uq_ptr, (int64_t)N_CLASSES * I, &h_counts[0]);
@@ -784,14 +889,18 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
-                    int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, int32_t *rowcnt,
-                    int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/, int64_t *d_counters /*[4]*/) {
+                    int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, double *coo_ls /*or NULL*/,
+                    int32_t *rowcnt, int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/,
+                    int64_t *d_counters /*[4]*/) {
     XM_ARG(R && u_avg && norms && rc && ub);
     XM_ARG(Q && small && uq_item && uq_q && cls_ptr && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && rowcnt_h && d_shards && d_counters);
     XM_ARG(coo_cap >= COO_SHARDS);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
     XM_ARG(n_heavy_units == 0 || !(phases & 5) || (hp_hi && hp_lo && hp_cnt && hp_mut));
+    // coo_ls selects the RecommenderSim variant: exact (double-double) sums, no filter, local sensitivity; its layout
+    // has no heavy rows
+    XM_ARG(!coo_ls || (method == XMAP_ADJUST_COSINE && n_heavy_units == 0));
     hipStream_t st = (hipStream_t)stream;
     if (phases & 8) {   // reset the COO cursor / counters / row counts
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
@@ -810,6 +919,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.hp_hi = hp_hi; A.hp_lo = hp_lo; A.hp_cnt = hp_cnt; A.hp_mut = hp_mut;
     A.shard_cap = coo_cap / COO_SHARDS; A.shard_cur = (unsigned long long *)d_shards;
     A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
+    A.coo_aux = coo_ls;
     A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials
         if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
@@ -824,16 +934,21 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
             if (hi <= lo) continue;
             A.unit_lo = lo; A.unit_hi = hi;
             const dim3 grid((unsigned)(hi - lo));
-            if (method == XMAP_COSINE) {
-                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 4><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_COSINE, 9, 2><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_COSINE, 8, 1><<<grid, dim3(64), 0, st>>>(A);
-                else k_pair_tri<XMAP_COSINE, 7, 1><<<grid, dim3(64), 0, st>>>(A);
+            if (coo_ls) {
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, true><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, true><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, true><<<grid, dim3(64), 0, st>>>(A);
+                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, true><<<grid, dim3(64), 0, st>>>(A);
+            } else if (method == XMAP_COSINE) {
+                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
+                else k_pair_tri<XMAP_COSINE, 7, 1, false><<<grid, dim3(64), 0, st>>>(A);
             } else {
-                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1><<<grid, dim3(64), 0, st>>>(A);
-                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
+                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, false><<<grid, dim3(64), 0, st>>>(A);
             }
             XM_LAUNCH_CHECK();
         }
@@ -852,16 +967,19 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
 }
 
 int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
-                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *row_ptr,
-                      int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist, int32_t *col, double *sim,
-                      int32_t *mutu, int32_t *nij) {
+                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_ls /*or NULL*/,
+                      const int64_t *row_ptr, int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist,
+                      int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *ls /*or NULL*/) {
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && row_ptr && fill && hid && hlist && col && sim && mutu && nij);
+    XM_ARG((coo_ls != nullptr) == (ls != nullptr));
     hipStream_t st = (hipStream_t)stream;
     XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
     if (n_coo > 0) {
-        // (an LDS histogram that bumps the heavy items' cursors once per workgroup was measured slower: 2.9 vs 2.4 ms)
+        // the kernel is bound by its partial-sector writes (PMC: 7.2 GB moved for 1.7 GB), not by the cursor atomics:
+        // an LDS histogram bumping the heavy items' cursors once per workgroup was slower (2.9 vs 2.4 ms), 64
+        // replicated cursors per heavy item changed nothing
         k_scatter<<<dim3((unsigned)((n_coo + 255) / 256)), dim3(256), 0, st>>>(
-            n_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, (const long long *)row_ptr, fill, col, sim, mutu, nij);
+            n_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_ls, (const long long *)row_ptr, fill, col, sim, mutu, nij, ls);
         XM_LAUNCH_CHECK();
     }
     return XMAP_OK;

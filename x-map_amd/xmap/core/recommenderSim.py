@@ -1,8 +1,9 @@
 # -*- coding: utf-8 -*-
 """RecommenderSim: second item-item similarity over the AlterEgo profile, with per-pair local sensitivity
-(mirror of reference core/recommenderSim.py:9-195).  Downstream of the hot path; host-side
-Python over RDD-like objects for now -- the pair accumulation is the stage-A kernel family and is the next
-candidate for the GPU."""
+(mirror of reference core/recommenderSim.py:9-195).  calculate_sim runs on the GPU
+(Engine.rec_sim: the stage-A pair machinery with a second walk for the leave-one-out local sensitivity); the
+profile / info helpers around it are host-side Python over RDD-like objects, as in the reference.  cosine_sim and
+adjusted_cosine_sim are kept as the readable per-pair statement of what the kernel computes (used by the CPU tests)."""
 from itertools import combinations
 
 import numpy as np
@@ -86,6 +87,11 @@ class RecommenderSim:
         """reference :188-195.  `"cosine_item" in "adjust_cosine_item"` is true, so (as in the reference) both
         method names take the cosine branch."""
         if "cosine_item" in self.method:
-            return self.produce_pairwise(user_profile).map(lambda line: self.cosine_sim(line, item_info))
+            from ..engine import session      # raises if libxmap_hip.so is missing: no CPU fallback
+            return session.rec_sim_from_profiles(user_profile, self.num_atleast, getattr(user_profile, "ctx", None))
         elif "adjust_cosine_item" in self.method:
             return self.produce_pairwise(user_profile).map(lambda line: self.adjusted_cosine_sim(line, user_info))
+
+    def calculate_sim_host(self, item_profile, user_profile, item_info, user_info):
+        """the per-pair Python statement of calculate_sim (reference :188-195), for tests without a GPU"""
+        return self.produce_pairwise(user_profile).map(lambda line: self.cosine_sim(line, item_info))

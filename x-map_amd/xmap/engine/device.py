@@ -242,8 +242,9 @@ class Engine(object):
         return S
 
     # ---- stage A, second formulation (stage_a2.hip): each unordered pair once, mirrored into the CSR
-    def tri_layout(self, stats, slot_target=640, ch_min=1024):
-        """weight-sorted private profiles, rater records, heavy set, work units (method independent)"""
+    def tri_layout(self, stats, slot_target=640, ch_min=1024, dups=False):
+        """weight-sorted private profiles, rater records, heavy set, work units (method independent).
+        dups: a profile may hold an item more than once (AlterEgo rows)."""
         R = self.R
         st = _stream(self.dev)
         I, U, nnz = R.n_items, R.n_users, R.nnz
@@ -258,10 +259,12 @@ class Engine(object):
         L.ub = self._empty(max(nnz, 1), torch.int64)           # (item | flag, rating bits) pairs
         L.rc = self._empty(max(nnz, 1) * 2, torch.int64)       # 16-byte rater records
         L.Wp = self._empty(max(I, 1), torch.int64)
+        L.dups = bool(dups)
         h_ctl = (C.c_int32 * 2)()
         with self.timed("tri_layout"):
             check(lib.xmap_sim2_layout(st, C.byref(R.c), vp(info), i32(ch_min), vp(L.hist), vp(L.pre), vp(L.ctl),
-                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub), vp(L.rc), h_ctl))
+                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub), vp(L.rc), i32(1 if dups else 0),
+                                       h_ctl))
         L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
         L.slot_target = slot_target
         self._tri_plan(L, slot_target)
@@ -283,7 +286,7 @@ class Engine(object):
         with self.timed("tri_plan"):
             check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.rc), vp(L.pre), vp(L.hid),
                                      vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.Wp), vp(L.Qcat), vp(L.uq_ptr),
-                                     vp(L.uc_ptr), h))
+                                     vp(L.uc_ptr), i32(1 if getattr(L, "dups", False) else 0), h))
             L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
             L.cls_ptr = (C.c_int64 * 5)(*[int(h[2 + c]) for c in range(5)])
             L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
@@ -294,8 +297,9 @@ class Engine(object):
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
-    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True):
-        """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows)"""
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False):
+        """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
+        rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity)."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -311,6 +315,7 @@ class Engine(object):
             coo_sim = self._empty(cap_coo, torch.float64)
             coo_mutu = self._empty(cap_coo, torch.int32)
             coo_nij = self._empty(cap_coo, torch.int32)
+            coo_ls = self._empty(cap_coo, torch.float64) if rec else None
             rowcnt = self._empty(max(I, 1), torch.int32)
             nh = L.n_heavy_units if do_heavy else 0
             hp_hi = self._empty(max(nh, 1) * 1024, torch.float64)
@@ -328,7 +333,7 @@ class Engine(object):
                     vp(L.uq_q), L.cls_ptr, i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
-                    vp(coo_mutu), vp(coo_nij), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
+                    vp(coo_mutu), vp(coo_nij), vp(coo_ls), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
             with self.timed("pair_heavy"):
                 run(8 | (1 if do_heavy else 0))
             with self.timed("pair_tri"):
@@ -351,7 +356,8 @@ class Engine(object):
             break
         sh = d_shards.view(2, 4096).sum(dim=1).tolist()
         n, n_unordered = int(sh[0]), int(sh[1])
-        out = ((coo_i, coo_j, coo_sim, coo_mutu, coo_nij), rowcnt, n, n_unordered)
+        coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if rec else ())
+        out = (coo, rowcnt, n, n_unordered)
         return out if retry else out + (0,)
 
     def tri_scatter(self, coo, rowcnt, info, n=None, L=None):
@@ -359,13 +365,16 @@ class Engine(object):
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
-        coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo]
+        coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo[:5]]
+        coo_ls = coo[5].contiguous() if len(coo) > 5 else None
         n_scan = int(coo_i.numel())
         if n is None:
             n = n_scan
         row_ptr = self._zeros(I + 1, torch.int64)
-        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rowcnt), vp(row_ptr), i64(I), None))
-        kept = 2 * n
+        tot = C.c_int64(0)
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rowcnt), vp(row_ptr), i64(I), C.byref(tot) if coo_ls is not None else None))
+        kept = 2 * n if coo_ls is None else int(tot.value)      # a row paired with itself is one entry
+        ls = self._empty(max(kept, 1), torch.float64) if coo_ls is not None else None
         col = self._empty(max(kept, 1), torch.int32)
         sim = self._empty(max(kept, 1), torch.float64)
         mutu = self._empty(max(kept, 1), torch.int32)
@@ -374,9 +383,32 @@ class Engine(object):
         with self.timed("scatter"):
           if n:
             check(lib.xmap_sim2_scatter(st, i32(I), i64(n_scan), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu),
-                                        vp(coo_nij), vp(row_ptr), vp(fill), vp(L.hid), vp(L.hlist), vp(col), vp(sim), vp(mutu),
-                                        vp(nij)))
-        return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
+                                        vp(coo_nij), vp(coo_ls), vp(row_ptr), vp(fill), vp(L.hid), vp(L.hlist), vp(col),
+                                        vp(sim), vp(mutu), vp(nij), vp(ls)))
+        S = self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
+        S.ls = ls[:kept] if ls is not None else None
+        return S
+
+    def rec_sim(self, cap, slot_target=640):
+        """RecommenderSim.calculate_sim (reference core/recommenderSim.py:65-133,188-195; both method names take the
+        cosine branch) over this engine's ratings, which are AlterEgo rows: weighted cosine and leave-one-out local
+        sensitivity of every directed item pair with a co-rater, CSR by first item (col, sim, nij, ls).  The same
+        pair machinery as stage A: exact (double-double) sums with a zero user average, no heavy set."""
+        R = self.R
+        st = _stream(self.dev)
+        with self.timed("rec_stats"):
+            self.build_csc()
+            zero_avg = self._zeros(max(R.n_users, 1), torch.float64)
+            info = self._zeros((max(R.n_items, 1), 4), torch.float64)
+            self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
+            check(lib.xmap_item_stats(st, C.byref(R.c), vp(zero_avg), vp(info), vp(self.norms), None, None))
+        stats = (zero_avg, None, info, None, None)
+        L = self.tri_layout(stats, slot_target, ch_min=max(64, R.n_users + 2), dups=True)
+        coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
+        S = self.tri_scatter(coo, rowcnt, info, n, L)
+        S.cap, S.n_unordered, S.layout = int(cap), n_unordered, L
+        S.norm = self.norms[R.n_items:2 * R.n_items]
+        return S
 
     def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
         """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU)."""

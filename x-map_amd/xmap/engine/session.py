@@ -83,6 +83,45 @@ class SimPairsRDD(LocalRDD):
                 for a, b, s, m, f, lab in zip(rows, col, sim, mutu, frac, label)]
 
 
+class RecSimRDD(LocalRDD):
+    """alterEgo_sim of recommender_calculate_sim_pipeline: ((iid1, iid2), [sim, local sensitivity]) -- rows live in
+    HBM (Engine.rec_sim); both directions of every pair, an item paired with itself once."""
+
+    def __init__(self, S, iids, ctx=None):
+        LocalRDD.__init__(self, None, ctx, self._rows)
+        self.S, self.iids = S, iids
+
+    def _rows(self):
+        S, iids = self.S, self.iids
+        row_ptr = S.row_ptr.cpu().numpy()
+        rows = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))
+        col = S.col.cpu().numpy()
+        o = np.lexsort((col, rows))        # canonical order: (iid1, iid2) ascending
+        sim, ls = S.sim.cpu().numpy()[o], S.ls.cpu().numpy()[o]
+        return [((iids[a], iids[b]), [float(s), float(l)]) for a, b, s, l in zip(rows[o], col[o], sim, ls)]
+
+
+def rec_sim_from_profiles(user_profiles, cap, ctx=None):
+    """user_profiles: [(uid, [(iid, rating, time)*])*] (the user-based AlterEgo profile).  Builds the index space
+    (items in lexicographic id order), uploads the CSR and runs Engine.rec_sim."""
+    import torch
+    from . import device
+    recs = records_of(user_profiles)
+    iids = sorted({t[0] for _, prof in recs for t in prof})
+    iidx = {s: k for k, s in enumerate(iids)}
+    ptr = np.zeros(len(recs) + 1, np.int64)
+    item, rating = [], []
+    for k, (_, prof) in enumerate(recs):
+        ptr[k + 1] = ptr[k] + len(prof)
+        item.extend(iidx[t[0]] for t in prof)
+        rating.extend(float(t[1]) for t in prof)
+    dev = "cuda:%d" % torch.cuda.current_device()
+    R = device.DeviceRatings(ptr, np.asarray(item, np.int32), np.asarray(rating, np.float32),
+                             np.zeros(len(item), np.int64), len(iids), xids.item_attrs(iids), dev)
+    S = device.Engine(R).rec_sim(cap)
+    return RecSimRDD(S, iids, ctx)
+
+
 class ExtendedSimRDD(LocalRDD):
     """extended_simRDD: (start_iid, [(end_iid, xsim)*]) -- candidate lists live in HBM."""
 
