@@ -144,6 +144,68 @@ def bench_dense(args, rank, world, local, dist):
         print(json.dumps(out), flush=True)
 
 
+def bench_recsim(args, rank, world, local, dist):
+    """--workload recsim: RecommenderSim.calculate_sim over the AlterEgo rows the hot path produces at
+    BASELINE configs[1] (one GPU; the rows come out of one untimed pass of the three pipelines)."""
+    from xmap.engine import device, synth, ids
+    dev = "cuda:%d" % local
+    r = synth.config_c2()
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev))
+    S = eng.item_sim(args.method, CAP)
+    E = eng.extend(S, args.k or 50)
+    _, _, mp = eng.select(E, True)
+    G = eng.alterego(mp)
+    u, it, ra = G.user.cpu().numpy(), G.item.cpu().numpy(), G.rating.cpu().numpy()
+    del eng, S, E, G
+    torch.cuda.empty_cache()
+    o = np.argsort(u, kind="stable")
+    uu, uinv = np.unique(u[o], return_inverse=True)
+    ii, iinv = np.unique(it[o], return_inverse=True)
+    ptr = np.zeros(len(uu) + 1, np.int64)
+    np.cumsum(np.bincount(uinv, minlength=len(uu)), out=ptr[1:])
+    all_ids = r.item_ids()
+    iids = [all_ids[x] for x in ii]
+    item, rating = iinv.astype(np.int32), ra[o].astype(np.float32)
+    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), ids.item_attrs(iids), dev)
+    eng = device.Engine(R)
+    log("recsim: AlterEgo rows %d, users %d, items %d" % (len(item), len(uu), len(iids)))
+    for _ in range(args.warmup):
+        eng.rec_sim(CAP)
+    torch.cuda.synchronize()
+    eng.timers = {}
+    t0 = time.time()
+    for _ in range(args.steps):
+        S = eng.rec_sim(CAP)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    tm = eng.timer_ms()
+    D = int(S.row_ptr[-1].item())
+    tri_ms = float(np.mean(tm["pair_tri"]))
+    nnz, I, P = len(item), len(iids), 2 * S.layout.half_contrib
+    # two walks over the co-ratings (accumulate, then the leave-one-out variants): 2 x (8 B per contribution it processes +
+    # rater records and profile copy once) + norms + 32 B per unordered pair written
+    bytes_tri = 2.0 * (8.0 * S.layout.half_contrib + 16.0 * nnz) + 8.0 * I + 32.0 * S.n_unordered
+    ach = bytes_tri / (tri_ms * 1e-3) / 1e9
+    out = {"metric": "recsim_pairs_per_s", "value": D * args.steps / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "RecommenderSim over the AlterEgo rows of BASELINE configs[1] (k=%d, private mapping)" % (args.k or 50),
+                      "rows": nnz, "users": len(uu), "items": I, "P_contributions": P, "D_pairs": D},
+           "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+           "roofline": {"bound": "hbm", "kernel": "k_pair_tri<LS>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms}}
+    if not args.no_cpu:
+        from oracle import xmap_oracle as xo
+        users = min(len(uu), 500000)           # bounded sample: the first users' rows (a closed sub-problem)
+        t0 = time.time()
+        O = xo.rec_sim(ptr[:users + 1], item[:ptr[users]], rating[:ptr[users]], I, CAP)
+        dt = time.time() - t0
+        out["cpu_baseline"] = dict(value=float(O.row_ptr[-1]) / dt, unit="pairs/s", cores=1, kind="port",
+                                   sample="oracle rec_sim on the rows of the first %d users: %d pairs in %.1f s, 1 thread"
+                                          % (users, int(O.row_ptr[-1]), dt))
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +237,9 @@ def main():
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
 
+    if args.workload == "recsim":
+        bench_recsim(args, rank, world, local, dist)
+        return
     if args.workload == "dense":
         bench_dense(args, rank, world, local, dist)
         if dist:

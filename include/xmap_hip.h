@@ -121,12 +121,13 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
  *            ascending user order), the heavy set H = items with more than CH raters (|H| <= 1024; ctl[0] = CH >=
  *            ch_min, ctl[1] = |H|), pre[v] = #items with fewer than v raters.
  *   plan   : W+[i] = contributions of row i (sum of its raters' prefix lengths); Q[i] hash partitions for light rows,
- *            small[i] = LDS table class of the row (1: 128 slots, 3: 256, 2: 512, 0: 1024), C[i] rater chunks for
+ *            small[i] = LDS table class of the row (1: 128 slots, 3: 256, 2: 512, 0: 1024, 4: 1024 shared by 16 waves
+ *            for light rows with >= 2048 raters), C[i] rater chunks for
  *            rows of H.  The light units are listed class-major (largest tables first): Qcat[rank][i] = Q[i] in the
  *            row's class rank, uq_ptr = exclusive scan over Qcat; h_counts = {light units, heavy units, first unit
- *            of class rank 0..3, light units} (cls_ptr of xmap_sim2_pairs = h_counts + 2).
+ *            of class rank 0..4, light units} (cls_ptr of xmap_sim2_pairs = h_counts + 2).
  *   pairs  : phases bit 8 = reset counters/rowcnt, 1 = k_pair_heavy (chunk partials of the rows of H), 2 = k_pair_tri
- *            (light units [unit_lo, unit_hi), one launch per table class; 4 / 2 waves share a 1024 / 512-slot table),
+ *            (light units [unit_lo, unit_hi), one launch per table class; 16 / 4 / 2 waves share a 1024 / 1024 / 512-slot table),
  *            4 = k_heavy_merge, 16 = fold the heavy items' row-count replicas (last);
  *            kept pairs (i lighter, j heavier) ->
  *            half COO: coo_cap entries cut into 4096 shards with a cursor each (d_shards[0][s]; unused entries keep
@@ -141,13 +142,13 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
                      int32_t dups /*1: a profile may hold an item more than once (AlterEgo rows)*/, int32_t *h_ctl /*[2]*/);
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small /*[I]*/,
-                   uint64_t *Wp /*[I] out: contributions per row*/, int32_t *Qcat /*[4 I]*/, int64_t *uq_ptr /*[4 I + 1]*/,
-                   int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int64_t *h_counts /*[7], host*/);
+                   uint64_t *Wp /*[I] out: contributions per row*/, int32_t *Qcat /*[5 I]*/, int64_t *uq_ptr /*[5 I + 1]*/,
+                   int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int64_t *h_counts /*[8], host*/);
 int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const int64_t *uq_ptr, int32_t *uq_item,
                     int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c);
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
                     const void *rc, const void *ub, const int32_t *Q,
-                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, const int64_t *cls_ptr /*[5], host*/,
+                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, const int64_t *cls_ptr /*[6], host*/,
                     int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,

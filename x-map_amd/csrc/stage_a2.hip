@@ -33,9 +33,12 @@ constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr int SMALL_BOUND = 96;          // rows with at most this many partners use the 128-slot table
 constexpr int MID_BOUND = 384;           // ... at most this many: the 512-slot table
 
-constexpr int N_CLASSES = 4;
-// table class (1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024) -> position in the class-major unit list
-__host__ __device__ __forceinline__ int class_rank(int cls) { return cls == 0 ? 0 : (cls == 2 ? 1 : (cls == 3 ? 2 : 3)); }
+constexpr int N_CLASSES = 5;
+constexpr int WIDE_MIN = 2048;           // light rows with at least this many raters: 16 waves on one 1024-slot table
+// table class (1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024, 4 = 1024 "wide") -> position in the class-major unit list
+__host__ __device__ __forceinline__ int class_rank(int cls) {
+    return cls == 4 ? 0 : (cls == 0 ? 1 : (cls == 2 ? 2 : (cls == 3 ? 3 : 4)));
+}
 
 __device__ __forceinline__ unsigned long long wkey(int n, int item) {
     return ((unsigned long long)(unsigned)n << 32) | (unsigned)item;
@@ -254,7 +257,10 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     Q[i] = q;
     C[i] = c;
     // table class: 1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024
-    const int cls = (q != 1) ? 0 : (bound <= SMALL_BOUND ? 1 : (bound <= 2 * SMALL_BOUND ? 3 : (bound <= MID_BOUND ? 2 : 0)));
+    // rows with very many raters (popular items below the heavy threshold, or every popular item when there is no
+    // heavy set: RecommenderSim) are bound by the walk over their raters, not by the table: class 4
+    const int cls = (q >= 1 && n >= WIDE_MIN) ? 4
+                    : ((q != 1) ? 0 : (bound <= SMALL_BOUND ? 1 : (bound <= 2 * SMALL_BOUND ? 3 : (bound <= MID_BOUND ? 2 : 0))));
     small[i] = (uint8_t)cls;
     Wp[i] = (unsigned long long)w;
     // the light units are listed class-major (largest tables first: their units run longest), so that each table
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     __shared__ unsigned long long cm[SLOTS_];     // n_ij (low 32) | mutuality (high 32)
     __shared__ double dot[SLOTS_];
     __shared__ double dlo[ADJ ? SLOTS_ : 1];
-    __shared__ unsigned short claim[ADJ && NW == 1 ? SLOTS_ : 1];
+    __shared__ unsigned short claim[ADJ && NW == 1 ? SLOTS_ : 1];   // (lane ids; NW > 1 uses lockw)
     __shared__ unsigned lockw[ADJ && NW > 1 ? SLOTS_ : 1];
     __shared__ double s_ny[LS ? SLOTS_ : 1];              // LS: norm of the partner
     __shared__ unsigned long long s_ls[LS ? SLOTS_ : 1];  // LS: running maximum (ls_key)
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     const long long unit = A.unit_lo + blockIdx.x;
     if (unit >= A.unit_hi) return;
     const int i = uniform(A.uq_item[unit]);
-    const int tcls = A.small[i];   // 1: 128 slots, 3: 256, 2: 512, 0: 1024
-    if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : 0)))) return;   // not reached: class-major units
+    const int tcls = A.small[i];   // 1: 128 slots, 3: 256, 2: 512, 0: 1024, 4: 1024 shared by 16 waves
+    if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : (NW == 16 ? 4 : 0))))) return;   // not reached: class-major units
     const int w = threadIdx.x >> 6;
     for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
         key[s] = T_EMPTY; cm[s] = 0ull; dot[s] = 0.0;
@@ -849,7 +855,7 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp /*[I] out*/,
                    int32_t *Qcat /*[4 I]*/, int64_t *uq_ptr /*[4 I + 1]*/, int64_t *uc_ptr, int32_t dups,
-                   int64_t *h_counts /*[7]: light units, heavy units, first unit of table class rank 0..3, light units*/) {
+                   int64_t *h_counts /*[8]: light units, heavy units, first unit of table class rank 0..4, light units*/) {
     XM_ARG(R && rc && Wp && pre && hid && ctl && Q && C && small && Qcat && uq_ptr && uc_ptr && h_counts);
     XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
     hipStream_t st = (hipStream_t)stream;
@@ -884,7 +890,7 @@ int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const in
 
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
                     const void *rc, const void *ub, const int32_t *Q,
-                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, const int64_t *cls_ptr /*host [5]*/,
+                    const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, const int64_t *cls_ptr /*host [6]*/,
                     int64_t unit_lo, int64_t unit_hi, const int32_t *hid,
                     const int32_t *hlist, const int32_t *ctl, const int32_t *C, const int64_t *uc_ptr,
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
@@ -935,19 +941,22 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
             A.unit_lo = lo; A.unit_hi = hi;
             const dim3 grid((unsigned)(hi - lo));
             if (coo_ls) {
-                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, true><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, true><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, true><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, true><<<grid, dim3(1024), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, true><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, true><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 3) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, true><<<grid, dim3(64), 0, st>>>(A);
                 else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, true><<<grid, dim3(64), 0, st>>>(A);
             } else if (method == XMAP_COSINE) {
-                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 16, false><<<grid, dim3(1024), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 3) k_pair_tri<XMAP_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
                 else k_pair_tri<XMAP_COSINE, 7, 1, false><<<grid, dim3(64), 0, st>>>(A);
             } else {
-                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, false><<<grid, dim3(1024), 0, st>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
+                else if (c == 3) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
                 else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, false><<<grid, dim3(64), 0, st>>>(A);
             }
             XM_LAUNCH_CHECK();

@@ -279,16 +279,16 @@ class Engine(object):
         L.Q = self._zeros(max(I, 1), torch.int32)
         L.C = self._zeros(max(I, 1), torch.int32)
         L.small = self._zeros(max(I, 1), torch.uint8)
-        L.Qcat = self._empty(4 * max(I, 1), torch.int32)
-        L.uq_ptr = self._zeros(4 * I + 1, torch.int64)     # light units class-major: [table class rank][item]
+        L.Qcat = self._empty(5 * max(I, 1), torch.int32)
+        L.uq_ptr = self._zeros(5 * I + 1, torch.int64)     # light units class-major: [table class rank][item]
         L.uc_ptr = self._zeros(I + 1, torch.int64)
-        h = (C.c_int64 * 7)()
+        h = (C.c_int64 * 8)()
         with self.timed("tri_plan"):
             check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.rc), vp(L.pre), vp(L.hid),
                                      vp(L.ctl), vp(L.Q), vp(L.C), vp(L.small), vp(L.Wp), vp(L.Qcat), vp(L.uq_ptr),
                                      vp(L.uc_ptr), i32(1 if getattr(L, "dups", False) else 0), h))
             L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
-            L.cls_ptr = (C.c_int64 * 5)(*[int(h[2 + c]) for c in range(5)])
+            L.cls_ptr = (C.c_int64 * 6)(*[int(h[2 + c]) for c in range(6)])
             L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
             L.uq_q = self._empty(max(L.n_light, 1), torch.int32)
             L.uc_item = self._empty(max(L.n_heavy_units, 1), torch.int32)
