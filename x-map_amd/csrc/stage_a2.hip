@@ -796,6 +796,24 @@ __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, 
 
 using namespace xmap;
 
+// forked streams for the per-class pair kernels (created once per process and device; never destroyed)
+struct SideStreams { hipStream_t s[N_CLASSES]; hipEvent_t fork, done[N_CLASSES]; int dev; };
+static SideStreams *side_streams() {
+    static thread_local SideStreams *cur[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return nullptr; }
+    if (cur[dev]) return cur[dev];
+    SideStreams *p = new SideStreams();
+    p->dev = dev;
+    bool ok = hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) == hipSuccess;
+    for (int c = 0; c < N_CLASSES && ok; c++)
+        ok = hipStreamCreateWithFlags(&p->s[c], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&p->done[c], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { set_error("could not create the side streams"); delete p; return nullptr; }
+    cur[dev] = p;
+    return p;
+}
+
 extern "C" {
 
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
@@ -933,33 +951,42 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         XM_LAUNCH_CHECK();
     }
     if ((phases & 2) && unit_hi > unit_lo) {
-        // one launch per table class: the class's units within [unit_lo, unit_hi)
+        // one launch per table class: the class's units within [unit_lo, unit_hi).  The classes are independent (they
+        // only share the COO cursors, which are atomic) and each ends in a tail of long rows at low occupancy: they
+        // run side by side on forked streams and the caller's stream joins them.
+        SideStreams *side = side_streams();
+        if (!side) return XMAP_ERR_HIP;
+        XM_HIP(hipEventRecord(side->fork, st));
         for (int c = 0; c < N_CLASSES; c++) {
             const long long lo = unit_lo > cls_ptr[c] ? unit_lo : cls_ptr[c];
             const long long hi = unit_hi < cls_ptr[c + 1] ? unit_hi : cls_ptr[c + 1];
             if (hi <= lo) continue;
             A.unit_lo = lo; A.unit_hi = hi;
             const dim3 grid((unsigned)(hi - lo));
+            hipStream_t cs = side->s[c];
+            XM_HIP(hipStreamWaitEvent(cs, side->fork, 0));
             if (coo_ls) {
-                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, true><<<grid, dim3(1024), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, true><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, true><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 3) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, true><<<grid, dim3(64), 0, st>>>(A);
-                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, true><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, true><<<grid, dim3(1024), 0, cs>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, true><<<grid, dim3(256), 0, cs>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, true><<<grid, dim3(128), 0, cs>>>(A);
+                else if (c == 3) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, true><<<grid, dim3(64), 0, cs>>>(A);
+                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, true><<<grid, dim3(64), 0, cs>>>(A);
             } else if (method == XMAP_COSINE) {
-                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 16, false><<<grid, dim3(1024), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 3) k_pair_tri<XMAP_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
-                else k_pair_tri<XMAP_COSINE, 7, 1, false><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_COSINE, 10, 16, false><<<grid, dim3(1024), 0, cs>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_COSINE, 10, 4, false><<<grid, dim3(256), 0, cs>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_COSINE, 9, 2, false><<<grid, dim3(128), 0, cs>>>(A);
+                else if (c == 3) k_pair_tri<XMAP_COSINE, 8, 1, false><<<grid, dim3(64), 0, cs>>>(A);
+                else k_pair_tri<XMAP_COSINE, 7, 1, false><<<grid, dim3(64), 0, cs>>>(A);
             } else {
-                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, false><<<grid, dim3(1024), 0, st>>>(A);
-                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, false><<<grid, dim3(256), 0, st>>>(A);
-                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, false><<<grid, dim3(128), 0, st>>>(A);
-                else if (c == 3) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, false><<<grid, dim3(64), 0, st>>>(A);
-                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, false><<<grid, dim3(64), 0, st>>>(A);
+                if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, false><<<grid, dim3(1024), 0, cs>>>(A);
+                else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, false><<<grid, dim3(256), 0, cs>>>(A);
+                else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, false><<<grid, dim3(128), 0, cs>>>(A);
+                else if (c == 3) k_pair_tri<XMAP_ADJUST_COSINE, 8, 1, false><<<grid, dim3(64), 0, cs>>>(A);
+                else k_pair_tri<XMAP_ADJUST_COSINE, 7, 1, false><<<grid, dim3(64), 0, cs>>>(A);
             }
             XM_LAUNCH_CHECK();
+            XM_HIP(hipEventRecord(side->done[c], cs));
+            XM_HIP(hipStreamWaitEvent(st, side->done[c], 0));
         }
         A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     }
