@@ -129,17 +129,14 @@ def test_golden_all_stages(dev, case, method):
             assert np.array_equal(G.time.cpu().numpy(), gold[gtag + ".ae_time"])
 
 
-@pytest.mark.parametrize("method", METHODS)
-def test_c1_vs_oracle(dev, method):
-    """BASELINE configs[0] size (10k users / 2x5k items): every stage against the CPU oracle."""
+def _check_all_stages(dev, r, method, k, private=True, picks_seed=None, **sim_kw):
+    """every stage of one pass against the CPU oracle, bit for bit (ratings of the AlterEgo rows: fp32, atol 1e-5)"""
     from oracle import xmap_oracle as xo
-    from xmap.engine import synth
-    r = synth.config_c1()
     attrs = r.item_attrs()
     eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs)
     T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
     So = xo.item_sim(T, method, CAP, nthreads=8)
-    S = eng.item_sim(method, CAP)
+    S = eng.item_sim_tri(method, CAP, **sim_kw) if sim_kw else eng.item_sim(method, CAP)
     assert S.n_eval == So.n_eval and S.n_contrib == So.n_contrib
     rows, cols, sim, mutu, nij = _sorted_sim(S)
     orow, ocol = csr_to_pairs(So.row_ptr, So.col)
@@ -148,7 +145,6 @@ def test_c1_vs_oracle(dev, method):
     # both sides sum error-free (cosine: integer-exact) -> bit-identical in both modes
     assert np.array_equal(S.info.cpu().numpy(), So.info)
     assert np.array_equal(sim, So.sim)
-    k = 5
     Xo = xo.extend(T, So, k)
     E = eng.extend(S, k, full=True)
     assert np.array_equal(E.bb.cpu().numpy()[:T.I], Xo.bb)
@@ -163,8 +159,17 @@ def test_c1_vs_oracle(dev, method):
     assert np.array_equal(st, ost) and np.array_equal(en, oen)
     # path values are bit-identical and both sides sum them error-free (double-double)
     assert np.array_equal(va, Xo.xs_val)
-    n_top_o, choice_o, m_o = xo.select(T, Xo, True, None)
-    n_top, choice, mp = eng.select(E, True, None)
+    picks = None
+    if not private:
+        n_top_probe, _, _ = xo.select(T, Xo, True, None)
+        np.random.seed(picks_seed)
+        try:
+            picks = dev.draw_picks(np.minimum(n_top_probe, 4))
+        except ValueError:       # a start with a single candidate: the reference's randint(0, 0) raises (generator.py:109)
+            picks = None
+            private = True
+    n_top_o, choice_o, m_o = xo.select(T, Xo, private, picks)
+    n_top, choice, mp = eng.select(E, private, picks)
     assert np.array_equal(n_top.cpu().numpy()[:T.I], n_top_o)
     assert np.array_equal(choice.cpu().numpy()[:T.I], choice_o)
     assert np.array_equal(mp.cpu().numpy()[:T.I], m_o)
@@ -176,6 +181,36 @@ def test_c1_vs_oracle(dev, method):
     assert eng.n_profiles(G) == ae["n_profiles"]
     xo.ext_free(Xo)
     xo.sim_free(So)
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_c1_vs_oracle(dev, method):
+    """BASELINE configs[0] size (10k users / 2x5k items): every stage against the CPU oracle."""
+    from xmap.engine import synth
+    _check_all_stages(dev, synth.config_c1(), method, 5)
+
+
+# a sweep over shapes: sparse / dense, skewed, tiny, one domain much larger, heavy rows forced, many partitions
+SWEEP = [
+    dict(seed=101, users=40, src=15, tgt=15, overlap=0.6, k=2),
+    dict(seed=102, users=300, src=40, tgt=200, overlap=0.3, k=3),
+    dict(seed=103, users=800, src=300, tgt=60, overlap=0.5, k=7, mu=1.6),
+    dict(seed=104, users=1500, src=120, tgt=120, overlap=0.9, k=4, zipf=1.3),
+    dict(seed=105, users=2500, src=900, tgt=900, overlap=0.15, k=10),
+    dict(seed=106, users=600, src=80, tgt=80, overlap=0.4, k=5, mu=2.4, sigma=0.8, sim_kw=dict(ch_min=64)),
+    dict(seed=107, users=1200, src=250, tgt=250, overlap=0.35, k=6, sim_kw=dict(slot_target=32)),
+    dict(seed=108, users=200, src=500, tgt=500, overlap=0.5, k=3, mu=3.0),
+]
+
+
+@pytest.mark.parametrize("cfg", SWEEP, ids=lambda c: "s%d" % c["seed"])
+@pytest.mark.parametrize("method", METHODS)
+def test_shape_sweep_vs_oracle(dev, method, cfg):
+    from xmap.engine import synth
+    kw = {n: cfg[n] for n in ("overlap", "mu", "sigma", "zipf") if n in cfg}
+    r = synth.make_two_domain(cfg["seed"], cfg["users"], cfg["src"], cfg["tgt"], **kw)
+    _check_all_stages(dev, r, method, cfg["k"], private=(cfg["seed"] % 2 == 0), picks_seed=cfg["seed"],
+                      **cfg.get("sim_kw", {}))
 
 
 def test_edge_cases(dev):
