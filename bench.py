@@ -51,7 +51,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(r, attrs, method, target_s=15.0, threads=4):
+def cpu_baseline(r, attrs, method, target_s=15.0, threads=4, k=0):
     """Oracle (CPU restatement, `port`) timed on this host on a bounded row sample of the same workload."""
     from oracle import xmap_oracle as xo
     T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
@@ -77,6 +77,15 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4):
     out = dict(value=S.n_eval / dt, unit="pairs/s", cores=threads, kind="port",
                sample="oracle stage A (item-item sim) on item rows [0,%d) of %d: %d pairs in %.1f s, OpenMP %d threads"
                       % (rows, I, S.n_eval, dt, threads))
+    if rows == I and k:
+        # stage B beside it: the oracle's path enumeration + X-Sim accumulation (one thread, the reference's
+        # (t, s)-centric order) on the source records of a bounded item range; the knn classification before it is not
+        # part of the figure
+        X = xo.extend(T, S, k, s_range=(0, I), max_seconds=8.0)
+        out["stage_b"] = dict(value=X.n_paths / max(X.path_seconds, 1e-9), unit="paths/s", cores=1, kind="port",
+                              sample="oracle extend (k=%d), source records in item order until 8 s have passed: %d paths in %.1f s, 1 thread"
+                                     % (k, X.n_paths, X.path_seconds))
+        xo.ext_free(X)
     xo.sim_free(S)
     return out
 
@@ -330,7 +339,7 @@ def main():
                                  "note": "latency/random-access bound: 32 B double-double read-modify-write per path"},
         }
         if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(r, attrs, args.method)
+            out["cpu_baseline"] = cpu_baseline(r, attrs, args.method, k=k)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

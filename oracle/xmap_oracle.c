@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -312,6 +313,7 @@ typedef struct {
     int64_t *xs_ptr;  /* [I+1] */
     int32_t *xs_end;
     double *xs_val;
+    double path_seconds; /* wall time of the path enumeration + X-Sim loop alone (CPU baseline of stage B) */
 } XoExt;
 
 typedef struct { double a; int32_t j; int64_t pos; } SortEnt;
@@ -407,7 +409,8 @@ typedef struct { int32_t n[4]; int len; } Path;
  * do_paths = 0 stops after the knn classification (B1-B4). */
 XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *prefix_cls,
                  const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
-                 int do_paths) {
+                 int do_paths, int32_t s_lo, int32_t s_hi /* source records [s_lo, s_hi): a bounded sample for the CPU
+                 baseline timing; (0, I) = everything */, double max_seconds /* > 0: stop the sample after this long */) {
     int32_t I = S->I, k = top_k;
     XoExt *X = (XoExt *)calloc(1, sizeof(XoExt));
     X->I = I; X->k = k;
@@ -469,10 +472,18 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
     }
     PMap M; pmap_init(&M, 1 << 16);
     int64_t n_paths = 0;
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     size_t p0cap = 1024;
     Path *P0 = (Path *)malloc(p0cap * sizeof(Path));
     /* B5b-B5e: every SRC record ((t,s), attach(s))   extender.py:61-70,174,176 */
-    for (int32_t s = 0; s < I; s++) {
+    if (s_lo < 0) s_lo = 0;
+    if (s_hi > I || s_hi < 0) s_hi = I;
+    for (int32_t s = s_lo; s < s_hi; s++) {
+        if (max_seconds > 0.0 && (s & 15) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            if ((double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec) > max_seconds) break;
+        }
         if (!(flags[s] & 1) || aptr[s + 1] == aptr[s]) continue; /* "S:" in s, attach(s) non-empty (s is BB by construction) */
         for (int l = 0; l < 2; l++) for (int32_t q = 0; q < X->cnt[(size_t)s * 2 + l]; q++) {
             int32_t t = X->col[((size_t)s * 2 + l) * k + q];       /* v in knn_BB[s].keys() */
@@ -524,6 +535,8 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
     }
     free(P0);
     X->n_paths = n_paths;
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    X->path_seconds = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
     /* B6  extender.py:184-217: xsim = sum(s_p c_p)/sum(c_p), grouped by start; ends ascending (canonical) */
     uint64_t *keys = (uint64_t *)malloc((size_t)(M.n ? M.n : 1) * sizeof(uint64_t));
     uint64_t nk = 0;

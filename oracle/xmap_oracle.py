@@ -36,7 +36,7 @@ class _XoExt(C.Structure):
                 ("cls", C.POINTER(C.c_uint8)), ("cnt", C.POINTER(C.c_int32)),
                 ("col", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double)),
                 ("n_paths", C.c_int64), ("xs_ptr", C.POINTER(C.c_int64)),
-                ("xs_end", C.POINTER(C.c_int32)), ("xs_val", C.POINTER(C.c_double))]
+                ("xs_end", C.POINTER(C.c_int32)), ("xs_val", C.POINTER(C.c_double)), ("path_seconds", C.c_double)]
 
 
 class _XoAlter(C.Structure):
@@ -141,11 +141,14 @@ class Ext(object):
     pass
 
 
-def extend(T, S, top_k, do_paths=True):
-    """Stage B from the oracle's own stage-A handle."""
+def extend(T, S, top_k, do_paths=True, s_range=None, max_seconds=0.0):
+    """Stage B from the oracle's own stage-A handle.  s_range = (lo, hi): paths of the source records in that item
+    range only (a bounded sample for timing; the X-Sim lists are then partial)."""
+    lo, hi = (0, T.I) if s_range is None else (int(s_range[0]), int(s_range[1]))
     h = lib().xo_extend(S._h, C.c_int(top_k), _p(S.info, C.c_double), _p(T.prefix_cls, C.c_int32),
                         _p(T.suffix_cls, C.c_int32), _p(T.contains_mask, C.c_uint32),
-                        _p(T.flags, C.c_uint8), C.c_int(1 if do_paths else 0))
+                        _p(T.flags, C.c_uint8), C.c_int(1 if do_paths else 0), C.c_int32(lo), C.c_int32(hi),
+                        C.c_double(max_seconds))
     x = h.contents
     I, k = T.I, top_k
     out = Ext()
@@ -157,6 +160,7 @@ def extend(T, S, top_k, do_paths=True):
     out.col = _arr(x.col, I * 2 * k, np.int32).reshape(I, 2, k)
     out.val = _arr(x.val, I * 2 * k * 3, np.float64).reshape(I, 2, k, 3)
     out.n_paths = int(x.n_paths)
+    out.path_seconds = float(x.path_seconds)
     out.xs_ptr = _arr(x.xs_ptr, I + 1, np.int64)
     n = int(out.xs_ptr[-1])
     out.xs_end = _arr(x.xs_end, n, np.int32)
