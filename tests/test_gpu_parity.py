@@ -200,6 +200,8 @@ SWEEP = [
     dict(seed=106, users=600, src=80, tgt=80, overlap=0.4, k=5, mu=2.4, sigma=0.8, sim_kw=dict(ch_min=64)),
     dict(seed=107, users=1200, src=250, tgt=250, overlap=0.35, k=6, sim_kw=dict(slot_target=32)),
     dict(seed=108, users=200, src=500, tgt=500, overlap=0.5, k=3, mu=3.0),
+    dict(seed=109, users=900, src=260, tgt=260, overlap=0.5, k=100, mu=1.4),     # BASELINE configs[3]'s top-k
+    dict(seed=110, users=500, src=150, tgt=150, overlap=0.6, k=64),
 ]
 
 
