@@ -14,11 +14,15 @@
 //                                         than CH raters (dense ids)
 //   k_sort_profiles : per-user sort by weight (4 short profiles per wave)
 //   k_rater_records : the rater records of every item; W+_i = number of contributions of row i (k_plan2)
-//   k_plan2 / k_fill_units2 : light units (item, hash partition), heavy units (item in H, chunk of CH raters)
-//   k_pair_tri      : light rows; wave-private LDS hash table as in stage_a.hip, rater records instead of a
-//                     dependent row_ptr hop, prefix-only profile reads; appends kept pairs to a half-COO
-//   k_pair_heavy    : rows of H, raters in chunks, DENSE LDS table over H, partial tables to HBM
-//   k_heavy_merge   : double-double merge of the chunk partials, finalise, append
+//   k_plan2 / k_fill_units2 : light units (item, hash partition) listed by LDS table class, heavy units (item in H,
+//                     chunk of CH raters)
+//   k_pair_tri      : light rows, one launch per table class (on forked streams); LDS hash table sized to the row's
+//                     partner bound and shared by 1 / 2 / 4 / 16 waves, rater records instead of a dependent row_ptr
+//                     hop, prefix-only profile reads; appends kept pairs to a half-COO.  LS = true is the
+//                     RecommenderSim variant (core/recommenderSim.py:65-133): no filter, self pairs, second walk for
+//                     the leave-one-out local sensitivity
+//   k_pair_heavy    : rows of H, raters in chunks (one rater per lane), DENSE LDS table over H, partial tables to HBM
+//   k_heavy_merge   : double-double merge of the chunk partials (4 waves per row), finalise, append
 //   k_scatter       : mirror the half-COO into the CSR rows (atomic cursors)
 // Sums are exact (double-double, or integer-exact in cosine mode), so neither the order of raters nor the
 // chunking changes a bit of the result.
