@@ -187,6 +187,9 @@ def bench_recsim(args, rank, world, local, dist):
         S = eng.rec_sim(CAP)
     torch.cuda.synchronize()
     wall = time.time() - t0
+    for _ in range(args.steps):      # neighbour selection (recommender_privacy_pipeline, non-private): outside the metric
+        eng.rec_select(S, 10)
+    torch.cuda.synchronize()
     tm = eng.timer_ms()
     D = int(S.row_ptr[-1].item())
     tri_ms = float(np.mean(tm["pair_tri"]))
@@ -212,6 +215,7 @@ def bench_recsim(args, rank, world, local, dist):
         out["cpu_baseline"] = dict(value=float(O.row_ptr[-1]) / dt, unit="pairs/s", cores=1, kind="port",
                                    sample="oracle rec_sim on the rows of the first %d users: %d pairs in %.1f s, 1 thread"
                                           % (users, int(O.row_ptr[-1]), dt))
+        xo.rec_free(O)
     print(json.dumps(out), flush=True)
 
 

@@ -294,6 +294,13 @@ int xmap_dense_layout(int32_t n_t, int32_t n_s, int32_t *n_pieces);
 int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const float *Ft, const float *Fs, int32_t top_k,
                     int32_t n_pieces, int32_t *part_idx, float *part_val, int32_t *out_idx, float *out_val);
 
+/* ---- RecommenderPrivacy.nonprivate_neighbor_selection (core/recommenderPrivacy.py:22-35,141-152)
+ * over the RecommenderSim rows (CSR of xmap_sim2_scatter with ls): per item the `keep` (= mapping_range, <= 64)
+ * neighbours by (|sim| desc, neighbour index asc) -- the reference's stable sort keeps the arrival order of equal
+ * similarities, which Spark does not define.  out_col/out_sim/out_ls: [I][keep], unused entries -1 / 0; out_cnt [I]. */
+int xmap_rec_select(void *stream, int32_t n_items, const int64_t *row_ptr, const int32_t *col, const double *sim,
+                    const double *ls, int32_t keep, int32_t *out_cnt, int32_t *out_col, double *out_sim, double *out_ls);
+
 /* ---- stage C: generator_pipeline (utils/assist.py:136-150) ---------------------------------- */
 
 /* Generator.cross_private_mapping / cross_nonprivate_mapping (core/generator.py:27-111) + map_to_dict

@@ -818,3 +818,33 @@ void xo_rec_free(XoRec *S) {
     if (!S) return;
     free(S->row_ptr); free(S->col); free(S->sim); free(S->ls); free(S->nij); free(S->norm); free(S);
 }
+
+/* RecommenderPrivacy.nonprivate_neighbor_selection (core/recommenderPrivacy.py:22-35,141-152) on the rows of
+ * xo_rec_sim: per item the `keep` neighbours with the largest |sim|; equal similarities in ascending neighbour index
+ * (the reference's stable sort keeps their arrival order, which Spark does not define). */
+typedef struct { double a; int32_t c; int64_t p; } RecEnt;
+static int cmp_rec(const void *x, const void *y) {
+    const RecEnt *a = (const RecEnt *)x, *b = (const RecEnt *)y;
+    if (a->a > b->a) return -1;
+    if (a->a < b->a) return 1;
+    return (a->c > b->c) - (a->c < b->c);
+}
+void xo_rec_select(const XoRec *S, int32_t keep, int32_t *out_cnt, int32_t *out_col, double *out_sim, double *out_ls) {
+    int64_t maxlen = 1;
+    for (int32_t i = 0; i < S->I; i++) { int64_t l = S->row_ptr[i + 1] - S->row_ptr[i]; if (l > maxlen) maxlen = l; }
+    RecEnt *e = (RecEnt *)malloc((size_t)maxlen * sizeof(RecEnt));
+    for (int32_t i = 0; i < S->I; i++) {
+        int64_t lo = S->row_ptr[i], n = S->row_ptr[i + 1] - lo;
+        for (int64_t t = 0; t < n; t++) { e[t].a = fabs(S->sim[lo + t]); e[t].c = S->col[lo + t]; e[t].p = lo + t; }
+        qsort(e, (size_t)n, sizeof(RecEnt), cmp_rec);
+        int32_t c = (int32_t)(n < keep ? n : keep);
+        out_cnt[i] = c;
+        for (int32_t t = 0; t < keep; t++) {
+            size_t o = (size_t)i * keep + t;
+            out_col[o] = t < c ? e[t].c : -1;
+            out_sim[o] = t < c ? S->sim[e[t].p] : 0.0;
+            out_ls[o] = t < c ? S->ls[e[t].p] : 0.0;
+        }
+    }
+    free(e);
+}

@@ -256,5 +256,22 @@ def rec_sim(user_ptr, item, rating, n_items, cap):
     D = int(R.row_ptr[-1])
     R.col, R.sim, R.ls, R.nij = _arr(c.col, D, np.int32), _arr(c.sim, D, np.float64), _arr(c.ls, D, np.float64), _arr(c.nij, D, np.int32)
     R.norm = _arr(c.norm, n_items, np.float64)
-    L.xo_rec_free(p)
+    R._h = p
     return R
+
+
+def rec_select(R, keep):
+    """nonprivate_neighbor_selection on a rec_sim result: (cnt [I], col [I][keep], sim, ls)"""
+    I = len(R.row_ptr) - 1
+    cnt = np.zeros(I, np.int32)
+    col = np.zeros((I, keep), np.int32)
+    sim = np.zeros((I, keep), np.float64)
+    ls = np.zeros((I, keep), np.float64)
+    lib().xo_rec_select(R._h, C.c_int32(keep), _p(cnt, C.c_int32), _p(col, C.c_int32), _p(sim, C.c_double), _p(ls, C.c_double))
+    return cnt, col, sim, ls
+
+
+def rec_free(R):
+    if getattr(R, "_h", None) is not None:
+        lib().xo_rec_free(R._h)
+        R._h = None

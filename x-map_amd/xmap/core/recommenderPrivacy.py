@@ -61,6 +61,11 @@ class RecommenderPrivacy:
         return sorted(pairs, key=lambda x: - abs(x[1][0]))[: self.mapping_range]
 
     def nonprivate_neighbor_selection(self, rdd):
+        """the mapping_range most similar neighbours per item.  On the RecommenderSim handle this is a per-row top-k
+        on the GPU (Engine.rec_select; ties in ascending neighbour id); on any other RDD the reference's Python."""
+        if hasattr(rdd, "select_neighbors") and self.mapping_range <= 64:
+            from ..engine.localrdd import LocalRDD
+            return LocalRDD(rdd.select_neighbors(self.mapping_range), getattr(rdd, "ctx", None))
         return self.find_neighbor(rdd).map(lambda rec: (rec[0], self.get_nonprivate_neighbor(rec[1])))
 
     # -- perturbation (reference :154-189) ------------------------------------------------------------

@@ -410,6 +410,20 @@ class Engine(object):
         S.norm = self.norms[R.n_items:2 * R.n_items]
         return S
 
+    def rec_select(self, S, keep):
+        """RecommenderPrivacy.nonprivate_neighbor_selection on a rec_sim result: per item the `keep` neighbours by
+        (|sim| desc, index asc).  Returns (cnt [I], col [I][keep], sim [I][keep], ls [I][keep]) on the device."""
+        st = _stream(self.dev)
+        I = self.R.n_items
+        cnt = self._zeros(max(I, 1), torch.int32)
+        col = self._empty((max(I, 1), keep), torch.int32)
+        sim = self._empty((max(I, 1), keep), torch.float64)
+        ls = self._empty((max(I, 1), keep), torch.float64)
+        with self.timed("rec_select"):
+            check(lib.xmap_rec_select(st, i32(I), vp(S.row_ptr), vp(S.col), vp(S.sim), vp(S.ls), i32(keep), vp(cnt),
+                                      vp(col), vp(sim), vp(ls)))
+        return cnt[:I], col[:I], sim[:I], ls[:I]
+
     def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
         """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU)."""
         with self.timed("stats"):

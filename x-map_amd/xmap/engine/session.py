@@ -87,9 +87,16 @@ class RecSimRDD(LocalRDD):
     """alterEgo_sim of recommender_calculate_sim_pipeline: ((iid1, iid2), [sim, local sensitivity]) -- rows live in
     HBM (Engine.rec_sim); both directions of every pair, an item paired with itself once."""
 
-    def __init__(self, S, iids, ctx=None):
+    def __init__(self, S, iids, ctx=None, engine=None):
         LocalRDD.__init__(self, None, ctx, self._rows)
-        self.S, self.iids = S, iids
+        self.S, self.iids, self.engine = S, iids, engine
+
+    def select_neighbors(self, keep):
+        """nonprivate_neighbor_selection on the device: [(iid, [(nid, [sim, ls])*])*], items in id order"""
+        cnt, col, sim, ls = [x.cpu().numpy() for x in self.engine.rec_select(self.S, int(keep))]
+        iids = self.iids
+        return [(iids[i], [(iids[col[i, t]], [float(sim[i, t]), float(ls[i, t])]) for t in range(cnt[i])])
+                for i in range(len(iids)) if cnt[i]]
 
     def _rows(self):
         S, iids = self.S, self.iids
@@ -118,8 +125,9 @@ def rec_sim_from_profiles(user_profiles, cap, ctx=None):
     dev = "cuda:%d" % torch.cuda.current_device()
     R = device.DeviceRatings(ptr, np.asarray(item, np.int32), np.asarray(rating, np.float32),
                              np.zeros(len(item), np.int64), len(iids), xids.item_attrs(iids), dev)
-    S = device.Engine(R).rec_sim(cap)
-    return RecSimRDD(S, iids, ctx)
+    eng = device.Engine(R)
+    S = eng.rec_sim(cap)
+    return RecSimRDD(S, iids, ctx, eng)
 
 
 class ExtendedSimRDD(LocalRDD):
