@@ -5,6 +5,7 @@ computation on the path is a kernel of libxmap_hip.so.  All results stay residen
 torch tensors until a caller asks for host copies.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -596,7 +597,7 @@ class Engine(object):
             check(lib.xmap_mid_place(st, *common, vp(tile_cnt), vp(tile_off), vp(M.dir_ptr), vp(M.dir), vp(M.midX)))
         return M
 
-    def extend(self, S, top_k, full=False, start_range=None, n_slots=4096, xs_cap=None, chunk=None,
+    def extend(self, S, top_k, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
                start_split=None, algo="mid"):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
@@ -611,7 +612,9 @@ class Engine(object):
         E.units = U
         M = self.mid_lists(E) if algo == "mid" else None
         E.mid = M
-        slot_budget = 48 << 30
+        # one private accumulator row (36 B per item) per resident wave: 5 waves per SIMD = 5120 rows on 256 CUs
+        slot_budget = int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "100")) * (1 << 30))
+        n_slots = int(os.environ.get("XMAP_N_SLOTS", n_slots))
         n_slots = int(max(4, min(n_slots, slot_budget // (36 * max(I, 1)), max(U.n_units, 4))))
         acc = self._zero_scratch("acc", n_slots * max(I, 1) * 4, torch.float64)
         touched = self._empty(n_slots * max(I, 1), torch.int32)
