@@ -107,15 +107,17 @@ __global__ __launch_bounds__(256) void k_csc_fill(long long U, const long long *
 }
 
 // one wave per item: lane-strided partial sums, fixed butterfly reduction (deterministic)
-__global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr, const int *iuser, const float *irating,
-                                                    const double *u_avg, double *info, double *norms, int *ia_user) {
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= I) return;
-    int lane = lane_id();
-    long long p0 = iptr[i], p1 = iptr[i + 1];
+// stats of item i on a group of G lanes (G = 16: four items per wave; G = 64: the whole wave); gl = lane in the group.
+// All lanes of the wave call it (the reductions are wave instructions); `on` says whether this group has an item.
+template <int G>
+__device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, const long long *iptr, const int *iuser,
+                                                 const float *irating, const double *u_avg, double *info, double *norms,
+                                                 int *ia_user) {
+    long long p0 = 0, p1 = 0;
+    if (on) { p0 = iptr[i]; p1 = iptr[i + 1]; }
     double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
-    if (p1 - p0 <= 64 * 8) {
-        for (long long p = p0 + lane; p < p1; p += 64) {
+    if (G < 64 || p1 - p0 <= 64 * 8) {
+        for (long long p = p0 + gl; p < p1; p += G) {
             double r = (double)irating[p];
             double d = r - u_avg[iuser[p]];
             s += r;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
         double su[UN], qu[UN], ah[UN], al[UN];
 #pragma unroll
         for (int t = 0; t < UN; t++) { su[t] = 0.0; qu[t] = 0.0; ah[t] = 0.0; al[t] = 0.0; }
-        for (long long p = p0 + lane; p < p1; p += 64 * UN) {
+        for (long long p = p0 + gl; p < p1; p += 64 * UN) {
             float rr[UN];
             int uu[UN];
 #pragma unroll
@@ -159,18 +161,18 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
             dd_add(a2, a2lo, al[t]);
         }
     }
-    s = wave_sum(s);
-    q = wave_sum(q);
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double oh = __shfl_down(a2, m, 64), ol = __shfl_down(a2lo, m, 64);
+    for (int m = G / 2; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+        double oh = __shfl_down(a2, m, G), ol = __shfl_down(a2lo, m, G);
         dd_add(a2, a2lo, oh);
         dd_add(a2, a2lo, ol);
     }
-    a2 = __shfl(a2, 0, 64);
+    a2 = __shfl(a2, 0, G);
     double n = (double)(p1 - p0);
     double avg = (p1 > p0) ? 1.0 * s / n : 0.0;
-    if (lane == 0) {
+    if (on && gl == 0) {
         info[(size_t)i * 4 + 0] = avg;
         info[(size_t)i * 4 + 1] = sqrt(q);
         info[(size_t)i * 4 + 2] = sqrt(a2);
@@ -181,9 +183,29 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr
         }
     }
     if (!ia_user) return;   // the flag-packed copies are read by the complete-rows formulation only
-    for (long long p = p0 + lane; p < p1; p += 64) {
+    for (long long p = p0 + gl; p < p1; p += G) {
         unsigned ge = ((double)irating[p] >= avg) ? 0x80000000u : 0u;
         ia_user[p] = (int)((unsigned)iuser[p] | ge);
+    }
+}
+
+// four items per wave: the ones with at most 64 raters (99 % at BASELINE configs[1]; the median item has 10) together,
+// one per 16-lane group; the others one after the other on the whole wave
+__global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr, const int *iuser, const float *irating,
+                                                    const double *u_avg, double *info, double *norms, int *ia_user) {
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (i0 >= I) return;
+    const int lane = lane_id();
+    {
+        const int i = i0 + (lane >> 4);
+        const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
+        item_stats_group<16>(on, i, lane & 15, I, iptr, iuser, irating, u_avg, info, norms, ia_user);
+    }
+    for (int t = 0; t < 4; t++) {
+        const int i = i0 + t;
+        if (i >= I) break;
+        if (iptr[i + 1] - iptr[i] <= 64) continue;
+        item_stats_group<64>(true, i, lane, I, iptr, iuser, irating, u_avg, info, norms, ia_user);
     }
 }
 
@@ -500,7 +522,7 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
     XM_ARG(R->nnz < 0x7fffffffLL);
     hipStream_t st = (hipStream_t)stream;
     if (R->n_items > 0) {
-        k_item_stats<<<dim3((unsigned)((R->n_items + 3) / 4)), dim3(256), 0, st>>>(
+        k_item_stats<<<dim3((unsigned)((R->n_items + 15) / 16)), dim3(256), 0, st>>>(
             R->n_items, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, norms, ia_user);
         XM_LAUNCH_CHECK();
     }

@@ -231,25 +231,12 @@ __global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, con
     rc[p] = r;
 }
 
-// light rows: Q partitions; heavy rows (in H): chunks of CH raters.  One wave per item sums W+ = the prefix lengths.
-__global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const RaterRec *rc, const long long *pre,
-                                               int HB, const int *hid, const int *CH, int target, int dups, int *Q, int *C,
-                                               uint8_t *small, unsigned long long *Wp, int *Qcat) {
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= I) return;
-    const int lane = lane_id();
-    const long long p0 = iptr[i], p1 = iptr[i + 1];
-    long long w = 0;
-    for (long long p = p0 + lane; p < p1; p += 64 * 8) {   // 8 loads in flight per lane (popular items: 1e5 raters)
-        int v[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++) v[t] = (p + 64 * t < p1) ? rc[p + 64 * t].pos_ge & 0x7fffffff : 0;
-#pragma unroll
-        for (int t = 0; t < 8; t++) w += v[t];
-    }
-    w = wave_sum_ll(w);
-    if (lane) return;
-    long long n = p1 - p0;
+// light rows: Q partitions; heavy rows (in H): chunks of CH raters.  W+ = the sum of the item's prefix lengths: four
+// items per wave, those with at most 64 raters together (one per 16-lane group), the others on the whole wave.
+__device__ __forceinline__ void plan_item(int i, long long w, int I, const long long *iptr, const long long *pre, int HB,
+                                          const int *hid, const int *CH, int target, int dups, int *Q, int *C,
+                                          uint8_t *small, unsigned long long *Wp, int *Qcat) {
+    const long long n = iptr[i + 1] - iptr[i];
     long long ge = I - pre[n < HB - 1 ? n : HB - 1];   // #{items with at least as many raters}
     const long long others = ge - 1 + (dups ? 1 : 0);   // with duplicate items a row can pair with itself
     long long bound = w < others ? w : others;
@@ -260,7 +247,6 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     }
     Q[i] = q;
     C[i] = c;
-    // table class: 1 = 128 slots, 3 = 256, 2 = 512, 0 = 1024
     // rows with very many raters (popular items below the heavy threshold, or every popular item when there is no
     // heavy set: RecommenderSim) are bound by the walk over their raters, not by the table: class 4
     const int cls = (q >= 1 && n >= WIDE_MIN) ? 4
@@ -270,6 +256,39 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     // the light units are listed class-major (largest tables first: their units run longest), so that each table
     // class is one contiguous range of units: Qcat[rank][i] (zero-initialised) is what the unit scan runs over
     Qcat[(size_t)class_rank(cls) * I + i] = q;
+}
+
+__global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const RaterRec *rc, const long long *pre,
+                                               int HB, const int *hid, const int *CH, int target, int dups, int *Q, int *C,
+                                               uint8_t *small, unsigned long long *Wp, int *Qcat) {
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (i0 >= I) return;
+    const int lane = lane_id();
+    {
+        const int i = i0 + (lane >> 4), gl = lane & 15;
+        const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
+        long long w = 0;
+        if (on) for (long long p = iptr[i] + gl; p < iptr[i + 1]; p += 16) w += rc[p].pos_ge & 0x7fffffff;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) w += __shfl_xor(w, m, 64);
+        if (on && gl == 0) plan_item(i, w, I, iptr, pre, HB, hid, CH, target, dups, Q, C, small, Wp, Qcat);
+    }
+    for (int t = 0; t < 4; t++) {
+        const int i = i0 + t;
+        if (i >= I) break;
+        const long long p0 = iptr[i], p1 = iptr[i + 1];
+        if (p1 - p0 <= 64) continue;
+        long long w = 0;
+        for (long long p = p0 + lane; p < p1; p += 64 * 8) {   // 8 loads in flight per lane (popular items: 1e5 raters)
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (p + 64 * u < p1) ? rc[p + 64 * u].pos_ge & 0x7fffffff : 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) w += v[u];
+        }
+        w = wave_sum_ll(w);
+        if (lane == 0) plan_item(i, w, I, iptr, pre, HB, hid, CH, target, dups, Q, C, small, Wp, Qcat);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Qcat, const long long *uq_ptr, int *uq_item, int *uq_q,
@@ -884,7 +903,7 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
     const int I = R->n_items;
     XM_HIP(hipMemsetAsync(Qcat, 0, sizeof(int32_t) * (size_t)N_CLASSES * (size_t)(I > 0 ? I : 1), st));
     if (I > 0) {
-        k_plan2<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(
+        k_plan2<<<dim3((unsigned)((I + 15) / 16)), dim3(256), 0, st>>>(
             I, (const long long *)R->item_ptr, (const RaterRec *)rc, (const long long *)pre, (int)R->n_users + 2, hid, ctl,
             slot_target, dups, Q, C, small, (unsigned long long *)Wp, Qcat);
         XM_LAUNCH_CHECK();
