@@ -126,3 +126,31 @@ def test_dense_extend_feeds_stage_c():
     assert {int(s): int(mp[s]) for s in range(I) if mp[s] >= 0} == exp
     G = eng.alterego(torch.from_numpy(mp).cuda())
     assert G.n_rows > 0
+
+
+def test_dense_error_codes():
+    """the C ABI reports misuse through its return code and xmap_last_error, it never launches on bad shapes"""
+    import ctypes as C
+    import torch
+    from xmap.engine import hipabi as abi
+    lib, vp, i32 = abi.lib, abi.vp, abi.i32
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    F = torch.randn(300, 96, device="cuda")
+    out_i = torch.empty((300, 8), dtype=torch.int32, device="cuda")
+    out_v = torch.empty((300, 8), dtype=torch.float32, device="cuda")
+    rc = lib.xmap_dense_topk(st, i32(300), i32(300), i32(96), vp(F), vp(F), i32(8), i32(1), vp(None), vp(None), vp(out_i), vp(out_v))
+    assert rc == abi.ERR_ARG and b"96" in lib.xmap_last_error()
+    G = torch.randn(300, 128, device="cuda")
+    rc = lib.xmap_dense_topk(st, i32(300), i32(300), i32(128), vp(G), vp(G), i32(65), i32(1), vp(None), vp(None), vp(out_i), vp(out_v))
+    assert rc == abi.ERR_ARG
+    big = torch.randn(70, 128, device="cuda")
+    many = torch.randn(40000, 128, device="cuda")
+    npc = C.c_int32(0)
+    abi.check(lib.xmap_dense_layout(i32(70), i32(40000), C.byref(npc)))
+    assert npc.value > 1
+    oi = torch.empty((70, 8), dtype=torch.int32, device="cuda")
+    ov = torch.empty((70, 8), dtype=torch.float32, device="cuda")
+    rc = lib.xmap_dense_topk(st, i32(70), i32(40000), i32(128), vp(big), vp(many), i32(8), i32(1), vp(None), vp(None), vp(oi), vp(ov))
+    assert rc == abi.ERR_CAPACITY and b"pieces" in lib.xmap_last_error()
+    with pytest.raises(abi.XmapError):
+        abi.check(rc)
