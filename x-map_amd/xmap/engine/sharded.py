@@ -96,9 +96,16 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         stats = eng.stats()
         L = eng.tri_layout(stats)
         while True:
-            n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
-            w = n_i[L.uq_item[:L.n_light].long()].cpu().numpy() if L.n_light else np.zeros(0)
-            lo, hi = balanced_ranges(w, world)[rank]
+            # contiguous unit ranges of equal rater-steps: prefix sum and cut points on the device (the units are listed
+            # by table class, every rank gets a slice of every class boundary it spans)
+            lo, hi = 0, 0
+            if L.n_light:
+                n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
+                c = torch.cumsum(n_i[L.uq_item[:L.n_light].long()].double(), 0)
+                tgt = c[-1] * torch.arange(1, world, dtype=torch.float64, device=dev) / world
+                cuts = [0] + torch.searchsorted(c, tgt).clamp(max=L.n_light).tolist() + [L.n_light]
+                cuts = np.maximum.accumulate(np.asarray(cuts, np.int64))
+                lo, hi = int(cuts[rank]), int(cuts[rank + 1])
             coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
                                                              do_heavy=(rank == 0), retry=False)
             flag = torch.tensor([ovf], dtype=torch.int64, device=dev)
@@ -107,8 +114,15 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
                 break
             eng._tri_plan(L, L.slot_target // 2)      # every rank re-plans identically
         comm.all_reduce(rowcnt)
-        valid = coo[0] >= 0                            # compact the padded local COO before the exchange
-        coo = [comm.all_gather_var(x[valid].contiguous()) for x in coo]
+        # compact the padded local COO (one index list for the five columns) and exchange it as ONE variable-length
+        # all-gather of 24-byte records: (i | j << 32, sim bits, mutu | n_ij << 32)
+        idx = torch.nonzero(coo[0] >= 0).flatten()
+        ci, cj, cs, cm, cn = [x[idx] for x in coo]
+        rec = torch.stack([ci.long() | (cj.long() << 32), cs.view(torch.int64), cm.long() | (cn.long() << 32)], dim=1)
+        rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
+        m32 = 0xffffffff
+        coo = [(rec[:, 0] & m32).to(torch.int32), (rec[:, 0] >> 32).to(torch.int32), rec[:, 1].contiguous().view(torch.float64),
+               (rec[:, 2] & m32).to(torch.int32), (rec[:, 2] >> 32).to(torch.int32)]
         tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
         S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
