@@ -23,7 +23,13 @@ def _summary(res):
     rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
     col = S.col.cpu().numpy()
     o = np.lexsort((col, rows))
-    return dict(n_eval=res["n_eval"], n_kept=res["n_kept"], n_paths=res["n_paths"], n_rows=res["n_rows"],
+    part = {}
+    if "S_part" in res:      # the rank's own partition of the similarity matrix (where its stage A ends)
+        P = res["S_part"]
+        prp = P.row_ptr.cpu().numpy()
+        prow = np.repeat(np.arange(len(prp) - 1), np.diff(prp))
+        part = dict(part_row=prow, part_col=P.col.cpu().numpy(), part_sim=P.sim.cpu().numpy())
+    return dict(part, n_eval=res["n_eval"], n_kept=res["n_kept"], n_paths=res["n_paths"], n_rows=res["n_rows"],
                 n_profiles=res["n_profiles"], row_ptr=rp, col=col[o], sim=S.sim.cpu().numpy()[o],
                 n_cand=E.n_cand.cpu().numpy(), top_end=E.top_end.cpu().numpy(), top_val=E.top_val.cpu().numpy(),
                 choice=res["choice"].cpu().numpy(), map=res["map"].cpu().numpy(),
@@ -69,3 +75,13 @@ def test_world2_equals_world1():
     for rank, out in got:
         for key, v in ref.items():
             assert np.array_equal(out[key], v), (rank, key)
+    # the two partitions are disjoint and together are the whole matrix
+    I = len(ref["row_ptr"]) - 1
+    rows = np.concatenate([out["part_row"] for _, out in got])
+    cols = np.concatenate([out["part_col"] for _, out in got])
+    sims = np.concatenate([out["part_sim"] for _, out in got])
+    o = np.lexsort((cols, rows))
+    full_rows = np.repeat(np.arange(I), np.diff(ref["row_ptr"]))
+    assert np.array_equal(rows[o], full_rows) and np.array_equal(cols[o], ref["col"])
+    assert np.array_equal(sims[o], ref["sim"])
+    assert all(len(out["part_row"]) > 0 for _, out in got)

@@ -3,9 +3,11 @@
 Sharding: inputs (CSR + CSC) are replicated in every GPU's HBM; the work is sharded by
 item.  Stage A: the work units (item, partition) of the pair kernel are split into contiguous ranges of
 equal rater-steps; each rank appends the kept pairs of its units to a half COO (every unordered pair is
-owned by exactly one unit, so there are no cross-GPU partials), the per-item row counts are all-reduced
-and the COO parts all-gathered (S4/S6 of SURVEY 2.3), then every rank mirrors the full COO into the CSR.
-Stage B: the knn tables are derived from the full CSR on every rank (one HBM pass, cheaper than
+owned by exactly one unit, so there are no cross-GPU partials) and mirrors them into a CSR of its own:
+that is the rank's partition of item2item_simRDD (both directions of its pairs), and where stage A ends.  Stage B starts with the exchange its input needs (the reference
+broadcasts the knn tables, utils/assist.py:88-101): the per-item row counts are all-reduced, the COO parts
+all-gathered (S4/S6 of SURVEY 2.3) and every rank mirrors the full COO into the CSR; then
+the knn tables are derived from the full CSR on every rank (one HBM pass, cheaper than
 exchanging them), the path enumeration is sharded by start item (ranges of equal path counts), and the
 fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
 passes over nnz and is replicated.
@@ -113,24 +115,31 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             if int(flag.item()) == 0:
                 break
             eng._tri_plan(L, L.slot_target // 2)      # every rank re-plans identically
-        comm.all_reduce(rowcnt)
-        # compact the padded local COO (one index list for the five columns) and exchange it as ONE variable-length
-        # all-gather of 24-byte records: (i | j << 32, sim bits, mutu | n_ij << 32)
-        idx = torch.nonzero(coo[0] >= 0).flatten()
-        ci, cj, cs, cm, cn = [x[idx] for x in coo]
-        rec = torch.stack([ci.long() | (cj.long() << 32), cs.view(torch.int64), cm.long() | (cn.long() << 32)], dim=1)
-        rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
-        m32 = 0xffffffff
-        coo = [(rec[:, 0] & m32).to(torch.int32), (rec[:, 0] >> 32).to(torch.int32), rec[:, 1].contiguous().view(torch.float64),
-               (rec[:, 2] & m32).to(torch.int32), (rec[:, 2] >> 32).to(torch.int32)]
+        # the rank's partition of item2item_simRDD: both directions of ITS kept pairs, CSR by first item (the same
+        # mirror step a single GPU does for all pairs)
+        S_part = eng.tri_scatter(coo, rowcnt, stats[2], n, L)
         tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
-        S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
         it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
         light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
     # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
     # ranges balanced by the exact per-start path counts
     with eng.timed("stage_b"):
+        # The extension needs the whole similarity matrix on every rank (the reference broadcasts its knn tables,
+        # utils/assist.py:88-101): the ranks' COO parts are exchanged here -- per-item row counts all-reduced, the
+        # compacted parts (one index list for the five columns) sent as ONE variable-length all-gather of 24-byte
+        # records (i | j << 32, sim bits, mutu | n_ij << 32) -- and every rank mirrors the full COO into the CSR.
+        with eng.timed("exchange"):
+            comm.all_reduce(rowcnt)
+            idx = torch.nonzero(coo[0] >= 0).flatten()
+            ci, cj, cs, cm, cn = [x[idx] for x in coo]
+            rec = torch.stack([ci.long() | (cj.long() << 32), cs.view(torch.int64), cm.long() | (cn.long() << 32)], dim=1)
+            rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
+            m32 = 0xffffffff
+            coo = [(rec[:, 0] & m32).to(torch.int32), (rec[:, 0] >> 32).to(torch.int32),
+                   rec[:, 1].contiguous().view(torch.float64), (rec[:, 2] & m32).to(torch.int32),
+                   (rec[:, 2] >> 32).to(torch.int32)]
+        S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
         E = eng.extend(S, k, full=False, start_split=(rank, world))
         comm.all_reduce(E.n_cand)
         comm.all_reduce(E.top_end, "max")             # -1 outside the local range
@@ -145,4 +154,4 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
     return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * L.half_contrib,
                 n_contrib_light=light_local, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
                 n_rows=G.n_rows, n_profiles=n_prof, knn_entries=int(E.kcnt.sum().item()),
-                S=S, E=E, G=G, choice=choice, map=mp)
+                S=S, S_part=S_part, E=E, G=G, choice=choice, map=mp)
