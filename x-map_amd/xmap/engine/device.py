@@ -124,6 +124,11 @@ class Engine(object):
     def _empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.dev)
 
+    def _out(self, shape, dtype, written):
+        """buffer a kernel is about to fill completely (`written`: it will run, i.e. the input is not empty): no
+        zero-fill launch in that case"""
+        return self._empty(shape, dtype) if written else self._zeros(shape, dtype)
+
     def _zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.dev)
 
@@ -147,8 +152,8 @@ class Engine(object):
         u_avg = self._empty(max(R.n_users, 1), torch.float64)
         u_norm = self._empty(max(R.n_users, 1), torch.float64)
         check(lib.xmap_user_stats(st, C.byref(R.c), vp(u_avg), vp(u_norm)))
-        info = self._zeros((max(R.n_items, 1), 4), torch.float64)
-        self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
+        info = self._out((max(R.n_items, 1), 4), torch.float64, R.n_items > 0)
+        self.norms = self._out(2 * max(R.n_items, 1), torch.float64, R.n_items > 0)
         ua_item = self._empty(max(R.nnz, 1), torch.int32) if packed else None
         ia_user = self._empty(max(R.nnz, 1), torch.int32) if packed else None
         check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user)))
@@ -269,20 +274,20 @@ class Engine(object):
         L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
         L.slot_target = slot_target
         self._tri_plan(L, slot_target)
-        L.half_contrib = int(L.Wp[:I].sum().item()) if I else 0
-        L.heavy_half = int(L.Wp[L.hlist[:L.n_heavy].long()].sum().item()) if L.n_heavy else 0
+        both = torch.stack([L.Wp[:I].sum(), L.Wp[L.hlist[:L.n_heavy].long()].sum()]).tolist() if I else [0, 0]   # one sync
+        L.half_contrib, L.heavy_half = int(both[0]), int(both[1])
         return L
 
     def _tri_plan(self, L, slot_target):
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
-        L.Q = self._zeros(max(I, 1), torch.int32)
-        L.C = self._zeros(max(I, 1), torch.int32)
-        L.small = self._zeros(max(I, 1), torch.uint8)
+        L.Q = self._out(max(I, 1), torch.int32, I > 0)
+        L.C = self._out(max(I, 1), torch.int32, I > 0)
+        L.small = self._out(max(I, 1), torch.uint8, I > 0)
         L.Qcat = self._empty(5 * max(I, 1), torch.int32)
-        L.uq_ptr = self._zeros(5 * I + 1, torch.int64)     # light units class-major: [table class rank][item]
-        L.uc_ptr = self._zeros(I + 1, torch.int64)
+        L.uq_ptr = self._out(5 * I + 1, torch.int64, I > 0)     # light units class-major: [table class rank][item]
+        L.uc_ptr = self._out(I + 1, torch.int64, I > 0)
         h = (C.c_int64 * 8)()
         with self.timed("tri_plan"):
             check(lib.xmap_sim2_plan(st, C.byref(R.c), i32(slot_target), vp(L.rc), vp(L.pre), vp(L.hid),
@@ -371,7 +376,7 @@ class Engine(object):
         n_scan = int(coo_i.numel())
         if n is None:
             n = n_scan
-        row_ptr = self._zeros(I + 1, torch.int64)
+        row_ptr = self._out(I + 1, torch.int64, I > 0)
         tot = C.c_int64(0)
         check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rowcnt), vp(row_ptr), i64(I), C.byref(tot) if coo_ls is not None else None))
         kept = 2 * n if coo_ls is None else int(tot.value)      # a row paired with itself is one entry
