@@ -912,8 +912,12 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
     if (rcode) return rcode;
     rcode = xmap_exclusive_scan_i32_to_i64(stream, C, uc_ptr, I, &h_counts[1]);
     if (rcode) return rcode;
-    for (int c = 0; c < N_CLASSES; c++)    // class boundaries (the scan above has synchronised the stream)
-        XM_HIP(hipMemcpyAsync(&h_counts[2 + c], uq_ptr + (size_t)c * I, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    // class boundaries uq_ptr[c I], c = 0..4: one strided copy (the scan above has synchronised the stream)
+    if (I > 0)
+        XM_HIP(hipMemcpy2DAsync(&h_counts[2], sizeof(int64_t), uq_ptr, sizeof(int64_t) * (size_t)I, sizeof(int64_t),
+                                N_CLASSES, hipMemcpyDeviceToHost, st));
+    else
+        for (int c = 0; c < N_CLASSES; c++) h_counts[2 + c] = 0;
     XM_HIP(hipStreamSynchronize(st));
     h_counts[2 + N_CLASSES] = h_counts[0];
     return XMAP_OK;
