@@ -3,7 +3,6 @@
 
 Same constructor, attributes and method names as the reference class; the RDD-shaped work runs
 on the MI355X through xmap.engine (no Spark shuffle, no CPU fallback)."""
-import numpy as np
 
 from xmap.engine.localrdd import LocalRDD, LocalDF, records_of
 

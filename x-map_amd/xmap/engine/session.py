@@ -195,7 +195,6 @@ def sim_from_records(state, records):
 
 def ext_from_records(state, records):
     """Device candidate arrays from generic (start, [(end, xsim)*]) records."""
-    import ctypes as C
     import torch
     from . import device, hipabi as abi
     eng = state.engine
