@@ -28,6 +28,17 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 CAP = 50                # parameters.yaml:18
 
 
+# The bench line is the ONLY thing on stdout: native libraries write there too (RCCL prints a version banner on
+# communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
+_REAL_STDOUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+
+
+def emit(out):
+    _REAL_STDOUT.write(json.dumps(out) + "\n")
+    _REAL_STDOUT.flush()
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -150,7 +161,7 @@ def bench_dense(args, rank, world, local, dist):
             out["cpu_baseline"] = dict(value=rows * float(n_s) / dt, unit="pairs/s", cores=threads, kind="port",
                                        sample="oracle dense top-k on target rows [0,%d) x all %d sources: %.1f s, OpenMP %d threads"
                                               % (rows, n_s, dt, threads))
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 def bench_recsim(args, rank, world, local, dist):
@@ -216,7 +227,7 @@ def bench_recsim(args, rank, world, local, dist):
                                    sample="oracle rec_sim on the rows of the first %d users: %d pairs in %.1f s, 1 thread"
                                           % (users, int(O.row_ptr[-1]), dt))
         xo.rec_free(O)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def main():
@@ -238,7 +249,14 @@ def main():
     if args.gpus > 1 and world == 1:
         log("bench.py: --gpus %d needs torch.distributed.run; running 1 rank" % args.gpus)
     dist = None
-    if world > 1:
+    # XMAP_FORCE_DIST=1: take the sharded path with one rank (rehearses the RCCL collectives on a one-GPU box)
+    force = world == 1 and os.environ.get("XMAP_FORCE_DIST") == "1"
+    if force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -344,7 +362,7 @@ def main():
         }
         if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(r, attrs, args.method, k=k)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

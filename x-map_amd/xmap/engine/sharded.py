@@ -75,7 +75,7 @@ class Comm(object):
 def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=False):
     """stage A -> B -> C once.  Returns the counters the bench reports."""
     I = eng.R.n_items
-    if dist is None or world == 1:
+    if dist is None:
         with eng.timed("stage_a"):
             S = eng.item_sim(method, cap)
         with eng.timed("stage_b"):
