@@ -479,38 +479,72 @@ __global__ __launch_bounds__(256) void k_topc_lists(int I, const long long *xs_p
 
 // xsim = sum(s_p c_p) / sum(c_p) (get_sim, extender.py:198-201), fused top-XMAP_TOPC by (|xsim| desc,
 // end asc) -- all a Generator reads (generator.py:85,109) --, optional full lists, row reset.
-__device__ __forceinline__ int finalize_start(const PathArgs &A, double *acc, const int *touched, int nt, int start) {
+// ONE pass over the start's row: every touched entry is read once, divided, (full mode: written to the start's list,)
+// zeroed, and offered to a running selection.  The row entries are random 32-byte accesses to HBM (a row is larger than
+// an XCD's L2), so the earlier form -- a division pass, XMAP_TOPC selection passes over the row and a reset pass -- cost
+// 12 random accesses per candidate against ~6 for accumulating it.  Running selection: candidates whose key is >= the
+// key of the XMAP_TOPC-th best so far (ties included: the order among equal keys is by end index) are appended to a
+// per-wave LDS buffer; when it passes FIN_CAP entries it is cut back to its exact XMAP_TOPC best, which raises the
+// threshold.  An entry is only ever dropped when XMAP_TOPC entries with a strictly larger key exist, so the result is
+// the exact top of the whole list; a stream in random order appends ~XMAP_TOPC ln(nt / XMAP_TOPC) entries.
+constexpr int FIN_CAP = 128;
+struct FinBuf { double v[FIN_CAP + 64]; int e[FIN_CAP + 64]; double ov[XMAP_TOPC]; int oe[XMAP_TOPC]; };
+
+__device__ __forceinline__ unsigned long long xsim_key(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+
+__device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt, int start) {
     const int lane = lane_id();
-    for (int b = lane; b < nt; b += 64) {
-        int e = touched[b];
-        acc[(size_t)e * 4] = 1.0 * acc[(size_t)e * 4] / acc[(size_t)e * 4 + 2];
-    }
-    select_topc(nt, [&](int b, int &e, double &v) { e = touched[b]; v = acc[(size_t)e * 4]; },
-                A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
+    volatile double *bv = F.v;
+    volatile int *be = F.e;
     if (lane == 0) A.n_cand[start] = nt;
+    unsigned long long off = 0;
+    bool full = false;
     if (A.xs_cap > 0 && nt > 0) {  // full candidate lists (extender_pipeline's RDD) via a cursor
-        unsigned long long off = 0;
         if (lane == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
         off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
-        if ((long long)(off + nt) <= A.xs_cap) {
-            for (int b = lane; b < nt; b += 64) {
-                int e = touched[b];
-                A.xs_end[off + b] = e;
-                A.xs_val[off + b] = acc[(size_t)e * 4];
-            }
-            if (lane == 0) A.xs_off[start] = (long long)off;
-        } else if (lane == 0) {
-            A.xs_off[start] = -1;
+        full = (long long)(off + nt) <= A.xs_cap;
+        if (lane == 0) A.xs_off[start] = full ? (long long)off : -1;
+    }
+    int nbuf = 0;
+    unsigned long long thr = 0;   // key of the XMAP_TOPC-th best so far (0 while fewer have been seen)
+    auto cut = [&](int *out_e, double *out_v) {
+        select_topc(nbuf, [&](int b, int &e, double &v) { e = be[b]; v = bv[b]; }, out_e, out_v);
+        return nbuf < XMAP_TOPC ? nbuf : XMAP_TOPC;
+    };
+    for (int b0 = 0; b0 < nt; b0 += 64) {
+        const int b = b0 + lane;
+        const bool act = b < nt;
+        int e = 0;
+        double v = 0.0;
+        unsigned long long key = 0;
+        if (act) {
+            e = touched[b];
+            double *a = acc + (size_t)e * 4;
+            v = 1.0 * a[0] / a[2];
+            a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
+            key = xsim_key(v);
+            if (full) { A.xs_end[off + b] = e; A.xs_val[off + b] = v; }
+        }
+        const bool q = act && key >= thr;
+        const unsigned long long m = __ballot(q);
+        if (q) { const int p = nbuf + __popcll(m & lanemask_lt()); bv[p] = v; be[p] = e; }
+        nbuf += __popcll(m);
+        if (nbuf > FIN_CAP) {
+            const int ns = cut(F.oe, F.ov);      // lane 0 writes the best ns, in order
+            int te = 0;
+            double tv = 0.0;
+            if (lane < ns) { te = ((volatile int *)F.oe)[lane]; tv = ((volatile double *)F.ov)[lane]; }
+            if (lane < ns) { be[lane] = te; bv[lane] = tv; }
+            nbuf = ns;
+            thr = (ns == XMAP_TOPC) ? xsim_key(rld(tv, XMAP_TOPC - 1)) : 0ull;
         }
     }
-    for (int b = lane; b < nt; b += 64) {
-        double *a = acc + (size_t)touched[b] * 4;
-        a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
-    }
+    cut(A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
     return nt;
 }
 
 __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
+    __shared__ FinBuf fin[4];
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= A.n_slots) return;
     const int lane = lane_id();
@@ -577,7 +611,7 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
                 }
             }
         }
-        if (row < 0) cand_total += finalize_start(A, W.acc, W.touched, W.nt, start);
+        if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
         else if (lane == 0) A.unit_nt[unit] = W.nt;
     }
     if (lane == 0) {
@@ -825,6 +859,7 @@ __device__ __forceinline__ void heads_X(const Path2Args &B, WaveAcc &W, int star
 // (112 VGPRs) allows, 6 (80 VGPRs, 128 B of scratch) 8 % slower: the kernel is bound by its random row updates, more
 // waves keep more of them in flight
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_paths2(Path2Args B) {
+    __shared__ FinBuf fin[4];
     const PathArgs &A = B.P;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= A.n_slots) return;
@@ -883,7 +918,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 }
                 ent++;
             }
-        if (row < 0) cand_total += finalize_start(A, W.acc, W.touched, W.nt, start);
+        if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
         else if (lane == 0) A.unit_nt[unit] = W.nt;
     }
     if (lane == 0) {
@@ -894,6 +929,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
 // heavy starts: add the G partial rows into the first one (double-double merge), then finalise
 __global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
+    __shared__ FinBuf fin[4];
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= n_heavy) return;
     const int lane = lane_id();
@@ -925,7 +961,7 @@ __global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const in
             nt += __popcll(m);
         }
     }
-    int n = finalize_start(A, acc0, touched0, nt, start);
+    int n = finalize_start(A, fin[threadIdx.x >> 6], acc0, touched0, nt, start);
     if (lane == 0) atomicAdd(&A.counters[0], (unsigned long long)n);
 }
 
