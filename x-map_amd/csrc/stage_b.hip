@@ -492,26 +492,35 @@ struct FinBuf { double v[FIN_CAP + 64]; int e[FIN_CAP + 64]; double ov[XMAP_TOPC
 
 __device__ __forceinline__ unsigned long long xsim_key(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 
-__device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt, int start) {
+// the full-list cursor of one start (lane 0 draws it); returns whether the list fits
+__device__ __forceinline__ bool fin_list_offset(const PathArgs &A, int nt, int start, unsigned long long &off) {
+    off = 0;
+    if (!(A.xs_cap > 0 && nt > 0)) return false;   // full candidate lists (extender_pipeline's RDD) via a cursor
+    if (lane_id() == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
+    off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
+    const bool full = (long long)(off + nt) <= A.xs_cap;
+    if (lane_id() == 0) A.xs_off[start] = full ? (long long)off : -1;
+    return full;
+}
+
+// exact XMAP_TOPC best of the nbuf buffered candidates; lane 0 writes them in order
+__device__ __forceinline__ int fin_cut(FinBuf &F, int nbuf, int *out_e, double *out_v) {
+    volatile double *bv = F.v;
+    volatile int *be = F.e;
+    select_topc(nbuf, [&](int b, int &e, double &v) { e = be[b]; v = bv[b]; }, out_e, out_v);
+    return nbuf < XMAP_TOPC ? nbuf : XMAP_TOPC;
+}
+
+// One wave's share of the pass: candidates b = 64 (w + j NW) + lane.  Leaves the best ns of them, in order, in
+// F.oe / F.ov and returns ns.
+__device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt,
+                                              unsigned long long off, bool full, int w, int NW) {
     const int lane = lane_id();
     volatile double *bv = F.v;
     volatile int *be = F.e;
-    if (lane == 0) A.n_cand[start] = nt;
-    unsigned long long off = 0;
-    bool full = false;
-    if (A.xs_cap > 0 && nt > 0) {  // full candidate lists (extender_pipeline's RDD) via a cursor
-        if (lane == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
-        off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
-        full = (long long)(off + nt) <= A.xs_cap;
-        if (lane == 0) A.xs_off[start] = full ? (long long)off : -1;
-    }
     int nbuf = 0;
     unsigned long long thr = 0;   // key of the XMAP_TOPC-th best so far (0 while fewer have been seen)
-    auto cut = [&](int *out_e, double *out_v) {
-        select_topc(nbuf, [&](int b, int &e, double &v) { e = be[b]; v = bv[b]; }, out_e, out_v);
-        return nbuf < XMAP_TOPC ? nbuf : XMAP_TOPC;
-    };
-    for (int b0 = 0; b0 < nt; b0 += 64) {
+    for (int b0 = 64 * w; b0 < nt; b0 += 64 * NW) {
         const int b = b0 + lane;
         const bool act = b < nt;
         int e = 0;
@@ -530,7 +539,7 @@ __device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, doub
         if (q) { const int p = nbuf + __popcll(m & lanemask_lt()); bv[p] = v; be[p] = e; }
         nbuf += __popcll(m);
         if (nbuf > FIN_CAP) {
-            const int ns = cut(F.oe, F.ov);      // lane 0 writes the best ns, in order
+            const int ns = fin_cut(F, nbuf, F.oe, F.ov);
             int te = 0;
             double tv = 0.0;
             if (lane < ns) { te = ((volatile int *)F.oe)[lane]; tv = ((volatile double *)F.ov)[lane]; }
@@ -539,7 +548,19 @@ __device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, doub
             thr = (ns == XMAP_TOPC) ? xsim_key(rld(tv, XMAP_TOPC - 1)) : 0ull;
         }
     }
-    cut(A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
+    return fin_cut(F, nbuf, F.oe, F.ov);
+}
+
+__device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt, int start) {
+    const int lane = lane_id();
+    if (lane == 0) A.n_cand[start] = nt;
+    unsigned long long off;
+    const bool full = fin_list_offset(A, nt, start, off);
+    const int ns = finalize_slice(A, F, acc, touched, nt, off, full, 0, 1);
+    if (lane < ns) {
+        A.top_end[(size_t)start * XMAP_TOPC + lane] = ((volatile int *)F.oe)[lane];
+        A.top_val[(size_t)start * XMAP_TOPC + lane] = ((volatile double *)F.ov)[lane];
+    }
     return nt;
 }
 
@@ -676,6 +697,94 @@ __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
             }
         }
     }
+}
+
+// Row-wise construction of the middle lists (default): ONE block per x', the tile sizes of its row in LDS (n_nb
+// counters: the row of the dense table without the table).  PHASE 0 counts the row's records and non-empty tiles;
+// PHASE 1 repeats the tally, turns it into offsets (block scan), writes the row's tile directory in x order and places
+// the records with LDS cursors.  No global atomics (the table form spends 1.6e8 of them per pass, twice, on a 3 GB
+// table) and no n_nb^2 memory.
+constexpr int MIDROW_WAVES = 16;
+template <int PHASE>
+__global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int *ng, long long *nrec, const long long *dir_ptr,
+                                                                const long long *rec_ptr, MidDir *dir) {
+    extern __shared__ int bins[];                      // [n_nb]
+    __shared__ unsigned long long s_wave[MIDROW_WAVES];
+    const int xpid = blockIdx.x;
+    const int xp = A.nb_list[xpid];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int n_nb = A.n_nb;
+    for (int i = threadIdx.x; i < n_nb; i += 64 * MIDROW_WAVES) bins[i] = 0;
+    __syncthreads();
+    const int nq = A.kcnt[(size_t)xp * 2];
+    // the joint (t,s) of the row are dealt round-robin to the waves (every wave scans the flags, 64 at a time); the
+    // lanes of a wave walk attach(s) together (coalesced, distinct x: no two lanes meet on a counter)
+    auto walk = [&](auto &&body) {
+        int ctr = 0;
+        for (int q = 0; q < nq; q++) {
+            const size_t o = ((size_t)xp * 2) * A.k + q;
+            const int t = A.kcol[o];
+            if (!(A.flags[t] & 2)) continue;
+            const double v2 = A.kval[o * 3], m2 = A.kval[o * 3 + 1], f2 = A.kval[o * 3 + 2];              // edge (x', t)
+            const long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
+            for (long long base = s0; base < s1; base += 64) {
+                const long long pl = base + lane;
+                unsigned long long m = __ballot(pl < s1 && (A.src_flag[pl < s1 ? pl : s0] & 1));
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if ((ctr++ % MIDROW_WAVES) != w) continue;
+                    const long long p = base + l;
+                    const int s = A.src_idx[p];
+                    for (long long ap = A.att_ptr[s] + lane; ap < A.att_ptr[s + 1]; ap += 64)
+                        body(A.nb_id[A.att_idx[ap]], v2, m2, f2, p, ap);
+                }
+            }
+        }
+    };
+    walk([&](int xid, double, double, double, long long, long long) { atomicAdd(&bins[xid], 1); });
+    __syncthreads();
+    // per thread a run of consecutive bins: (non-empty tiles << 40 | records), block-wide exclusive scan
+    const int per = (n_nb + 64 * MIDROW_WAVES - 1) / (64 * MIDROW_WAVES);
+    const int b0 = threadIdx.x * per, b1 = (b0 + per) < n_nb ? (b0 + per) : n_nb;
+    unsigned long long mine = 0;
+    for (int i = b0; i < b1; i++) { const int c = bins[i]; mine += (unsigned long long)c + (c ? (1ull << 40) : 0ull); }
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+    for (int o = 0; o < MIDROW_WAVES; o++) { const unsigned long long v = s_wave[o]; if (o < w) before += v; total += v; }
+    if (PHASE == 0) {
+        if (threadIdx.x == 0) { ng[xpid] = (int)(total >> 40); nrec[xpid] = (long long)(total & ((1ull << 40) - 1)); }
+        return;
+    }
+    unsigned long long ex = before + incl - mine;
+    int rank = (int)(ex >> 40);
+    int off = (int)(ex & ((1ull << 40) - 1));
+    const long long rbase = rec_ptr[xpid], dbase = dir_ptr[xpid];
+    for (int i = b0; i < b1; i++) {
+        const int c = bins[i];
+        bins[i] = off;                                  // placement cursor of the tile
+        if (c) {
+            MidDir d;
+            d.x = A.nb_list[i]; d.ne = 1 + A.kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = 0; d.off = rbase + off;
+            dir[dbase + rank] = d;
+            rank++;
+            off += c;
+        }
+    }
+    __syncthreads();
+    walk([&](int xid, double v2, double m2, double f2, long long p, long long ap) {
+        const long long pos = rbase + atomicAdd(&bins[xid], 1);
+        const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];      // edge (t, s)
+        const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
+        MidX r;
+        r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
+        r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
+        A.midX[pos] = r;
+    });
 }
 
 // directory of the non-empty tiles of every x' (row of the dense table): count, then fill
@@ -858,7 +967,13 @@ __device__ __forceinline__ void heads_X(const Path2Args &B, WaveAcc &W, int star
 // 5 waves per SIMD (94 VGPRs, 68 B of scratch per lane) measured 6 % faster than the 4 the unconstrained allocation
 // (112 VGPRs) allows, 6 (80 VGPRs, 128 B of scratch) 8 % slower: the kernel is bound by its random row updates, more
 // waves keep more of them in flight
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_paths2(Path2Args B) {
+#ifdef B_TRACE
+__device__ unsigned long long g_btrace[1 << 20][2];   // per unit: begin, end (wall_clock64, 100 MHz)
+#endif
+#ifndef B_WAVES
+#define B_WAVES 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_WAVES))) void k_paths2(Path2Args B) {
     __shared__ FinBuf fin[4];
     const PathArgs &A = B.P;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -876,6 +991,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         const int c = uniform(A.unit_c[unit]);
         const int G = uniform(A.unit_G[unit]);
         const int row = uniform(A.unit_row[unit]);
+#ifdef B_TRACE
+        const unsigned long long tr0 = wall_clock64();
+#endif
         if (row < 0) {
             W.acc = A.acc + (size_t)slot * A.I * 4;
             W.touched = A.touched + (size_t)slot * A.I;
@@ -920,6 +1038,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             }
         if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
         else if (lane == 0) A.unit_nt[unit] = W.nt;
+#ifdef B_TRACE
+        if (lane == 0 && unit < (1 << 20)) { g_btrace[unit][0] = tr0; g_btrace[unit][1] = wall_clock64(); }
+#endif
     }
     if (lane == 0) {
         atomicAdd(&A.counters[0], cand_total);
@@ -927,22 +1048,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
 }
 
-// heavy starts: add the G partial rows into the first one (double-double merge), then finalise
-__global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
-    __shared__ FinBuf fin[4];
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+// heavy starts: add the G partial rows into the first one (double-double merge), then finalise.  One block of
+// MERGE_WAVES waves per start: the touched entries of a partial row are distinct, so the waves take 64 of them at a
+// time side by side (a single wave per start had left a chain of G - 1 serial merges: 68 ms at BASELINE configs[1]);
+// the finalisation pass is shared the same way, every wave keeping the best of its share, wave 0 the best of those.
+constexpr int MERGE_WAVES = 16;
+__global__ __launch_bounds__(64 * MERGE_WAVES) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
+    __shared__ FinBuf fin[MERGE_WAVES];
+    __shared__ int s_nt, s_ns[MERGE_WAVES], s_full;
+    __shared__ unsigned long long s_off;
+    const int h = blockIdx.x;
     if (h >= n_heavy) return;
-    const int lane = lane_id();
+    const int lane = lane_id(), w = threadIdx.x >> 6;
     const int u0 = heavy_unit0[h];
     const int start = A.unit_start[u0], G = A.unit_G[u0], r0 = A.unit_row[u0];
     double *acc0 = A.hacc + (size_t)r0 * A.I * 4;
     int *touched0 = A.htouched + (size_t)r0 * A.I;
-    int nt = A.unit_nt[u0];
+    if (threadIdx.x == 0) s_nt = A.unit_nt[u0];
+    __syncthreads();
     for (int c = 1; c < G; c++) {
         double *accc = A.hacc + (size_t)(r0 + c) * A.I * 4;
         const int *tc = A.htouched + (size_t)(r0 + c) * A.I;
         const int ntc = A.unit_nt[u0 + c];
-        for (int b0 = 0; b0 < ntc; b0 += 64) {
+        for (int b0 = 64 * w; b0 < ntc; b0 += 64 * MERGE_WAVES) {
             const int b = b0 + lane;
             bool first = false;
             int e = 0;
@@ -956,13 +1084,40 @@ __global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const in
                 d[0] = s_hi; d[1] = s_lo; d[2] = c_hi; d[3] = c_lo;
                 s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
             }
-            unsigned long long m = __ballot(first);
-            if (first) touched0[nt + __popcll(m & lanemask_lt())] = e;
-            nt += __popcll(m);
+            const unsigned long long m = __ballot(first);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_nt, __popcll(m));
+            base = rl32(base, 0);
+            if (first) touched0[base + __popcll(m & lanemask_lt())] = e;
         }
+        __syncthreads();      // row 0 and its touched list are complete before the next partial row (entries may repeat)
     }
-    int n = finalize_start(A, fin[threadIdx.x >> 6], acc0, touched0, nt, start);
-    if (lane == 0) atomicAdd(&A.counters[0], (unsigned long long)n);
+    const int nt = s_nt;
+    if (w == 0) {
+        if (lane == 0) A.n_cand[start] = nt;
+        unsigned long long off;
+        const bool full = fin_list_offset(A, nt, start, off);
+        if (lane == 0) { s_off = off; s_full = full ? 1 : 0; }
+    }
+    __syncthreads();
+    const int ns = finalize_slice(A, fin[w], acc0, touched0, nt, s_off, s_full != 0, w, MERGE_WAVES);
+    if (lane == 0) s_ns[w] = ns;
+    __syncthreads();
+    if (w == 0) {       // the best of the waves' best
+        volatile double *bv = fin[0].v;
+        volatile int *be = fin[0].e;
+        int nbuf = 0;
+        for (int o = 0; o < MERGE_WAVES; o++) {
+            const int n = s_ns[o];
+            int te = 0;
+            double tv = 0.0;
+            if (lane < n) { te = ((volatile int *)fin[o].oe)[lane]; tv = ((volatile double *)fin[o].ov)[lane]; }
+            if (lane < n) { be[nbuf + lane] = te; bv[nbuf + lane] = tv; }
+            nbuf += n;
+        }
+        fin_cut(fin[0], nbuf, A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
+        if (lane == 0) atomicAdd(&A.counters[0], (unsigned long long)nt);
+    }
 }
 
 // ---- per-start path counts (scheduling weights): T(s) tails of s, sums over src(t), heads of x' -------------
@@ -1017,6 +1172,11 @@ __global__ __launch_bounds__(256) void k_w_starts(int I, const uint8_t *flags, c
 using namespace xmap;
 
 extern "C" {
+#ifdef B_TRACE
+int xmap_debug_btrace(unsigned long long *host, long long n_units) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_btrace), (size_t)n_units * 16);
+}
+#endif
 
 int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls, uint8_t *bb) {
     XM_ARG(S && prefix_cls && bb);
@@ -1154,7 +1314,7 @@ static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items
         }
         XM_LAUNCH_CHECK();
         if (n_heavy > 0) {
-            k_merge<<<dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, st>>>(A, n_heavy, heavy_unit0);
+            k_merge<<<dim3((unsigned)n_heavy), dim3(64 * MERGE_WAVES), 0, st>>>(A, n_heavy, heavy_unit0);
             XM_LAUNCH_CHECK();
         }
     }
@@ -1212,6 +1372,53 @@ static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const in
     A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
     A.n_nb = n_nb; A.nb_list = nb_list; A.nb_id = nb_id;
     return A;
+}
+
+// row-wise construction (k_mid_rows); the tile counters of a row live in LDS: n_nb <= XMAP_MID_ROWS_MAX
+static int mid_rows_lds(int32_t n_nb, size_t *bytes) {
+    *bytes = sizeof(int32_t) * (size_t)n_nb;
+    if (n_nb > XMAP_MID_ROWS_MAX) { set_error("row-wise middle lists need n_nb <= %d (got %d)", XMAP_MID_ROWS_MAX, n_nb); return XMAP_ERR_ARG; }
+    return XMAP_OK;
+}
+
+int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                        const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                        const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                        const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                        int32_t *ng /*[n_nb]*/, int64_t *nrec /*[n_nb]*/) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id && ng && nrec);
+    if (n_nb == 0) return XMAP_OK;
+    size_t lds;
+    int rc = mid_rows_lds(n_nb, &lds);
+    if (rc) return rc;
+    MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
+                         src_flag, n_nb, nb_list, nb_id);
+    XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_mid_rows<0><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, ng, (long long *)nrec, nullptr,
+                                                                                              nullptr, nullptr);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                        const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                        const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                        const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                        const int64_t *dir_ptr /*[n_nb+1]*/, const int64_t *rec_ptr /*[n_nb+1]*/, void *dir, void *midX) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id);
+    XM_ARG(dir_ptr && rec_ptr && dir && midX);
+    if (n_nb == 0) return XMAP_OK;
+    size_t lds;
+    int rc = mid_rows_lds(n_nb, &lds);
+    if (rc) return rc;
+    MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
+                         src_flag, n_nb, nb_list, nb_id);
+    A.midX = (MidX *)midX;
+    XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_mid_rows<1><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(
+        A, nullptr, nullptr, (const long long *)dir_ptr, (const long long *)rec_ptr, (MidDir *)dir);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
 }
 
 int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,

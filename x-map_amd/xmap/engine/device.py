@@ -540,8 +540,9 @@ class Engine(object):
         p[hi:] = 0
         total = int(p.sum())
         if chunk is None:
-            chunk = max(1 << 22, total // 8192)
+            chunk = max(1 << 22, total // int(os.environ.get("XMAP_CHUNK_DIV", "8192")))
         row_bytes = 36 * max(I, 1)
+        row_budget = int(float(os.environ.get("XMAP_ROW_BUDGET_GB", row_budget / (1 << 30))) * (1 << 30))
         while True:
             G = np.where(p > chunk, -(-p // chunk), 1).astype(np.int64)
             G[p == 0] = 0
@@ -569,16 +570,19 @@ class Engine(object):
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
-    def mid_lists(self, E, table_budget=24 << 30):
+    def mid_lists(self, E, table_budget=24 << 30, rows=None):
         """middle lists of all joint paths, one tile of records per (x', x) (stage_b.hip, second formulation).
-        Returns None when the dense n_nb x n_nb tile table would not fit the budget (callers fall back to the
+        rows (default: whenever n_nb <= abi.MID_ROWS_MAX): built row-wise, one block per x' with the row's tile sizes in
+        LDS; otherwise through the dense n_nb x n_nb tile table.  Returns None when neither fits (callers fall back to the
         per-path enumeration)."""
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
         nb_list = torch.nonzero(E.cls[:I] == 2).flatten().to(torch.int32).contiguous()
         n_nb = int(nb_list.numel())
-        if n_nb == 0 or n_nb * n_nb * 12 > table_budget:
+        if rows is None:
+            rows = n_nb <= abi.MID_ROWS_MAX and os.environ.get("XMAP_MID_TABLE") != "1"
+        if n_nb == 0 or (not rows and n_nb * n_nb * 12 > table_budget):
             return None
         M = ExtResult()
         M.n_nb, M.nb_list = n_nb, nb_list
@@ -587,6 +591,21 @@ class Engine(object):
         common = (i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags), vp(E.att[0]), vp(E.att[1]),
                   vp(E.att[2]), vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]), i32(n_nb), vp(M.nb_list),
                   vp(M.nb_id))
+        if rows:
+            with self.timed("mid_build"):
+                M.ng = self._empty(n_nb, torch.int32)
+                nrec = self._empty(n_nb, torch.int64)
+                check(lib.xmap_mid_rows_count(st, *common, vp(M.ng), vp(nrec)))
+                M.dir_ptr = self._zeros(n_nb + 1, torch.int64)
+                rec_ptr = self._zeros(n_nb + 1, torch.int64)
+                tx, tg = C.c_int64(0), C.c_int64(0)
+                check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(M.ng), vp(M.dir_ptr), i64(n_nb), C.byref(tg)))
+                check(lib.xmap_exclusive_scan_i64(st, vp(nrec), vp(rec_ptr), i64(n_nb), C.byref(tx)))
+                M.n_records, M.n_tiles = int(tx.value), int(tg.value)
+                M.dir = self._empty(max(M.n_tiles, 1) * 3, torch.int64)
+                M.midX = self._empty(max(M.n_records, 1) * 8, torch.float64)
+                check(lib.xmap_mid_rows_place(st, *common, vp(M.dir_ptr), vp(rec_ptr), vp(M.dir), vp(M.midX)))
+            return M
         with self.timed("mid_build"):
             tile_cnt = self._empty(n_nb * n_nb, torch.int32)
             M.ng = self._zeros(n_nb, torch.int32)

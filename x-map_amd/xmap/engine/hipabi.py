@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("XMAP_HIP_LIB") or os.path.normpath(os.path.join(HERE,
 COSINE, ADJUST_COSINE = 0, 1
 METHODS = {"cosine": COSINE, "adjust_cosine": ADJUST_COSINE}
 TOPC = 10
+MID_ROWS_MAX = 40000      # XMAP_MID_ROWS_MAX
 ERR_HIP, ERR_ARG, ERR_OVERFLOW, ERR_CAPACITY = -1, -2, -3, -4     # XMAP_ERR_* of include/xmap_hip.h
 
 
@@ -40,7 +41,8 @@ EXPORTS = [
     "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", "xmap_sim_plan", "xmap_sim_units", "xmap_sim_count",
     "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
     "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_bridge_flags", "xmap_knn_classify", "xmap_reverse_count",
-    "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", "xmap_mid_tally", "xmap_mid_place", "xmap_extend_paths2", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
+    "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", "xmap_mid_tally", "xmap_mid_place",
+    "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_extend_paths2", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
 ]
 
 if not os.path.exists(LIB_PATH):
