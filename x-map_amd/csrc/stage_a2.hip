@@ -428,6 +428,19 @@ __device__ __forceinline__ unsigned long long ls_key(double d) {
     return (d != d) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(d);
 }
 
+// -DA_TRACE: per-unit time stamps (scratch/trace_a.py reads them): a unit of the smallest class lives ~14 us -- 2.0 us
+// until its item / partition / rater range are read, 3.4 us until the first rater records and prefixes are in, 9.7 us
+// until its (single) step of 8 raters is in the table, 4.3 us of finalisation and appends -- and holds its LDS table
+// all that time; LDS capacity x unit lifetime (79 GB us over 41 MB of LDS = 1.9 ms) is what bounds the class launches.
+#ifdef A_TRACE
+__device__ unsigned long long g_atrace[1 << 21][2];   // per light unit: begin, end (wall_clock64, 100 MHz)
+__device__ unsigned int g_astamp[1 << 21][4];          // offsets from begin: unit read, first rater records in, walk done
+struct ATraceEnd { long long u; long long t0;
+    __device__ ~ATraceEnd() { if (threadIdx.x == 0 && u < (1 << 21)) { g_atrace[u][0] = (unsigned long long)t0; g_atrace[u][1] = wall_clock64(); } } };
+#define A_STAMP(k) do { if (threadIdx.x == 0 && unit < (1 << 21)) g_astamp[unit][k] = (unsigned)(wall_clock64() - (unsigned long long)tr_.t0); } while (0)
+#else
+#define A_STAMP(k) do {} while (0)
+#endif
 template <int METHOD, int LOG_SLOTS, int NW, bool LS>
 __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     constexpr int SLOTS_ = 1 << LOG_SLOTS;
@@ -446,6 +459,9 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     const int lane = lane_id();
     const long long unit = A.unit_lo + blockIdx.x;
     if (unit >= A.unit_hi) return;
+#ifdef A_TRACE
+    ATraceEnd tr_{unit, (long long)wall_clock64()};
+#endif
     const int i = uniform(A.uq_item[unit]);
     const int tcls = A.small[i];   // 1: 128 slots, 3: 256, 2: 512, 0: 1024, 4: 1024 shared by 16 waves
     if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : (NW == 16 ? 4 : 0))))) return;   // not reached: class-major units
@@ -465,6 +481,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     const int p1 = uniform((int)A.iptr[i + 1]);
     const int g = lane / GRP, sub = lane % GRP;
     int ovf = 0;
+    A_STAMP(0);
 
     // walk(body): every co-rating of this unit's raters (those of hash partition q); body(act, j, jw, rj, ri, a, gei)
     // runs once per lane and inner step.  Wave w takes every NW-th block of 64 raters.
@@ -480,6 +497,9 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
                 if (ADJ) au = A.u_avg[rr.user];
             }
             const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
+#ifdef A_TRACE
+            if (base == p0 + 64 * w && __shfl(e0, 0, 64) >= 0) A_STAMP(1);
+#endif
             // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
             int nb0 = 0, nb1 = 0, npw = 0, njw = 0;
             float nrj = 0.f;
@@ -563,6 +583,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             }
         }
     });
+    A_STAMP(2);
     if (NW > 1) {
         if (ovf) s_ovf = 1;
         __syncthreads();          // all raters are in the table
@@ -838,6 +859,14 @@ static SideStreams *side_streams() {
 }
 
 extern "C" {
+#ifdef A_TRACE
+int xmap_debug_astamp(unsigned int *host, long long n_units) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_astamp), (size_t)n_units * 16);
+}
+int xmap_debug_atrace(unsigned long long *host, long long n_units) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_atrace), (size_t)n_units * 16);
+}
+#endif
 
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]: CH, n_heavy*/, int32_t *hid, int32_t *hlist /*[1024]*/,
