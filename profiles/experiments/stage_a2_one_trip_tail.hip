@@ -1,3 +1,6 @@
+// EXPERIMENT, not built: stage_a2.hip with append_pairs reserving the COO segment per occupied slot up front and gathering the
+// heavy ids together with the norms (one round trip of tail instead of three).  Parity-green; k_pair_tri unchanged at 2.46 ms
+// (DESIGN.md 7.1).
 // stage_a2.hip -- stage A, second formulation: every unordered item pair is computed ONCE, in the row of
 // its lighter item, and mirrored into the CSR afterwards (baseliner_calculate_sim_pipeline, reference
 // utils/assist.py:66-77; core/baselinerSim.py:176-216).  sim, mutu and n_ij are symmetric in the reference
@@ -320,6 +323,7 @@ struct TriArgs {
     long long shard_cap;            // COO entries per shard
     unsigned long long *shard_cur;  // [COO_SHARDS] cursors
     unsigned long long *shard_occ;  // [COO_SHARDS] unordered pairs evaluated
+    unsigned long long *shard_kept; // [COO_SHARDS] unordered pairs kept
     int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
     double *coo_aux;                // optional 6th column (RecommenderSim: local sensitivity)
     int *rowcnt;
@@ -346,43 +350,64 @@ constexpr int COO_SHARDS = 4096;
 // up to ~I rows, and that many atomics on one word would serialise (k_fold_heavy adds the replicas up).
 constexpr int HEAVY_SHARDS = 64;
 
-// finalise(s, j, n, m, sim, occupied) -> keep.  Pass 1 finalises every slot once (the result is parked by `park`),
-// pass 2 writes the kept ones.
-template <typename Fin, typename Park, typename Get, typename Aux>
-__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begin, int n_slots, Fin fin, Park park, Get get,
+// peek(s, j) -> occupied (and the partner).  finalise(s, j, n, m, sim, occupied) -> keep.  Pass 1 finalises every slot
+// once (the result is parked by `park`), pass 2 writes the kept ones.
+// A unit holds its LDS table until its last instruction, and a unit of a few raters lives ~14 us, nearly all of it
+// dependent memory round trips (per-unit trace, profiles/): LDS capacity x unit lifetime is what bounds the pair
+// kernels.  So the tail is ONE round trip: the COO segment is reserved up front for every OCCUPIED slot (known from LDS
+// alone; the entries a filter drops stay -1 at the end of the segment), and the partner's norm and heavy id are
+// gathered while that atomic is in flight; the kept count goes to a third per-shard word.
+template <int ITERS, typename Peek, typename Fin, typename Park, typename Get, typename Aux>
+__device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begin, Peek peek, Fin fin, Park park, Get get,
                                              Aux aux) {
     const int lane = lane_id();
     const int shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (COO_SHARDS - 1);
-    int kept = 0, occ = 0;
-    for (int s0 = s_begin; s0 < n_slots; s0 += 64) {
-        int j, n, m; double sv; bool o;
-        bool keep = fin(s0 + lane, j, n, m, sv, o);
-        park(s0 + lane, o, keep, sv);
-        kept += __popcll(__ballot(keep));
-        occ += __popcll(__ballot(o));
+    int occ = 0;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        int j;
+        occ += __popcll(__ballot(peek(s_begin + 64 * it + lane, j)));
     }
-    if (lane == 0 && occ) atomicAdd(&A.shard_occ[shard], (unsigned long long)occ);
-    if (!kept) return;
+    if (!occ) return;
     unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&A.shard_cur[shard], (unsigned long long)occ);      // used after pass 1
+    int kept = 0;
+    int hjv[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int s = s_begin + 64 * it + lane;
+        int j = 0, n, m; double sv; bool o;
+        const bool oc = peek(s, j);
+        hjv[it] = oc ? A.hid[j] : -1;
+        bool keep = fin(s, j, n, m, sv, o);
+        park(s, o, keep, sv);
+        kept += __popcll(__ballot(keep));
+    }
     if (lane == 0) {
-        base = atomicAdd(&A.shard_cur[shard], (unsigned long long)kept);
-        atomicAdd(&A.rowcnt[i], kept);
+        atomicAdd(&A.shard_occ[shard], (unsigned long long)occ);
+        if (kept) {
+            atomicAdd(&A.shard_kept[shard], (unsigned long long)kept);
+            atomicAdd(&A.rowcnt[i], kept);
+        }
     }
     base = ((unsigned long long)(unsigned)rl32((int)(base >> 32), 0) << 32) | (unsigned)rl32((int)(base & 0xffffffffull), 0);
-    if ((long long)(base + kept) > A.shard_cap) {
+    if ((long long)(base + occ) > A.shard_cap) {
         if (lane == 0) atomicOr(&A.counters[3], 1ull);
         return;
     }
+    if (!kept) return;
     base += (unsigned long long)shard * (unsigned long long)A.shard_cap;
-    for (int s0 = s_begin; s0 < n_slots; s0 += 64) {
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int s = s_begin + 64 * it + lane;
         int j, n, m; double sv;
-        bool keep = get(s0 + lane, j, n, m, sv);
+        bool keep = get(s, j, n, m, sv);
         unsigned long long km = __ballot(keep);
         if (keep) {
             long long p = (long long)base + __popcll(km & lanemask_lt());
             A.coo_i[p] = i; A.coo_j[p] = j; A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
-            if (A.coo_aux) A.coo_aux[p] = aux(s0 + lane);
-            const int hj = A.hid[j];
+            if (A.coo_aux) A.coo_aux[p] = aux(s);
+            const int hj = hjv[it];
             if (j == i) {}   // a row paired with itself (RecommenderSim) has no mirror entry
             else if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
             else atomicAdd(&A.rowcnt[j], 1);
@@ -428,13 +453,9 @@ __device__ __forceinline__ unsigned long long ls_key(double d) {
     return (d != d) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(d);
 }
 
-// -DA_TRACE: per-unit time stamps (profiles/tools/trace_a.py reads them): a unit of the smallest class lives ~14 us -- 2.0 us
-// until its item / partition / rater range are read, 3.4 us until the first rater records and prefixes are in, 9.7 us
-// until its (single) step of 8 raters is in the table, 4.3 us of finalisation and appends -- and holds its LDS table
-// all that time; LDS capacity x unit lifetime (79 GB us over 41 MB of LDS = 1.9 ms) is what bounds the class launches.
 #ifdef A_TRACE
 __device__ unsigned long long g_atrace[1 << 21][2];   // per light unit: begin, end (wall_clock64, 100 MHz)
-__device__ unsigned int g_astamp[1 << 21][4];          // offsets from begin: unit read, first rater records in, walk done
+__device__ unsigned int g_astamp[1 << 21][4];          // offsets from begin: unit read, raters' first prefixes in, walk done, tail reserved
 struct ATraceEnd { long long u; long long t0;
     __device__ ~ATraceEnd() { if (threadIdx.x == 0 && u < (1 << 21)) { g_atrace[u][0] = (unsigned long long)t0; g_atrace[u][1] = wall_clock64(); } } };
 #define A_STAMP(k) do { if (threadIdx.x == 0 && unit < (1 << 21)) g_astamp[unit][k] = (unsigned)(wall_clock64() - (unsigned long long)tr_.t0); } while (0)
@@ -497,9 +518,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
                 if (ADJ) au = A.u_avg[rr.user];
             }
             const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
-#ifdef A_TRACE
             if (base == p0 + 64 * w && __shfl(e0, 0, 64) >= 0) A_STAMP(1);
-#endif
             // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
             int nb0 = 0, nb1 = 0, npw = 0, njw = 0;
             float nrj = 0.f;
@@ -629,7 +648,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             atomicMax(&s_ls[h], k1 > k2 ? k1 : k2);
         });
         if (NW > 1) __syncthreads();
-        append_pairs(A, i, w * (SLOTS_ / NW), (w + 1) * (SLOTS_ / NW),
+        append_pairs<SLOTS_ / NW / 64>(A, i, w * (SLOTS_ / NW),
+            [&](int s, int &j) { const uint32_t kj = key[s]; j = (int)kj; return kj != T_EMPTY; },
             [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
                 const uint32_t kj = key[s];
                 o = kj != T_EMPTY;
@@ -647,7 +667,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             [&](int s) { return __longlong_as_double((long long)s_ls[s]); });
         return;
     }
-    append_pairs(A, i, w * (SLOTS_ / NW), (w + 1) * (SLOTS_ / NW),
+    append_pairs<SLOTS_ / NW / 64>(A, i, w * (SLOTS_ / NW),
+        [&](int s, int &j) { const uint32_t kj = key[s]; j = (int)kj; return kj != T_EMPTY; },
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             uint32_t kj = key[s];
             o = kj != T_EMPTY;
@@ -774,7 +795,8 @@ __global__ __launch_bounds__(256) void k_heavy_merge(TriArgs A, int n_heavy) {
     if (nc == 0) return;
     __syncthreads();
     const int w = threadIdx.x >> 6;
-    append_pairs(A, i, w * (HMAX / 4), (w + 1) * (HMAX / 4),
+    append_pairs<HMAX / 4 / 64>(A, i, w * (HMAX / 4),
+        [&](int s, int &j) { const bool o = cnt[s] != 0; j = o ? A.hlist[s] : 0; return o; },
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             o = cnt[s] != 0;
             if (!o) return false;
@@ -970,7 +992,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     const int32_t *uc_item, const int32_t *uc_c, int32_t n_heavy_units, int32_t n_heavy, int phases,
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, double *coo_ls /*or NULL*/,
-                    int32_t *rowcnt, int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/,
+                    int32_t *rowcnt, int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[3][4096]*/,
                     int64_t *d_counters /*[4]*/) {
     XM_ARG(R && u_avg && norms && rc && ub);
     XM_ARG(Q && small && uq_item && uq_q && cls_ptr && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
@@ -984,7 +1006,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     hipStream_t st = (hipStream_t)stream;
     if (phases & 8) {   // reset the COO cursor / counters / row counts
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
-        XM_HIP(hipMemsetAsync(d_shards, 0, 2 * COO_SHARDS * sizeof(int64_t), st));
+        XM_HIP(hipMemsetAsync(d_shards, 0, 3 * COO_SHARDS * sizeof(int64_t), st));
         XM_HIP(hipMemsetAsync(rowcnt_h, 0, sizeof(int32_t) * HEAVY_SHARDS * HMAX, st));
         XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry
         XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
@@ -998,7 +1020,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.uc_ptr = (const long long *)uc_ptr; A.C = C;
     A.hp_hi = hp_hi; A.hp_lo = hp_lo; A.hp_cnt = hp_cnt; A.hp_mut = hp_mut;
     A.shard_cap = coo_cap / COO_SHARDS; A.shard_cur = (unsigned long long *)d_shards;
-    A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
+    A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.shard_kept = (unsigned long long *)d_shards + 2 * COO_SHARDS;
+    A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.coo_aux = coo_ls;
     A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials

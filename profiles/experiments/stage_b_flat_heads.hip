@@ -1,0 +1,1328 @@
+// EXPERIMENT, not built: stage_b.hip with heads_X rewritten (records of all heads of a column laid end to end over the lanes, next
+// directory entry kept in registers, row entries requested before the reduction).  Parity-green; 0.93 s at 4 waves per SIMD,
+// 1.10 s at 5 -- no gain over the shipped form.
+// stage_b.hip -- cross-domain top-k similarity extension (extender_pipeline, reference
+// utils/assist.py:80-133; core/extender.py).
+//
+// Kernels (DESIGN.md section "Stage B"):
+//   k_bridge_flags  : bb[i] = any kept pair of row i whose 2-char prefixes differ        (HBM-bound, one pass over D')
+//   k_knn_classify  : per row, chunked bitonic sort in LDS by (|sim| desc, col asc) and the two
+//                     filtered top-k lists of find_knn_items                              (HBM-bound, one pass over D')
+//   k_reverse       : reverse adjacencies (attach / src / rnn) built in row order with an O(1)
+//                     membership test against the k-th entry of the neighbour's list       (HBM-bound, one pass over D')
+//   k_paths         : streamed path enumeration, one wave per start item, fp64 (s_p, c_p) in
+//                     registers, per-start accumulators, fused top-10                      (ALU / latency bound)
+#include "common.h"
+
+namespace xmap {
+
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_bridge_flags(int I, const long long *row_ptr, const int *col,
+                                                      const int *prefix_cls, uint8_t *bb) {
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= I) return;
+    int lane = lane_id();
+    long long lo = row_ptr[i], hi = row_ptr[i + 1];
+    int pi = prefix_cls[i];
+    int found = 0;
+    for (long long b = lo; b < hi && !found; b += 64) {
+        long long p = b + lane;
+        int f = (p < hi) && (prefix_cls[col[p]] != pi);
+        found = __ballot(f) != 0ull;
+    }
+    if (lane == 0) bb[i] = (uint8_t)found;
+}
+
+// =============================================================================================
+constexpr int K_THREADS = 256;
+constexpr int K_CH = 2048;  // entries sorted per chunk (32 KB of LDS)
+
+__device__ __forceinline__ bool before(unsigned long long ka, int ca, unsigned long long kb, int cb) {
+    return (ka > kb) || (ka == kb && ca < cb);
+}
+
+// exclusive scan of one long long per thread across the block (256 threads)
+__device__ __forceinline__ long long block_scan_ll(long long v, long long *total, long long *smem) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < K_THREADS / 64; k++) {
+        long long s = smem[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+struct KnnArgs {
+    int I, k;
+    const long long *row_ptr;
+    const int *col;
+    const double *sim;
+    const int *mutu;
+    const int *nij;
+    const double *info;
+    const double *frac;
+    const uint8_t *bb;
+    const int *suffix_cls;
+    const uint32_t *contains_mask;
+    uint8_t *cls;
+    int *kcnt;
+    int *kcol;
+    double *kval;
+};
+
+__global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
+    __shared__ unsigned long long skey[K_CH];
+    __shared__ int scol[K_CH];
+    __shared__ int spos[K_CH];
+    __shared__ long long sscan[4];
+
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const long long lo = A.row_ptr[i];
+    const int n = (int)(A.row_ptr[i + 1] - lo);
+    const int k = A.k;
+    if (n == 0) {
+        if (tid == 0) {
+            A.cls[i] = 0;
+            A.kcnt[(size_t)i * 2] = 0;
+            A.kcnt[(size_t)i * 2 + 1] = 0;
+        }
+        return;
+    }
+    const bool isbb = A.bb[i] != 0;
+    const int sc = A.suffix_cls[i];
+    int nc = 0, consumed = 0;
+    for (;;) {
+        const int take = (K_CH - nc) < (n - consumed) ? (K_CH - nc) : (n - consumed);
+        for (int t = tid; t < take; t += K_THREADS) {
+            int p = consumed + t;
+            double s = A.sim[lo + p];
+            skey[nc + t] = (unsigned long long)__double_as_longlong(fabs(s));
+            scol[nc + t] = A.col[lo + p];
+            spos[nc + t] = p;
+        }
+        const int total = nc + take;
+        int N = 2;
+        while (N < total) N <<= 1;
+        for (int t = total + tid; t < N; t += K_THREADS) {
+            skey[t] = 0ull;
+            scol[t] = 0x7fffffff;
+            spos[t] = -1;
+        }
+        __syncthreads();
+        // bitonic sort by (|sim| desc, col asc); pads (|sim| = 0) end up last
+        for (int k2 = 2; k2 <= N; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (N >> 1); t += K_THREADS) {
+                    int a = 2 * t - (t & (j - 1));
+                    int b = a + j;
+                    bool up = (a & k2) == 0;
+                    unsigned long long ka = skey[a], kb = skey[b];
+                    int ca = scol[a], cb = scol[b];
+                    bool sw = up ? before(kb, cb, ka, ca) : before(ka, ca, kb, cb);
+                    if (sw) {
+                        skey[a] = kb; skey[b] = ka;
+                        scol[a] = cb; scol[b] = ca;
+                        int pa = spos[a], pb = spos[b];
+                        spos[a] = pb; spos[b] = pa;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // class predicates, ranks in sorted order
+        const int per = (N + K_THREADS - 1) / K_THREADS;
+        const int s0 = tid * per;
+        int cA = 0, cB = 0;
+        for (int t = s0; t < s0 + per && t < total; t++) {
+            int c = scol[t];
+            bool pa, pb;
+            if (isbb) {
+                bool has = (A.contains_mask[c] >> sc) & 1u;  // domain_label in pair[0]
+                pa = !has; pb = has;
+            } else {
+                pa = A.bb[c] != 0; pb = true;                 // NB_NN keeps every neighbour
+            }
+            cA += pa; cB += pb;
+        }
+        long long tot;
+        long long ex = block_scan_ll(((long long)cB << 32) | (unsigned)cA, &tot, sscan);
+        int rA = (int)(ex & 0xffffffffll), rB = (int)(ex >> 32);
+        const int totA = (int)(tot & 0xffffffffll), totB = (int)(tot >> 32);
+        consumed += take;
+        const bool last = consumed >= n;
+        if (last) {
+            for (int t = s0; t < s0 + per && t < total; t++) {
+                int c = scol[t];
+                bool pa, pb;
+                if (isbb) {
+                    bool has = (A.contains_mask[c] >> sc) & 1u;
+                    pa = !has; pb = has;
+                } else {
+                    pa = A.bb[c] != 0; pb = true;
+                }
+                long long p = lo + spos[t];
+                if ((pa && rA < k) || (pb && rB < k)) {
+                    double sv = A.sim[p];
+                    double mu = (double)A.mutu[p];
+                    double fr = A.frac ? A.frac[p]
+                                       : 1.0 * mu / (A.info[(size_t)i * 4 + 3] + A.info[(size_t)c * 4 + 3] - (double)A.nij[p]);
+                    if (pa && rA < k) {
+                        size_t o = ((size_t)i * 2 + 0) * k + rA;
+                        A.kcol[o] = c; A.kval[o * 3] = sv; A.kval[o * 3 + 1] = mu; A.kval[o * 3 + 2] = fr;
+                    }
+                    if (pb && rB < k) {
+                        size_t o = ((size_t)i * 2 + 1) * k + rB;
+                        A.kcol[o] = c; A.kval[o * 3] = sv; A.kval[o * 3 + 1] = mu; A.kval[o * 3 + 2] = fr;
+                    }
+                }
+                rA += pa; rB += pb;
+            }
+            if (tid == 0) {
+                int nA = totA < k ? totA : k, nB = totB < k ? totB : k;
+                uint8_t c = isbb ? 1 : (nA > 0 ? 2 : 0);  // no bridge neighbour -> dropped (extender.py:39)
+                A.cls[i] = c;
+                A.kcnt[(size_t)i * 2] = c ? nA : 0;
+                A.kcnt[(size_t)i * 2 + 1] = c ? nB : 0;
+            }
+            return;
+        }
+        // carry the selected <= 2k entries to the front (sorted order kept), then take the next chunk
+        unsigned long long rk[K_CH / K_THREADS];
+        int rc[K_CH / K_THREADS], rp[K_CH / K_THREADS];
+        int nk = 0;
+        for (int t = s0; t < s0 + per && t < total; t++) {
+            int c = scol[t];
+            bool pa, pb;
+            if (isbb) {
+                bool has = (A.contains_mask[c] >> sc) & 1u;
+                pa = !has; pb = has;
+            } else {
+                pa = A.bb[c] != 0; pb = true;
+            }
+            if ((pa && rA < k) || (pb && rB < k)) { rk[nk] = skey[t]; rc[nk] = c; rp[nk] = spos[t]; nk++; }
+            rA += pa; rB += pb;
+        }
+        long long tk;
+        long long ek = block_scan_ll((long long)nk, &tk, sscan);
+        for (int q = 0; q < nk; q++) {
+            skey[ek + q] = rk[q]; scol[ek + q] = rc[q]; spos[ek + q] = rp[q];
+        }
+        nc = (int)tk;
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// membership of item a in list l of neighbour b, given |sim(a,b)| (bit-symmetric by construction):
+// a is in the list iff it passes the list's class predicate and sorts at or before the list's
+// last entry in the order (|sim| desc, col asc) -- or the list is not full.
+struct RevArgs {
+    int I, k, mode;
+    const long long *row_ptr;
+    const int *col;
+    const double *sim;
+    const int *mutu;
+    const int *nij;
+    const double *info;
+    const double *frac;
+    const uint8_t *bb;
+    const uint8_t *cls;
+    const int *kcnt;
+    const int *kcol;
+    const double *kval;
+    const int *suffix_cls;
+    const uint32_t *contains_mask;
+    const uint8_t *flags;
+    const long long *attach_ptr;
+    int *rcnt;
+    const long long *rptr;
+    int *ridx;
+    double *rval;
+    uint8_t *rflag;
+};
+
+__device__ __forceinline__ bool in_list(const RevArgs &A, int b, int l, int a, double abs_sim) {
+    int c = A.kcnt[(size_t)b * 2 + l];
+    if (c == 0) return false;
+    bool pred;
+    if (A.cls[b] == 1) {
+        bool has = (A.contains_mask[a] >> A.suffix_cls[b]) & 1u;
+        pred = (l == 0) ? !has : has;
+    } else {
+        pred = (l == 0) ? (A.bb[a] != 0) : true;
+    }
+    if (!pred) return false;
+    if (c < A.k) return true;
+    size_t o = ((size_t)b * 2 + l) * A.k + (c - 1);
+    double la = fabs(A.kval[o * 3]);
+    return (abs_sim > la) || (abs_sim == la && a <= A.kcol[o]);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
+    int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= A.I) return;
+    int lane = lane_id();
+    long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
+    bool row_ok = true;
+    if (A.mode == 1) row_ok = (A.flags[a] & 2) != 0;  // "T:" in t
+    long long out = FILL ? A.rptr[a] : 0;
+    int total = 0;
+    if (row_ok)
+        for (long long base = lo; base < hi; base += 64) {
+            long long p = base + lane;
+            bool ok = false;
+            int b = 0;
+            double sv = 0.0;
+            uint8_t fl = 0;
+            if (p < hi) {
+                b = A.col[p];
+                sv = A.sim[p];
+                double ab = fabs(sv);
+                int cb = A.cls[b];
+                if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
+                    ok = (cb == 2) && in_list(A, b, 0, a, ab);
+                } else if (A.mode == 1) {    // src(t = a): s = b
+                    ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
+                         (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
+                    if (ok) {
+                        bool joint = (A.cls[a] == 1) && (A.attach_ptr[a + 1] > A.attach_ptr[a]) &&
+                                     (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
+                        fl = joint ? 1 : 0;
+                    }
+                } else {                     // rnn(y = a): x = b non-bridge record with a in NB_NN(x)
+                    ok = (cb == 2) && in_list(A, b, 1, a, ab);
+                }
+            }
+            unsigned long long m = __ballot(ok);
+            if (FILL && ok) {
+                long long o = out + __popcll(m & lanemask_lt());
+                double mu = (double)A.mutu[p];
+                A.ridx[o] = b;
+                A.rval[o * 3] = sv;
+                A.rval[o * 3 + 1] = mu;
+                A.rval[o * 3 + 2] = A.frac ? A.frac[p]
+                                           : 1.0 * mu / (A.info[(size_t)a * 4 + 3] + A.info[(size_t)b * 4 + 3] - (double)A.nij[p]);
+                if (A.rflag) A.rflag[o] = fl;
+            }
+            int c = __popcll(m);
+            out += c;
+            total += c;
+        }
+    if (!FILL && lane == 0) A.rcnt[a] = total;
+}
+
+// =============================================================================================
+struct PathArgs {
+    int I, k;
+    const uint8_t *cls;
+    const int *kcnt;
+    const int *kcol;
+    const double *kval;
+    const uint8_t *flags;
+    const long long *att_ptr; const int *att_idx; const double *att_val;
+    const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
+    const long long *rnn_ptr; const int *rnn_idx; const double *rnn_val;
+    // work units: (start, chunk c of G).  G == 1: the unit owns the start, accumulates in the wave's slot
+    // row and finalises it.  G > 1: the start's (head, t) entries are dealt round-robin to G units, each
+    // with a dedicated row (unit_row); k_merge adds the rows up and finalises.
+    int n_units;
+    const int *unit_start; const int *unit_c; const int *unit_G; const int *unit_row; int *unit_nt;
+    int n_slots;
+    double *acc; int *touched;     // slot rows   [n_slots][I][4] / [n_slots][I]
+    double *hacc; int *htouched;   // heavy rows  [n_rows][I][4]  / [n_rows][I]
+    int *n_cand; int *top_end; double *top_val;
+    long long xs_cap; long long *xs_off; int *xs_end; double *xs_val;
+    unsigned long long *counters;  // [0] total candidates, [1] paths, [2] work cursor, [3] xs cursor
+};
+
+struct Carry { double sm, mu, c; };  // sum sim*mutu, sum mutu, prod frac_mutu along the path so far
+
+__device__ __forceinline__ Carry first_edge(double sim, double mutu, double frac) {
+    Carry r; r.sm = sim * mutu; r.mu = mutu; r.c = frac; return r;   // python sum(): 0 + x == x
+}
+__device__ __forceinline__ Carry add_edge(Carry a, double sim, double mutu, double frac) {
+    Carry r; r.sm = a.sm + sim * mutu; r.mu = a.mu + mutu; r.c = a.c * frac; return r;
+}
+
+// Error-free accumulation (Knuth two-sum, double-double running sums): the per-(start,end) sums become
+// independent of the order in which paths are enumerated (to ~2^-104), so items with identical
+// path multisets tie exactly and the tie-break (ascending end index) is well defined.
+struct WaveAcc {
+    double *acc; int *touched; int nt; unsigned long long paths;
+    __device__ __forceinline__ void add(bool active, int end, Carry p) {
+        bool first = false;
+        if (active) {
+            double sp = (p.mu != 0.0) ? 1.0 * p.sm / p.mu : 0.0;   // calculate_path_confidence (extender.py:83-89)
+            double *a = acc + (size_t)end * 4;
+            double s_hi = a[0], s_lo = a[1], c_hi = a[2], c_lo = a[3];
+            first = (c_hi == 0.0);
+            dd_add(s_hi, s_lo, sp * p.c);
+            dd_add(c_hi, c_lo, p.c);
+            a[0] = s_hi; a[1] = s_lo; a[2] = c_hi; a[3] = c_lo;
+        }
+        unsigned long long m = __ballot(first);
+        if (first) touched[nt + __popcll(m & lanemask_lt())] = end;
+        nt += __popcll(m);
+        paths += __popcll(__ballot(active));
+    }
+};
+
+// tails of one (t,s) after edge (t,s): end s is accumulated by the caller (vector step over s);
+// here: for x in attach(s): end x, then end y for y in NN(x)         (extender.py:134-138 / :154-158)
+__device__ __forceinline__ void tails(const PathArgs &A, WaveAcc &W, int s, Carry c_ts) {
+    const int lane = lane_id();
+    const int k = A.k;
+    long long a0 = A.att_ptr[s], a1 = A.att_ptr[s + 1];
+    for (long long ap = a0; ap < a1; ap++) {
+        const int x = A.att_idx[ap];
+        const Carry c_sx = add_edge(c_ts, A.att_val[ap * 3], A.att_val[ap * 3 + 1], A.att_val[ap * 3 + 2]);
+        const int nn = A.kcnt[(size_t)x * 2 + 1];
+        for (int b = 0; b < nn + 1; b += 64) {
+            int idx = b + lane;
+            bool act = idx < nn + 1;
+            int end = x;
+            Carry c = c_sx;
+            if (act && idx > 0) {
+                size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
+                end = A.kcol[o];
+                c = add_edge(c_sx, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+            }
+            W.add(act, end, c);
+        }
+    }
+}
+
+// all (t,s) of src(t) behind a given head carry (head_len = number of edges in front of (t,s))
+__device__ __forceinline__ void through_t(const PathArgs &A, WaveAcc &W, int t, bool has_head, Carry head) {
+    const int lane = lane_id();
+    long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
+    for (long long base = s0; base < s1; base += 64) {
+        long long p = base + lane;
+        bool act = p < s1;
+        int s = 0;
+        Carry c; c.sm = 0; c.mu = 0; c.c = 0;
+        if (act) {
+            if (has_head && !(A.src_flag[p] & 1)) act = false;  // joint paths need (t,s) in TGT as well
+        }
+        if (act) {
+            s = A.src_idx[p];
+            double sv = A.src_val[p * 3], mu = A.src_val[p * 3 + 1], fr = A.src_val[p * 3 + 2];
+            c = has_head ? add_edge(head, sv, mu, fr) : first_edge(sv, mu, fr);
+        }
+        W.add(act, s, c);  // path ... -> t -> s
+        unsigned long long m = __ballot(act);
+        while (m) {
+            int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int sb = rl32(s, l);
+            Carry cb;
+            cb.sm = rld(c.sm, l); cb.mu = rld(c.mu, l); cb.c = rld(c.c, l);
+            tails(A, W, sb, cb);
+        }
+    }
+}
+
+// wave-wide selection of the XMAP_TOPC best of nt candidates in the order (|xsim| desc, end asc);
+// get(b, end, val) returns candidate b.  Lane 0 writes the result.
+template <typename Get>
+__device__ __forceinline__ void select_topc(int nt, Get get, int *top_end, double *top_val) {
+    const int lane = lane_id();
+    unsigned long long pk = 0;
+    int pe = -1;
+    int nsel = nt < XMAP_TOPC ? nt : XMAP_TOPC;
+    for (int r = 0; r < nsel; r++) {
+        unsigned long long bk = 0;
+        int be = 0x7fffffff;
+        double bv = 0.0;
+        bool have = false;
+        for (int b = lane; b < nt; b += 64) {
+            int e; double v;
+            get(b, e, v);
+            unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v));
+            bool after_prev = (r == 0) || (key < pk) || (key == pk && e > pe);
+            if (after_prev && (!have || key > bk || (key == bk && e < be))) { bk = key; be = e; bv = v; have = true; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            unsigned long long ok = __shfl_xor(bk, m, 64);
+            int oe = __shfl_xor(be, m, 64);
+            double ov = __shfl_xor(bv, m, 64);
+            int oh = __shfl_xor((int)have, m, 64);
+            if (oh && (!have || ok > bk || (ok == bk && oe < be))) { bk = ok; be = oe; bv = ov; have = true; }
+        }
+        pk = bk; pe = be;
+        if (lane == 0) { top_end[r] = be; top_val[r] = bv; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_topc_lists(int I, const long long *xs_ptr, const int *xs_end, const double *xs_val,
+                                                    int *n_cand, int *top_end, double *top_val) {
+    int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= I) return;
+    long long lo = xs_ptr[s];
+    int nt = (int)(xs_ptr[s + 1] - lo);
+    select_topc(nt, [&](int b, int &e, double &v) { e = xs_end[lo + b]; v = xs_val[lo + b]; },
+                top_end + (size_t)s * XMAP_TOPC, top_val + (size_t)s * XMAP_TOPC);
+    if (lane_id() == 0) n_cand[s] = nt;
+}
+
+// xsim = sum(s_p c_p) / sum(c_p) (get_sim, extender.py:198-201), fused top-XMAP_TOPC by (|xsim| desc,
+// end asc) -- all a Generator reads (generator.py:85,109) --, optional full lists, row reset.
+// ONE pass over the start's row: every touched entry is read once, divided, (full mode: written to the start's list,)
+// zeroed, and offered to a running selection.  The row entries are random 32-byte accesses to HBM (a row is larger than
+// an XCD's L2), so the earlier form -- a division pass, XMAP_TOPC selection passes over the row and a reset pass -- cost
+// 12 random accesses per candidate against ~6 for accumulating it.  Running selection: candidates whose key is >= the
+// key of the XMAP_TOPC-th best so far (ties included: the order among equal keys is by end index) are appended to a
+// per-wave LDS buffer; when it passes FIN_CAP entries it is cut back to its exact XMAP_TOPC best, which raises the
+// threshold.  An entry is only ever dropped when XMAP_TOPC entries with a strictly larger key exist, so the result is
+// the exact top of the whole list; a stream in random order appends ~XMAP_TOPC ln(nt / XMAP_TOPC) entries.
+constexpr int FIN_CAP = 128;
+struct FinBuf { double v[FIN_CAP + 64]; int e[FIN_CAP + 64]; double ov[XMAP_TOPC]; int oe[XMAP_TOPC]; };
+
+__device__ __forceinline__ unsigned long long xsim_key(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+
+__device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt, int start) {
+    const int lane = lane_id();
+    volatile double *bv = F.v;
+    volatile int *be = F.e;
+    if (lane == 0) A.n_cand[start] = nt;
+    unsigned long long off = 0;
+    bool full = false;
+    if (A.xs_cap > 0 && nt > 0) {  // full candidate lists (extender_pipeline's RDD) via a cursor
+        if (lane == 0) off = atomicAdd(&A.counters[3], (unsigned long long)nt);
+        off = ((unsigned long long)(unsigned)rl32((int)(off >> 32), 0) << 32) | (unsigned)rl32((int)(off & 0xffffffffull), 0);
+        full = (long long)(off + nt) <= A.xs_cap;
+        if (lane == 0) A.xs_off[start] = full ? (long long)off : -1;
+    }
+    int nbuf = 0;
+    unsigned long long thr = 0;   // key of the XMAP_TOPC-th best so far (0 while fewer have been seen)
+    auto cut = [&](int *out_e, double *out_v) {
+        select_topc(nbuf, [&](int b, int &e, double &v) { e = be[b]; v = bv[b]; }, out_e, out_v);
+        return nbuf < XMAP_TOPC ? nbuf : XMAP_TOPC;
+    };
+    for (int b0 = 0; b0 < nt; b0 += 64) {
+        const int b = b0 + lane;
+        const bool act = b < nt;
+        int e = 0;
+        double v = 0.0;
+        unsigned long long key = 0;
+        if (act) {
+            e = touched[b];
+            double *a = acc + (size_t)e * 4;
+            v = 1.0 * a[0] / a[2];
+            a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
+            key = xsim_key(v);
+            if (full) { A.xs_end[off + b] = e; A.xs_val[off + b] = v; }
+        }
+        const bool q = act && key >= thr;
+        const unsigned long long m = __ballot(q);
+        if (q) { const int p = nbuf + __popcll(m & lanemask_lt()); bv[p] = v; be[p] = e; }
+        nbuf += __popcll(m);
+        if (nbuf > FIN_CAP) {
+            const int ns = cut(F.oe, F.ov);      // lane 0 writes the best ns, in order
+            int te = 0;
+            double tv = 0.0;
+            if (lane < ns) { te = ((volatile int *)F.oe)[lane]; tv = ((volatile double *)F.ov)[lane]; }
+            if (lane < ns) { be[lane] = te; bv[lane] = tv; }
+            nbuf = ns;
+            thr = (ns == XMAP_TOPC) ? xsim_key(rld(tv, XMAP_TOPC - 1)) : 0ull;
+        }
+    }
+    cut(A.top_end + (size_t)start * XMAP_TOPC, A.top_val + (size_t)start * XMAP_TOPC);
+    return nt;
+}
+
+__global__ __launch_bounds__(256) void k_paths(PathArgs A) {
+    __shared__ FinBuf fin[4];
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.n_slots) return;
+    const int lane = lane_id();
+    const int k = A.k;
+    WaveAcc W;
+    W.paths = 0;
+    unsigned long long cand_total = 0;
+    for (;;) {
+        int u_ = 0;
+        if (lane == 0) u_ = (int)atomicAdd(&A.counters[2], 1ull);
+        const int unit = uniform(u_);
+        if (unit >= A.n_units) break;  // every wave reaches this exit: the cursor only grows
+        const int start = uniform(A.unit_start[unit]);
+        const int c = uniform(A.unit_c[unit]);
+        const int G = uniform(A.unit_G[unit]);
+        const int row = uniform(A.unit_row[unit]);
+        if (row < 0) {
+            W.acc = A.acc + (size_t)slot * A.I * 4;
+            W.touched = A.touched + (size_t)slot * A.I;
+        } else {
+            W.acc = A.hacc + (size_t)row * A.I * 4;
+            W.touched = A.htouched + (size_t)row * A.I;
+        }
+        W.nt = 0;
+        int ent = 0;  // running index of the start's (head, t) entries; unit c takes ent % G == c
+        // role T: start = t (final_nonjoint_extend on every SRC record, extender.py:124-140,:180)
+        if (A.flags[start] & 2) {
+            if (G == 1 || ent % G == c) {
+                Carry none; none.sm = 0; none.mu = 0; none.c = 0;
+                through_t(A, W, start, false, none);
+            }
+            ent++;
+        }
+        // role X': start = x' in attach(t) (target_path, extender.py:160-163)
+        if (A.cls[start] == 2) {
+            int nb = A.kcnt[(size_t)start * 2];
+            for (int q = 0; q < nb; q++) {
+                size_t o = ((size_t)start * 2) * k + q;
+                int t = A.kcol[o];
+                if (!(A.flags[t] & 2)) continue;  // BB_other_intra_target keeps "T:" bridges only (:175)
+                if (G == 1 || ent % G == c) {
+                    Carry h = first_edge(A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+                    through_t(A, W, t, true, h);
+                }
+                ent++;
+            }
+        }
+        // role Y': start = y' in NN(x'), x' in attach(t) (longest_path, extender.py:164-167)
+        {
+            long long r0 = A.rnn_ptr[start], r1 = A.rnn_ptr[start + 1];
+            for (long long rp = r0; rp < r1; rp++) {
+                int xp = A.rnn_idx[rp];
+                Carry h0 = first_edge(A.rnn_val[rp * 3], A.rnn_val[rp * 3 + 1], A.rnn_val[rp * 3 + 2]);
+                int nb = A.kcnt[(size_t)xp * 2];
+                for (int q = 0; q < nb; q++) {
+                    size_t o = ((size_t)xp * 2) * k + q;
+                    int t = A.kcol[o];
+                    if (!(A.flags[t] & 2)) continue;
+                    if (G == 1 || ent % G == c) {
+                        Carry h = add_edge(h0, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+                        through_t(A, W, t, true, h);
+                    }
+                    ent++;
+                }
+            }
+        }
+        if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
+        else if (lane == 0) A.unit_nt[unit] = W.nt;
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], cand_total);
+        atomicAdd(&A.counters[1], W.paths);
+    }
+}
+
+// =============================================================================================
+// Second formulation of the enumeration ("middle lists").  Every joint path has the shape
+//   [y'] - x' - t - s - [x - [y]]      with x', x non-bridge items, t in NB_BB(x'), (t,s) joint.
+// For each non-bridge x' the middles (t,s,x) are materialised ONCE, grouped by x (one "tile" per (x', x); a dense
+// n_nb x n_nb count table gives the tile offsets, so the build is a tally pass + a placement pass over
+// (x', t) work items -- no per-x' serial section).  A head (start, x') then streams the tiles of x': all
+// records of one tile hit the same ends {x} U NN(x), so each lane keeps its end's double-double sums in
+// REGISTERS across the tile and the start's row in HBM is touched once per (head, tile) instead of once per
+// path.  The edge products sim*mutu and the fractions are stored per edge, so a path's (sum sim*mutu, sum
+// mutu, prod frac) is rebuilt in the reference's left-to-right order, bit for bit.
+struct MidX { double sm2, sm3, sm4, f2, f3, f4, mu; int xid; int pad; };   // 64 B; xid = index of x in nb_list
+struct MidDir { int x; int ne; int cnt; int pad; long long off; };          // one tile of x': item x, 1+|NN(x)| ends, records [off, off+cnt)
+
+struct MidArgs {
+    int I, k;
+    const uint8_t *cls; const int *kcnt; const int *kcol; const double *kval; const uint8_t *flags;
+    const long long *att_ptr; const int *att_idx; const double *att_val;
+    const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
+    int n_nb; const int *nb_list; const int *nb_id;
+    int *tile_cnt;                 // [n_nb * n_nb] tally, then placement cursor
+    const long long *tile_off;     // [n_nb * n_nb + 1]
+    MidX *midX;
+};
+
+// one wave per (x', position q in NB_BB(x')): lanes over the joint (t,s), each walks attach(s)
+template <bool PLACE>
+__global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)A.n_nb * A.k) return;
+    const int xpid = (int)(w / A.k), q = (int)(w % A.k);
+    const int xp = A.nb_list[xpid];
+    if (q >= A.kcnt[(size_t)xp * 2]) return;
+    const size_t o = ((size_t)xp * 2) * A.k + q;
+    const int t = A.kcol[o];
+    if (!(A.flags[t] & 2)) return;
+    const int lane = lane_id();
+    const double v2 = A.kval[o * 3], m2 = A.kval[o * 3 + 1], f2 = A.kval[o * 3 + 2];              // edge (x', t)
+    for (long long p = A.src_ptr[t] + lane; p < A.src_ptr[t + 1]; p += 64) {
+        if (!(A.src_flag[p] & 1)) continue;
+        const int s = A.src_idx[p];
+        const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];  // edge (t, s)
+        for (long long ap = A.att_ptr[s]; ap < A.att_ptr[s + 1]; ap++) {
+            const int xid = A.nb_id[A.att_idx[ap]];
+            const size_t tile = (size_t)xpid * A.n_nb + xid;
+            if (!PLACE) {
+                atomicAdd(&A.tile_cnt[tile], 1);
+            } else {
+                const long long pos = A.tile_off[tile] + atomicAdd(&A.tile_cnt[tile], 1);
+                const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
+                MidX r;
+                r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
+                r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
+                A.midX[pos] = r;
+            }
+        }
+    }
+}
+
+// directory of the non-empty tiles of every x' (row of the dense table): count, then fill
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, const long long *tile_off,
+                                                 int *ng, const long long *dir_ptr, MidDir *dir, const int *nb_list,
+                                                 const int *kcnt) {
+    const int xpid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xpid >= n_nb) return;
+    const int lane = lane_id();
+    const size_t row = (size_t)xpid * n_nb;
+    long long out = FILL ? dir_ptr[xpid] : 0;
+    int total = 0;
+    for (int b = 0; b < n_nb; b += 64) {
+        const int xid = b + lane;
+        const int c = (xid < n_nb) ? tile_cnt[row + xid] : 0;
+        const unsigned long long m = __ballot(c > 0);
+        if (FILL && c > 0) {
+            MidDir d;
+            d.x = nb_list[xid]; d.ne = 1 + kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = 0; d.off = tile_off[row + xid];
+            dir[out + __popcll(m & lanemask_lt())] = d;
+        }
+        out += __popcll(m);
+        total += __popcll(m);
+    }
+    if (!FILL && lane == 0) ng[xpid] = total;
+}
+
+struct Path2Args {
+    PathArgs P;
+    const int *nb_id; const int *nb_list; int n_nb;
+    const MidX *midX; const MidDir *dir; const long long *dir_ptr; const int *ng;
+};
+
+// merge a lane's register sums into the start's row (distinct ends per call)
+__device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, double s_hi, double s_lo, double c_hi, double c_lo) {
+    bool first = false;
+    if (active) {
+        double *a = W.acc + (size_t)end * 4;
+        double h0 = a[0], l0 = a[1], h1 = a[2], l1 = a[3];
+        first = (h1 == 0.0);
+        dd_add(h0, l0, s_hi); dd_add(h0, l0, s_lo);
+        dd_add(h1, l1, c_hi); dd_add(h1, l1, c_lo);
+        a[0] = h0; a[1] = l0; a[2] = h1; a[3] = l1;
+    }
+    unsigned long long m = __ballot(first);
+    if (first) W.touched[W.nt + __popcll(m & lanemask_lt())] = end;
+    W.nt += __popcll(m);
+}
+
+// paths [start -] x' - t - s of one head (end s): lanes over the joint (t,s) of each t in NB_BB(x')
+__device__ __forceinline__ void head_S(const PathArgs &A, WaveAcc &W, int xp, bool has_e1, Carry e1) {
+    const int lane = lane_id();
+    const int nb = A.kcnt[(size_t)xp * 2];
+    for (int q = 0; q < nb; q++) {
+        const size_t o = ((size_t)xp * 2) * A.k + q;
+        const int t = A.kcol[o];
+        if (!(A.flags[t] & 2)) continue;
+        const Carry c2 = has_e1 ? add_edge(e1, A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2])
+                                : first_edge(A.kval[o * 3], A.kval[o * 3 + 1], A.kval[o * 3 + 2]);
+        const long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
+        for (long long base = s0; base < s1; base += 64) {
+            const long long p = base + lane;
+            const bool act = (p < s1) && (A.src_flag[p] & 1);
+            int s = 0;
+            Carry c = c2;
+            if (act) {
+                s = A.src_idx[p];
+                c = add_edge(c2, A.src_val[p * 3], A.src_val[p * 3 + 1], A.src_val[p * 3 + 2]);
+            }
+            W.add(act, s, c);
+        }
+    }
+}
+
+// Tile-major reduction over the heads of one start.  Up to 64 heads (one per lane) are merged by item x: every
+// head's tile directory is sorted by x, so the smallest current x over the lanes is the next tile column; all heads
+// that own a tile (x', x) for it are reduced into the SAME register sums before the start's row is touched -- one
+// row access per (start, x) instead of one per (head, x) (2.1x fewer at BASELINE configs[1], 25x for the starts
+// with many heads).  [xlo, xhi) restricts the columns (work splitting of heavy starts).
+//
+// A column step is a chain of dependent memory round trips with little arithmetic in between (3.8 records per (start, x)
+// on average), and a start with 10^5..10^6 paths spends its time waiting on them (93 ns per path against 16 for the
+// starts with many heads, per-unit trace).  Three measures shorten the chain:
+//  * the records of ALL participating heads are laid end to end over the lanes (lane g takes the g-th record of the
+//    column; head and position from an exclusive prefix sum of the tile sizes), so one gather fetches them instead of
+//    one gather per head, in the same (head, record) order as before;
+//  * every head keeps the directory entry AFTER its current one in registers: advancing costs no round trip;
+//  * the start's row entries are requested as soon as the ends are known, before the records are reduced.
+__device__ __forceinline__ void heads_X(const Path2Args &B, WaveAcc &W, int start, long long h0, long long nH, int self,
+                                        int xlo, int xhi) {
+    const PathArgs &A = B.P;
+    const int lane = lane_id();
+    const int k = A.k;
+    const int INF = 0x7fffffff;
+    // this lane's head
+    const long long h = h0 + lane;
+    const bool hv = h < nH;
+    double sm1 = 0.0, mu1 = 0.0, f1 = 1.0;
+    int has_e1 = 0;
+    long long dpos = 0, dend = 0;
+    if (hv) {
+        int xp = start;
+        if (h >= self) {
+            const long long rp = A.rnn_ptr[start] + (h - self);
+            xp = A.rnn_idx[rp];
+            const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1];
+            sm1 = sv * mu; mu1 = mu; f1 = A.rnn_val[rp * 3 + 2];
+            has_e1 = 1;
+        }
+        const int xpid = B.nb_id[xp];
+        dpos = B.dir_ptr[xpid];
+        dend = B.dir_ptr[xpid + 1];
+        if (xlo > 0) {   // lower bound of xlo in this head's directory (sorted by x)
+            long long lo = dpos, hi = dend;
+            while (lo < hi) {
+                long long mid = (lo + hi) >> 1;
+                if (B.dir[mid].x < xlo) lo = mid + 1; else hi = mid;
+            }
+            dpos = lo;
+        }
+    }
+    int cx = INF, ccnt = 0, cne = 0;     // current entry
+    long long coff = 0;
+    int nx = INF, ncnt = 0, nne = 0;     // the entry after it
+    long long noff = 0;
+    if (hv && dpos < dend) { const MidDir d = B.dir[dpos]; cx = d.x >= xhi ? INF : d.x; ccnt = d.cnt; cne = d.ne; coff = d.off; }
+    if (hv && dpos + 1 < dend) { const MidDir d = B.dir[dpos + 1]; nx = d.x >= xhi ? INF : d.x; ncnt = d.cnt; nne = d.ne; noff = d.off; }
+    for (;;) {
+        int xmin = cx;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(xmin, m, 64); xmin = o < xmin ? o : xmin; }
+        if (xmin == INF) break;
+        const bool mine = cx == xmin;
+        const unsigned long long part = __ballot(mine);
+        const int x = xmin;
+        const int ne = rl32(cne, __ffsll((long long)part) - 1);
+        // the column's records laid end to end: head l owns [pre_l, pre_l + cnt_l)
+        const int tcnt = mine ? ccnt : 0;
+        const long long toff = coff;
+        int incl = tcnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int pre = incl - tcnt;
+        const int R = rl32(incl, 63);
+        // advance the heads that take part; their next entry is already here, the one after it is requested now
+        if (mine) {
+            dpos++;
+            cx = nx; ccnt = ncnt; cne = nne; coff = noff;
+            nx = INF;
+            if (dpos + 1 < dend) { const MidDir d = B.dir[dpos + 1]; nx = d.x >= xhi ? INF : d.x; ncnt = d.cnt; nne = d.ne; noff = d.off; }
+        }
+        for (int b = 0; b < ne; b += 64) {
+            const int idx = b + lane;
+            const bool act = idx < ne;
+            int end = x;
+            double sm5 = 0.0, mu5 = 0.0, f5 = 1.0;
+            const bool has5 = act && idx > 0;
+            if (has5) {
+                size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
+                end = A.kcol[o];
+                const double v = A.kval[o * 3], m = A.kval[o * 3 + 1];
+                sm5 = v * m; mu5 = m; f5 = A.kval[o * 3 + 2];
+            }
+            double s_hi = 0.0, s_lo = 0.0, c_hi = 0.0, c_lo = 0.0;
+            // 64 records of the column: gather, then the part of a path's value that does not depend on the end, once per
+            // record on the record's lane (same operations in the same order as the per-path statement)
+            double bsm = 0.0, bc = 0.0, bmu = 0.0;
+            auto fetch = [&](int cb, MidX &m, int &hl) {
+                const int g = cb + lane;
+                hl = -1;
+                long long o = 0;
+                unsigned long long pm = part;
+                while (pm) {
+                    const int l = __ffsll((long long)pm) - 1;
+                    pm &= pm - 1;
+                    const int p = rl32(pre, l), c = rl32(tcnt, l);
+                    if (g >= p && g < p + c) { hl = l; o = rl64(toff, l) + (g - p); }
+                }
+                m.sm2 = m.sm3 = m.sm4 = m.f2 = m.f3 = m.f4 = m.mu = 0.0;
+                if (hl >= 0) m = B.midX[o];
+            };
+            auto reduce = [&](int cb, const MidX &m, int hl) {
+                const int src = hl < 0 ? lane : hl;
+                const bool he1 = __shfl(has_e1, src, 64) != 0;
+                const double hsm1 = __shfl(sm1, src, 64), hmu1 = __shfl(mu1, src, 64), hf1 = __shfl(f1, src, 64);
+                if (he1) { bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4; bc = ((hf1 * m.f2) * m.f3) * m.f4; }
+                else { bsm = (m.sm2 + m.sm3) + m.sm4; bc = (m.f2 * m.f3) * m.f4; }
+                bmu = m.mu + (he1 ? hmu1 : 0.0);
+                const int nr = (R - cb) < 64 ? (R - cb) : 64;
+                for (int r = 0; r < nr; r++) {
+                    double sm = rld(bsm, r), c = rld(bc, r), mu = rld(bmu, r);
+                    if (has5) { sm = sm + sm5; c = c * f5; mu = mu + mu5; }
+                    const double sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;
+                    dd_add(s_hi, s_lo, sp * c);
+                    dd_add(c_hi, c_lo, c);
+                }
+            };
+            MidX m0;
+            int hl0;
+            fetch(0, m0, hl0);
+            // the row entries are requested before the records are reduced
+            double *a = W.acc + (size_t)end * 4;
+            double h0_ = 0.0, l0_ = 0.0, h1_ = 0.0, l1_ = 0.0;
+            if (act) { h0_ = a[0]; l0_ = a[1]; h1_ = a[2]; l1_ = a[3]; }
+            reduce(0, m0, hl0);
+            for (int cb = 64; cb < R; cb += 64) {
+                MidX m;
+                int hl;
+                fetch(cb, m, hl);
+                reduce(cb, m, hl);
+            }
+            bool first = false;
+            if (act) {
+                first = (h1_ == 0.0);
+                dd_add(h0_, l0_, s_hi); dd_add(h0_, l0_, s_lo);
+                dd_add(h1_, l1_, c_hi); dd_add(h1_, l1_, c_lo);
+                a[0] = h0_; a[1] = l0_; a[2] = h1_; a[3] = l1_;
+            }
+            const unsigned long long fm = __ballot(first);
+            if (first) W.touched[W.nt + __popcll(fm & lanemask_lt())] = end;
+            W.nt += __popcll(fm);
+            W.paths += (unsigned long long)R * (unsigned long long)__popcll(__ballot(act));
+        }
+    }
+}
+
+// 5 waves per SIMD (94 VGPRs, 68 B of scratch per lane) measured 6 % faster than the 4 the unconstrained allocation
+// (112 VGPRs) allows, 6 (80 VGPRs, 128 B of scratch) 8 % slower: the kernel is bound by its random row updates, more
+// waves keep more of them in flight
+#ifdef B_TRACE
+__device__ unsigned long long g_btrace[1 << 20][2];   // per unit: begin, end (wall_clock64, 100 MHz)
+#endif
+#ifndef B_WAVES
+#define B_WAVES 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_WAVES))) void k_paths2(Path2Args B) {
+    __shared__ FinBuf fin[4];
+    const PathArgs &A = B.P;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.n_slots) return;
+    const int lane = lane_id();
+    WaveAcc W;
+    W.paths = 0;
+    unsigned long long cand_total = 0;
+    for (;;) {
+        int u_ = 0;
+        if (lane == 0) u_ = (int)atomicAdd(&A.counters[2], 1ull);
+        const int unit = uniform(u_);
+        if (unit >= A.n_units) break;  // every wave reaches this exit: the cursor only grows
+        const int start = uniform(A.unit_start[unit]);
+        const int c = uniform(A.unit_c[unit]);
+        const int G = uniform(A.unit_G[unit]);
+        const int row = uniform(A.unit_row[unit]);
+#ifdef B_TRACE
+        const unsigned long long tr0 = wall_clock64();
+#endif
+        if (row < 0) {
+            W.acc = A.acc + (size_t)slot * A.I * 4;
+            W.touched = A.touched + (size_t)slot * A.I;
+        } else {
+            W.acc = A.hacc + (size_t)row * A.I * 4;
+            W.touched = A.htouched + (size_t)row * A.I;
+        }
+        W.nt = 0;
+        int ent = 0;  // work entries of a start: role T; per head its (t,s) part; per (64-head batch, column range) the tiles
+        if (A.flags[start] & 2) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
+            if (G == 1 || ent % G == c) {
+                Carry none; none.sm = 0; none.mu = 0; none.c = 0;
+                through_t(A, W, start, false, none);
+            }
+            ent++;
+        }
+        const long long r0 = uniform((int)A.rnn_ptr[start]), r1 = uniform((int)A.rnn_ptr[start + 1]);
+        const int self = (A.cls[start] == 2) ? 1 : 0;   // head 0 = the start itself (target_path, extender.py:160-163)
+        const long long nH = self + (r1 - r0);          // heads >= self: start in NN(x') (longest_path, :164-167)
+        for (long long h = 0; h < nH; h++) {
+            if (G == 1 || ent % G == c) {
+                const bool has_e1 = h >= self;
+                const int xp = has_e1 ? A.rnn_idx[r0 + h - self] : start;
+                Carry e1; e1.sm = 0; e1.mu = 0; e1.c = 1.0;
+                if (has_e1) e1 = first_edge(A.rnn_val[(r0 + h - self) * 3], A.rnn_val[(r0 + h - self) * 3 + 1],
+                                            A.rnn_val[(r0 + h - self) * 3 + 2]);
+                head_S(A, W, xp, has_e1, e1);
+            }
+            ent++;
+        }
+        const long long nbatch = (nH + 63) / 64;
+        const int RX = (nbatch > 0) ? (int)((G + nbatch - 1) / nbatch) : 1;   // column ranges: nbatch * RX >= G entries
+        const int n_nb = B.n_nb;
+        for (long long bt = 0; bt < nbatch; bt++)
+            for (int rx = 0; rx < RX; rx++) {
+                if (G == 1 || ent % G == c) {
+                    const int xlo = (rx == 0) ? 0 : B.nb_list[(long long)rx * n_nb / RX];
+                    const int xhi = (rx == RX - 1) ? 0x7fffffff : B.nb_list[(long long)(rx + 1) * n_nb / RX];
+                    heads_X(B, W, start, bt * 64, nH, self, xlo, xhi);
+                }
+                ent++;
+            }
+        if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
+        else if (lane == 0) A.unit_nt[unit] = W.nt;
+#ifdef B_TRACE
+        if (lane == 0 && unit < (1 << 20)) { g_btrace[unit][0] = tr0; g_btrace[unit][1] = wall_clock64(); }
+#endif
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], cand_total);
+        atomicAdd(&A.counters[1], W.paths);
+    }
+}
+
+// heavy starts: add the G partial rows into the first one (double-double merge), then finalise
+__global__ __launch_bounds__(256) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
+    __shared__ FinBuf fin[4];
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n_heavy) return;
+    const int lane = lane_id();
+    const int u0 = heavy_unit0[h];
+    const int start = A.unit_start[u0], G = A.unit_G[u0], r0 = A.unit_row[u0];
+    double *acc0 = A.hacc + (size_t)r0 * A.I * 4;
+    int *touched0 = A.htouched + (size_t)r0 * A.I;
+    int nt = A.unit_nt[u0];
+    for (int c = 1; c < G; c++) {
+        double *accc = A.hacc + (size_t)(r0 + c) * A.I * 4;
+        const int *tc = A.htouched + (size_t)(r0 + c) * A.I;
+        const int ntc = A.unit_nt[u0 + c];
+        for (int b0 = 0; b0 < ntc; b0 += 64) {
+            const int b = b0 + lane;
+            bool first = false;
+            int e = 0;
+            if (b < ntc) {
+                e = tc[b];
+                double *s = accc + (size_t)e * 4, *d = acc0 + (size_t)e * 4;
+                double s_hi = d[0], s_lo = d[1], c_hi = d[2], c_lo = d[3];
+                first = (c_hi == 0.0);
+                dd_add(s_hi, s_lo, s[0]); dd_add(s_hi, s_lo, s[1]);
+                dd_add(c_hi, c_lo, s[2]); dd_add(c_hi, c_lo, s[3]);
+                d[0] = s_hi; d[1] = s_lo; d[2] = c_hi; d[3] = c_lo;
+                s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+            }
+            unsigned long long m = __ballot(first);
+            if (first) touched0[nt + __popcll(m & lanemask_lt())] = e;
+            nt += __popcll(m);
+        }
+    }
+    int n = finalize_start(A, fin[threadIdx.x >> 6], acc0, touched0, nt, start);
+    if (lane == 0) atomicAdd(&A.counters[0], (unsigned long long)n);
+}
+
+// ---- per-start path counts (scheduling weights): T(s) tails of s, sums over src(t), heads of x' -------------
+__global__ __launch_bounds__(256) void k_w_tails(int I, const long long *att_ptr, const int *att_idx, const int *kcnt,
+                                                 long long *T) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= I) return;
+    long long a0 = att_ptr[s], a1 = att_ptr[s + 1], t = 0;
+    for (long long ap = a0; ap < a1; ap++) t += 1 + kcnt[(size_t)att_idx[ap] * 2 + 1];
+    T[s] = (a1 > a0) ? t + 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_w_src(int I, const long long *src_ptr, const int *src_idx, const uint8_t *src_flag,
+                                               const long long *T, long long *ST_all, long long *ST_j) {
+    int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= I) return;
+    int lane = lane_id();
+    long long a = 0, j = 0;
+    for (long long p = src_ptr[t] + lane; p < src_ptr[t + 1]; p += 64) {
+        long long v = T[src_idx[p]];
+        a += v;
+        if (src_flag[p] & 1) j += v;
+    }
+    a = wave_sum_ll(a);
+    j = wave_sum_ll(j);
+    if (lane == 0) { ST_all[t] = a; ST_j[t] = j; }
+}
+__global__ __launch_bounds__(256) void k_w_heads(int I, int k, const uint8_t *cls, const int *kcnt, const int *kcol,
+                                                 const uint8_t *flags, const long long *ST_j, long long *HX) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= I) return;
+    long long h = 0;
+    if (cls[x] == 2) {
+        int nb = kcnt[(size_t)x * 2];
+        for (int q = 0; q < nb; q++) {
+            int t = kcol[((size_t)x * 2) * k + q];
+            if (flags[t] & 2) h += ST_j[t];
+        }
+    }
+    HX[x] = h;
+}
+__global__ __launch_bounds__(256) void k_w_starts(int I, const uint8_t *flags, const long long *rnn_ptr, const int *rnn_idx,
+                                                  const long long *ST_all, const long long *HX, long long *P) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= I) return;
+    long long p = ((flags[s] & 2) ? ST_all[s] : 0) + HX[s];
+    for (long long rp = rnn_ptr[s]; rp < rnn_ptr[s + 1]; rp++) p += HX[rnn_idx[rp]];
+    P[s] = p;
+}
+
+}  // namespace xmap
+
+using namespace xmap;
+
+extern "C" {
+#ifdef B_TRACE
+int xmap_debug_btrace(unsigned long long *host, long long n_units) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_btrace), (size_t)n_units * 16);
+}
+#endif
+
+int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls, uint8_t *bb) {
+    XM_ARG(S && prefix_cls && bb);
+    if (S->n_items == 0) return XMAP_OK;
+    k_bridge_flags<<<dim3((unsigned)((S->n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        S->n_items, (const long long *)S->row_ptr, S->col, prefix_cls, bb);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const int32_t *suffix_cls,
+                      const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt, int32_t *kcol, double *kval) {
+    XM_ARG(S && bb && suffix_cls && contains_mask && cls && kcnt && kcol && kval);
+    XM_ARG(top_k >= 1 && 2 * top_k <= K_CH / 2);
+    if (S->n_items == 0) return XMAP_OK;
+    KnnArgs A;
+    A.I = S->n_items; A.k = top_k;
+    A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
+    A.info = S->info; A.frac = S->frac; A.bb = bb; A.suffix_cls = suffix_cls; A.contains_mask = contains_mask;
+    A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
+    k_knn_classify<<<dim3((unsigned)S->n_items), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, int top_k, const uint8_t *bb,
+                          const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
+                          const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
+                          const int64_t *attach_ptr, int32_t *rcnt, const int64_t *rptr, int32_t *ridx, double *rval,
+                          uint8_t *rflag) {
+    XM_ARG(S && bb && cls && kcnt && kcol && kval && suffix_cls && contains_mask && flags);
+    XM_ARG(mode >= 0 && mode <= 2);
+    XM_ARG(mode != 1 || attach_ptr);
+    if (S->n_items == 0) return XMAP_OK;
+    RevArgs A;
+    A.I = S->n_items; A.k = top_k; A.mode = mode;
+    A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
+    A.info = S->info; A.frac = S->frac; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
+    A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
+    A.attach_ptr = (const long long *)attach_ptr;
+    A.rcnt = rcnt; A.rptr = (const long long *)rptr; A.ridx = ridx; A.rval = rval; A.rflag = rflag;
+    dim3 grid((unsigned)((S->n_items + 3) / 4)), block(256);
+    if (fill) k_reverse<true><<<grid, block, 0, (hipStream_t)stream>>>(A);
+    else k_reverse<false><<<grid, block, 0, (hipStream_t)stream>>>(A);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
+                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, int32_t *rcnt) {
+    XM_ARG(rcnt);
+    return reverse_common(stream, false, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
+                          attach_ptr, rcnt, nullptr, nullptr, nullptr, nullptr);
+}
+
+int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
+                      const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                      const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
+                      const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag) {
+    XM_ARG(rptr && ridx && rval);
+    return reverse_common(stream, true, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
+                          attach_ptr, nullptr, rptr, ridx, rval, rflag);
+}
+
+int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end, const double *xs_val,
+                         int32_t *n_cand, int32_t *top_end, double *top_val) {
+    XM_ARG(xs_ptr && xs_end && xs_val && n_cand && top_end && top_val);
+    if (n_items == 0) return XMAP_OK;
+    k_topc_lists<<<dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        n_items, (const long long *)xs_ptr, xs_end, xs_val, n_cand, top_end, top_val);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_path_weights(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                      const int64_t *src_ptr, const int32_t *src_idx, const uint8_t *src_flag, const int64_t *rnn_ptr,
+                      const int32_t *rnn_idx, int64_t *tmp /*[4][I]*/, int64_t *paths /*[I]*/) {
+    XM_ARG(cls && kcnt && kcol && flags && att_ptr && src_ptr && rnn_ptr && tmp && paths);
+    if (n_items == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    long long *T = (long long *)tmp, *STa = T + n_items, *STj = STa + n_items, *HX = STj + n_items;
+    unsigned g1 = (unsigned)((n_items + 255) / 256), g4 = (unsigned)((n_items + 3) / 4);
+    k_w_tails<<<dim3(g1), dim3(256), 0, st>>>(n_items, (const long long *)att_ptr, att_idx, kcnt, T);
+    XM_LAUNCH_CHECK();
+    k_w_src<<<dim3(g4), dim3(256), 0, st>>>(n_items, (const long long *)src_ptr, src_idx, src_flag, T, STa, STj);
+    XM_LAUNCH_CHECK();
+    k_w_heads<<<dim3(g1), dim3(256), 0, st>>>(n_items, top_k, cls, kcnt, kcol, flags, STj, HX);
+    XM_LAUNCH_CHECK();
+    k_w_starts<<<dim3(g1), dim3(256), 0, st>>>(n_items, flags, (const long long *)rnn_ptr, rnn_idx, STa, HX,
+                                                (long long *)paths);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && rnn_ptr);
+    XM_ARG(acc && touched && n_cand && top_end && top_val && d_counters);
+    XM_ARG(n_slots > 0 && n_units >= 0 && n_heavy >= 0);
+    XM_ARG(n_units == 0 || (unit_start && unit_c && unit_G && unit_row && unit_nt));
+    XM_ARG(n_heavy == 0 || (heavy_unit0 && hacc && htouched));
+    XM_ARG(xs_cap == 0 || (xs_off && xs_end && xs_val));
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+    if (n_units > 0) {
+        PathArgs A;
+        A.I = n_items; A.k = top_k;
+        A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval; A.flags = flags;
+        A.att_ptr = (const long long *)att_ptr; A.att_idx = att_idx; A.att_val = att_val;
+        A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
+        A.rnn_ptr = (const long long *)rnn_ptr; A.rnn_idx = rnn_idx; A.rnn_val = rnn_val;
+        A.n_units = n_units; A.unit_start = unit_start; A.unit_c = unit_c; A.unit_G = unit_G; A.unit_row = unit_row;
+        A.unit_nt = unit_nt;
+        A.n_slots = n_slots; A.acc = acc; A.touched = touched; A.hacc = hacc; A.htouched = htouched;
+        A.n_cand = n_cand; A.top_end = top_end; A.top_val = top_val;
+        A.xs_cap = xs_cap; A.xs_off = (long long *)xs_off; A.xs_end = xs_end; A.xs_val = xs_val;
+        A.counters = (unsigned long long *)d_counters;
+        int slots = n_slots < n_units ? n_slots : n_units;
+        A.n_slots = slots;
+        if (mid) {
+            Path2Args B = *mid;
+            B.P = A;
+            k_paths2<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(B);
+        } else {
+            k_paths<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(A);
+        }
+        XM_LAUNCH_CHECK();
+        if (n_heavy > 0) {
+            k_merge<<<dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, st>>>(A, n_heavy, heavy_unit0);
+            XM_LAUNCH_CHECK();
+        }
+    }
+    if (h_counters) {
+        XM_HIP(hipMemcpyAsync(h_counters, d_counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        XM_HIP(hipStreamSynchronize(st));
+        if (xs_cap > 0 && h_counters[0] > xs_cap) {
+            set_error("candidate buffer too small: need %lld entries, have %lld", (long long)h_counters[0],
+                      (long long)xs_cap);
+            return XMAP_ERR_CAPACITY;
+        }
+    }
+    return XMAP_OK;
+}
+
+int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters) {
+    return extend_paths_impl(nullptr, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
+}
+
+int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
+                      const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
+                      const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
+                      const double *src_val, const uint8_t *src_flag, const int64_t *rnn_ptr, const int32_t *rnn_idx,
+                      const double *rnn_val, int32_t n_units, const int32_t *unit_start, const int32_t *unit_c,
+                      const int32_t *unit_G, const int32_t *unit_row, int32_t *unit_nt, int32_t n_heavy,
+                      const int32_t *heavy_unit0, int32_t n_slots, double *acc, int32_t *touched, double *hacc,
+                      int32_t *htouched, int32_t *n_cand, int32_t *top_end, double *top_val, int64_t xs_cap,
+                      int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
+                       const int32_t *nb_id, const int32_t *nb_list, int32_t n_nb, const void *midX, const void *dir,
+                       const int64_t *dir_ptr, const int32_t *ng) {
+    XM_ARG(nb_id && nb_list && midX && dir && dir_ptr && ng && n_nb > 0);
+    Path2Args B;
+    memset(&B, 0, sizeof(B));
+    B.nb_id = nb_id; B.nb_list = nb_list; B.n_nb = n_nb; B.midX = (const MidX *)midX; B.dir = (const MidDir *)dir;
+    B.dir_ptr = (const long long *)dir_ptr; B.ng = ng;
+    return extend_paths_impl(&B, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
+}
+
+static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                        const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                        const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                        const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id) {
+    MidArgs A;
+    memset(&A, 0, sizeof(A));
+    A.I = n_items; A.k = top_k; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval; A.flags = flags;
+    A.att_ptr = (const long long *)att_ptr; A.att_idx = att_idx; A.att_val = att_val;
+    A.src_ptr = (const long long *)src_ptr; A.src_idx = src_idx; A.src_val = src_val; A.src_flag = src_flag;
+    A.n_nb = n_nb; A.nb_list = nb_list; A.nb_id = nb_id;
+    return A;
+}
+
+int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                   const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                   const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                   int32_t *tile_cnt /*[n_nb*n_nb], zeroed here*/, int32_t *ng /*[n_nb]*/) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id && tile_cnt && ng);
+    if (n_nb == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
+                         src_flag, n_nb, nb_list, nb_id);
+    A.tile_cnt = tile_cnt;
+    XM_HIP(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * (size_t)n_nb * (size_t)n_nb, st));
+    const long long waves = (long long)n_nb * top_k;
+    k_mid_build<false><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
+    XM_LAUNCH_CHECK();
+    k_mid_dir<false><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, nullptr, ng, nullptr, nullptr,
+                                                                             nullptr, nullptr);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
+                   const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
+                   const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
+                   const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
+                   int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
+                   void *dir /*24 B per tile*/, void *midX /*64 B per record*/) {
+    XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id);
+    XM_ARG(tile_cnt && tile_off && dir_ptr && dir && midX);
+    if (n_nb == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
+                         src_flag, n_nb, nb_list, nb_id);
+    A.tile_cnt = tile_cnt; A.tile_off = (const long long *)tile_off; A.midX = (MidX *)midX;
+    k_mid_dir<true><<<dim3((unsigned)((n_nb + 3) / 4)), dim3(256), 0, st>>>(n_nb, tile_cnt, (const long long *)tile_off,
+                                                                            nullptr, (const long long *)dir_ptr, (MidDir *)dir, nb_list, kcnt);
+    XM_LAUNCH_CHECK();
+    XM_HIP(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * (size_t)n_nb * (size_t)n_nb, st));   // now the placement cursors
+    const long long waves = (long long)n_nb * top_k;
+    k_mid_build<true><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+}
