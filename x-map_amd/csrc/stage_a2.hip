@@ -500,32 +500,34 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
 #ifdef A_TRACE
             if (base == p0 + 64 * w && __shfl(e0, 0, 64) >= 0) A_STAMP(1);
 #endif
-            // software pipeline: the first GRP entries of the NEXT step's prefixes are loaded before this step is processed
-            int nb0 = 0, nb1 = 0, npw = 0, njw = 0;
-            float nrj = 0.f;
-            {
-                const int t = g;
+            // software pipeline: the first 2 GRP entries of the NEXT step's prefixes are loaded before this step is
+            // processed (a step waits for the longest of its 8 prefixes; every load inside the loop below is one more
+            // dependent round trip while the unit holds its table: 16 entries cover nearly all prefixes)
+            int nb0 = 0, nb1 = 0, npw = 0, njw = 0, njw2 = 0;
+            float nrj = 0.f, nrj2 = 0.f;
+            auto prefetch = [&](int t) {
                 nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
                 nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
                 if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
-            }
+                if (nb0 + GRP + sub < nb1) { const int2 v = A.ub[nb0 + GRP + sub]; njw2 = v.x; nrj2 = __int_as_float(v.y); }
+            };
+            prefetch(g);
             for (int t0 = 0; t0 < nr; t0 += NGRP) {
                 const int t = t0 + g;                    // this lane group's rater
                 const int b0 = nb0, b1 = nb1, pwt = npw;
                 int jw = njw;
                 float rj = nrj;
-                if (t0 + NGRP < nr) {
-                    const int tn = t + NGRP;
-                    nb0 = __shfl(e0, tn, 64); npw = __shfl(pw, tn, 64);
-                    nb1 = (tn < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
-                    if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
-                }
+                const int jw2 = njw2;
+                const float rj2 = nrj2;
+                if (t0 + NGRP < nr) prefetch(t + NGRP);
                 const double ri = (double)__shfl(r, t, 64);
                 const double a = ADJ ? __shfl(au, t, 64) : 0.0;
                 const unsigned gei = ((unsigned)pwt) >> 31;
-                for (int e = b0 + sub; __ballot(e < b1); e += GRP) {
+                int it = 0;
+                for (int e = b0 + sub; __ballot(e < b1); e += GRP, it++) {
                     bool act = e < b1;
-                    if (act && e >= b0 + GRP) { const int2 v = A.ub[e]; jw = v.x; rj = __int_as_float(v.y); }
+                    if (it == 1) { jw = jw2; rj = rj2; }
+                    else if (act && it >= 2) { const int2 v = A.ub[e]; jw = v.x; rj = __int_as_float(v.y); }
                     const int j = jw & 0x7fffffff;
                     if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
                     body(act, j, jw, rj, ri, a, gei);
