@@ -1049,10 +1049,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
 }
 
 // heavy starts: add the G partial rows into the first one (double-double merge), then finalise.  One block of
-// MERGE_WAVES waves per start: the touched entries of a partial row are distinct, so the waves take 64 of them at a
+// MERGE_WAVES waves per job: the touched entries of a partial row are distinct, so the waves take 64 of them at a
 // time side by side (a single wave per start had left a chain of G - 1 serial merges: 68 ms at BASELINE configs[1]);
 // the finalisation pass is shared the same way, every wave keeping the best of its share, wave 0 the best of those.
+// Two levels for the starts with more than MERGE_GROUP rows (the heaviest has 133): level 1 folds every group of
+// MERGE_GROUP consecutive rows into the group's first row (one block per group), level 2 the group heads into row 0.
 constexpr int MERGE_WAVES = 16;
+constexpr int MERGE_GROUP = 12;
+
+// rows of one start: add row (acc_s, touched_s[0..nt_s)) into (acc_d, touched_d, *s_nt); all waves of the block
+__device__ __forceinline__ void merge_row(double *acc_d, int *touched_d, int *s_nt, double *acc_s, const int *touched_s, int nt_s) {
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int b0 = 64 * w; b0 < nt_s; b0 += 64 * MERGE_WAVES) {
+        const int b = b0 + lane;
+        bool first = false;
+        int e = 0;
+        if (b < nt_s) {
+            e = touched_s[b];
+            double *s = acc_s + (size_t)e * 4, *d = acc_d + (size_t)e * 4;
+            double s_hi = d[0], s_lo = d[1], c_hi = d[2], c_lo = d[3];
+            first = (c_hi == 0.0);
+            dd_add(s_hi, s_lo, s[0]); dd_add(s_hi, s_lo, s[1]);
+            dd_add(c_hi, c_lo, s[2]); dd_add(c_hi, c_lo, s[3]);
+            d[0] = s_hi; d[1] = s_lo; d[2] = c_hi; d[3] = c_lo;
+            s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+        }
+        const unsigned long long m = __ballot(first);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(s_nt, __popcll(m));
+        base = rl32(base, 0);
+        if (first) touched_d[base + __popcll(m & lanemask_lt())] = e;
+    }
+    __syncthreads();      // the destination row and its touched list are complete before the next row (entries repeat)
+}
+
+__global__ __launch_bounds__(64 * MERGE_WAVES) void k_merge_groups(PathArgs A, int n_heavy, const int *heavy_unit0) {
+    __shared__ int s_nt;
+    const int h = blockIdx.x;
+    if (h >= n_heavy) return;
+    const int u0 = heavy_unit0[h];
+    const int G = A.unit_G[u0], r0 = A.unit_row[u0];
+    if (G <= MERGE_GROUP) return;
+    for (int g = blockIdx.y; g * MERGE_GROUP < G; g += gridDim.y) {
+        const int b = g * MERGE_GROUP;
+        const int e = (b + MERGE_GROUP) < G ? (b + MERGE_GROUP) : G;
+        if (threadIdx.x == 0) s_nt = A.unit_nt[u0 + b];
+        __syncthreads();
+        for (int c = b + 1; c < e; c++)
+            merge_row(A.hacc + (size_t)(r0 + b) * A.I * 4, A.htouched + (size_t)(r0 + b) * A.I, &s_nt,
+                      A.hacc + (size_t)(r0 + c) * A.I * 4, A.htouched + (size_t)(r0 + c) * A.I, A.unit_nt[u0 + c]);
+        if (threadIdx.x == 0) A.unit_nt[u0 + b] = s_nt;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(64 * MERGE_WAVES) void k_merge(PathArgs A, int n_heavy, const int *heavy_unit0) {
     __shared__ FinBuf fin[MERGE_WAVES];
     __shared__ int s_nt, s_ns[MERGE_WAVES], s_full;
@@ -1066,32 +1116,10 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void k_merge(PathArgs A, int n_he
     int *touched0 = A.htouched + (size_t)r0 * A.I;
     if (threadIdx.x == 0) s_nt = A.unit_nt[u0];
     __syncthreads();
-    for (int c = 1; c < G; c++) {
-        double *accc = A.hacc + (size_t)(r0 + c) * A.I * 4;
-        const int *tc = A.htouched + (size_t)(r0 + c) * A.I;
-        const int ntc = A.unit_nt[u0 + c];
-        for (int b0 = 64 * w; b0 < ntc; b0 += 64 * MERGE_WAVES) {
-            const int b = b0 + lane;
-            bool first = false;
-            int e = 0;
-            if (b < ntc) {
-                e = tc[b];
-                double *s = accc + (size_t)e * 4, *d = acc0 + (size_t)e * 4;
-                double s_hi = d[0], s_lo = d[1], c_hi = d[2], c_lo = d[3];
-                first = (c_hi == 0.0);
-                dd_add(s_hi, s_lo, s[0]); dd_add(s_hi, s_lo, s[1]);
-                dd_add(c_hi, c_lo, s[2]); dd_add(c_hi, c_lo, s[3]);
-                d[0] = s_hi; d[1] = s_lo; d[2] = c_hi; d[3] = c_lo;
-                s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
-            }
-            const unsigned long long m = __ballot(first);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(&s_nt, __popcll(m));
-            base = rl32(base, 0);
-            if (first) touched0[base + __popcll(m & lanemask_lt())] = e;
-        }
-        __syncthreads();      // row 0 and its touched list are complete before the next partial row (entries may repeat)
-    }
+    const int stride = G > MERGE_GROUP ? MERGE_GROUP : 1;     // group heads (k_merge_groups ran) or all rows
+    for (int c = stride; c < G; c += stride)
+        merge_row(acc0, touched0, &s_nt, A.hacc + (size_t)(r0 + c) * A.I * 4, A.htouched + (size_t)(r0 + c) * A.I,
+                  A.unit_nt[u0 + c]);
     const int nt = s_nt;
     if (w == 0) {
         if (lane == 0) A.n_cand[start] = nt;
@@ -1314,6 +1342,8 @@ static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items
         }
         XM_LAUNCH_CHECK();
         if (n_heavy > 0) {
+            k_merge_groups<<<dim3((unsigned)n_heavy, 16), dim3(64 * MERGE_WAVES), 0, st>>>(A, n_heavy, heavy_unit0);
+            XM_LAUNCH_CHECK();
             k_merge<<<dim3((unsigned)n_heavy), dim3(64 * MERGE_WAVES), 0, st>>>(A, n_heavy, heavy_unit0);
             XM_LAUNCH_CHECK();
         }

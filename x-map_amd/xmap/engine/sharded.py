@@ -104,7 +104,11 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             if L.n_light:
                 n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
                 c = torch.cumsum(n_i[L.uq_item[:L.n_light].long()].double(), 0)
-                tgt = c[-1] * torch.arange(1, world, dtype=torch.float64, device=dev) / world
+                # rank 0 also computes the heavy rows (their chunk partials are merged per row, so they stay together):
+                # their rater visits count against its share of the light units
+                w_heavy = n_i[L.hlist[:L.n_heavy].long()].sum().double() if L.n_heavy else torch.zeros((), dtype=torch.float64, device=dev)
+                first = torch.minimum(((c[-1] + w_heavy) / world - w_heavy).clamp(min=0.0), c[-1])
+                tgt = first + (c[-1] - first) / max(world - 1, 1) * torch.arange(0, world - 1, dtype=torch.float64, device=dev)
                 cuts = [0] + torch.searchsorted(c, tgt).clamp(max=L.n_light).tolist() + [L.n_light]
                 cuts = np.maximum.accumulate(np.asarray(cuts, np.int64))
                 lo, hi = int(cuts[rank]), int(cuts[rank + 1])
