@@ -311,3 +311,28 @@ def test_determinism_and_partitions(dev):
     assert np.array_equal(E1.top_end.cpu().numpy(), E2.top_end.cpu().numpy())
     assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
     assert np.array_equal(E1.n_cand.cpu().numpy(), E2.n_cand.cpu().numpy())
+
+
+def test_heavy_starts_with_long_candidate_lists(dev):
+    """Starts split over dedicated rows whose candidate lists are long enough for every wave of the merge block to cut
+    its running selection back several times (k_merge_groups + k_merge + finalize_slice with 16 waves) against the
+    one-wave-per-start form (finalize_start), which test_c1_vs_oracle pins to the oracle at the same size."""
+    from xmap.engine import synth
+    r = synth.config_c1()
+    eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs())
+    S = eng.item_sim("adjust_cosine", CAP)
+    E1 = eng.extend(S, 10, full=True, chunk=1 << 40)
+    assert E1.units.n_heavy == 0
+    assert int(E1.n_cand.max().item()) > 16 * 128          # slices longer than the selection buffer
+    for chunk in (1 << 14, 1 << 11):                       # few rows per start / more than one merge group
+        E2 = eng.extend(S, 10, full=True, chunk=chunk)
+        assert E2.units.n_heavy > 10
+        g = E2.units.unit_G.cpu().numpy()
+        if chunk == 1 << 11:
+            assert g.max() > 12                            # more than one merge group
+        assert E1.n_paths == E2.n_paths and E1.n_out == E2.n_out
+        assert np.array_equal(E1.n_cand.cpu().numpy(), E2.n_cand.cpu().numpy())
+        assert np.array_equal(E1.top_end.cpu().numpy(), E2.top_end.cpu().numpy())
+        assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
+        for x, y in zip(_xsim_lists(E1, r.n_items), _xsim_lists(E2, r.n_items)):
+            assert np.array_equal(x, y)
