@@ -531,40 +531,43 @@ class Engine(object):
             check(lib.xmap_path_weights(st, i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(R.flags),
                                         vp(E.att[0]), vp(E.att[1]), vp(E.src[0]), vp(E.src[1]), vp(E.src[3]),
                                         vp(E.rnn[0]), vp(E.rnn[1]), vp(tmp), vp(P)))
-        p = P.cpu().numpy()[:I].copy()
+        # planning on the device (a numpy argsort of the starts alone was 15 ms of host time per pass)
+        p = P[:I].clone()
         if start_split is not None:   # (rank, world): contiguous start ranges of equal path counts
             from .sharded import balanced_ranges
-            start_range = balanced_ranges(p, start_split[1])[start_split[0]]
+            start_range = balanced_ranges(p.cpu().numpy(), start_split[1])[start_split[0]]
         lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
         p[:lo] = 0
         p[hi:] = 0
-        total = int(p.sum())
+        total = int(p.sum().item())
         if chunk is None:
             chunk = max(1 << 22, total // int(os.environ.get("XMAP_CHUNK_DIV", "8192")))
         row_bytes = 36 * max(I, 1)
         row_budget = int(float(os.environ.get("XMAP_ROW_BUDGET_GB", row_budget / (1 << 30))) * (1 << 30))
         while True:
-            G = np.where(p > chunk, -(-p // chunk), 1).astype(np.int64)
-            G[p == 0] = 0
-            n_rows = int(G[G > 1].sum())
+            G = torch.where(p > chunk, (p + (chunk - 1)) // chunk, (p > 0).to(torch.int64))
+            n_rows = int(G[G > 1].sum().item())
             if n_rows * row_bytes <= row_budget or chunk > total:
                 break
             chunk *= 2
-        starts = np.nonzero(G > 0)[0]
-        cost = p[starts] / np.maximum(G[starts], 1)
-        order = starts[np.argsort(-cost, kind="stable")]
+        starts = torch.nonzero(G > 0).flatten()
+        cost = p[starts].double() / G[starts].clamp(min=1).double()
+        order = starts[torch.sort(-cost, stable=True).indices]
         g = G[order]
-        unit_start = np.repeat(order, g).astype(np.int32)
-        first = np.cumsum(g) - g
-        unit_c = (np.arange(len(unit_start)) - np.repeat(first, g)).astype(np.int32)
-        unit_G = np.repeat(g, g).astype(np.int32)
+        unit_start = torch.repeat_interleave(order, g).to(torch.int32)
+        first = torch.cumsum(g, 0) - g
+        n_units = int(unit_start.numel())
+        unit_c = (torch.arange(n_units, dtype=torch.int64, device=self.dev) - torch.repeat_interleave(first, g)).to(torch.int32)
+        unit_G = torch.repeat_interleave(g, g).to(torch.int32)
         heavy = g > 1
-        row0 = np.cumsum(np.where(heavy, g, 0)) - np.where(heavy, g, 0)
-        unit_row = np.where(np.repeat(heavy, g), np.repeat(row0, g) + unit_c, -1).astype(np.int32)
-        heavy_unit0 = first[heavy].astype(np.int32)
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a if len(a) else np.zeros(1, a.dtype))).to(self.dev)
+        gh = torch.where(heavy, g, torch.zeros_like(g))
+        row0 = torch.cumsum(gh, 0) - gh
+        unit_row = torch.where(torch.repeat_interleave(heavy, g), torch.repeat_interleave(row0, g) + unit_c.long(),
+                               torch.full((n_units,), -1, dtype=torch.int64, device=self.dev)).to(torch.int32)
+        heavy_unit0 = first[heavy].to(torch.int32)
+        t = lambda a: a.contiguous() if a.numel() else torch.zeros(1, dtype=a.dtype, device=self.dev)
         U = ExtResult()
-        U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = len(unit_start), int(heavy.sum()), n_rows, total, int(chunk)
+        U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = n_units, int(heavy_unit0.numel()), n_rows, total, int(chunk)
         U.unit_start, U.unit_c, U.unit_G, U.unit_row = t(unit_start), t(unit_c), t(unit_G), t(unit_row)
         U.heavy_unit0 = t(heavy_unit0)
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
