@@ -200,14 +200,22 @@ int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t 
  *                               (core/extender.py:61-70,174,176); rflag bit0 = (t,s) also joins TGT (:72-81,175-178)
  *   mode 2 RNN   : rnn(y)    = [x : x non-bridge record, y in NB_NN(x)]    (core/extender.py:142-169 longest_path)
  * count pass: rcnt[I]; fill pass: ridx / rval (sim, mutu, frac) / rflag at rptr[a] + ... */
+/* thr[i][l] = {|sim| (double), column (int32), length (int32)} of the LAST entry of list l of item i (16 B each): the
+ * membership tests of xmap_reverse_* then cost one gather into a 32 B x n_items table instead of three into the lists. */
+int xmap_knn_thresholds(void *stream, int32_t n_items, int top_k, const int32_t *kcnt, const int32_t *kcol, const double *kval,
+                        void *thr /*[n_items][2] x 16 B*/);
 int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                        const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                        const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
+                       const void *thr /*xmap_knn_thresholds or NULL*/,
+                       int32_t *long_rows /*[I+1] scratch or NULL: written here, rows of > 4096 entries get 16 waves*/,
                        int32_t *rcnt /*[I]*/);
 int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
-                      const int64_t *rptr /*[I+1]*/, int32_t *ridx, double *rval /*[n][3]*/, uint8_t *rflag);
+                      const void *thr /*xmap_knn_thresholds or NULL*/,
+                      int32_t *long_rows /*as left by xmap_reverse_count, or NULL*/, const int64_t *rptr /*[I+1]*/,
+                      int32_t *ridx, double *rval /*[n][3]*/, uint8_t *rflag);
 
 /* Scheduling weights of the path enumeration: paths[start] = number of paths that start at `start`
  * (exact; tails(s) summed over src(t), heads over NB_BB / rnn).  tmp: 4*n_items int64 of scratch. */

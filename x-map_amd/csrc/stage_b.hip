@@ -226,8 +226,25 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
 // membership of item a in list l of neighbour b, given |sim(a,b)| (bit-symmetric by construction):
 // a is in the list iff it passes the list's class predicate and sorts at or before the list's
 // last entry in the order (|sim| desc, col asc) -- or the list is not full.
+// the last entry of a top-k list: membership of a in the list of b is one comparison against it (the similarity is
+// bit-symmetric); 12.8 MB for 4e5 items -- resident in the Infinity Cache, where the lists themselves (1.1 GB) are not
+struct KnnThr { double la; int col; int cnt; };
+__global__ __launch_bounds__(256) void k_knn_thresholds(int I, int k, const int *kcnt, const int *kcol, const double *kval, KnnThr *thr) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2ll * I) return;
+    KnnThr th;
+    th.cnt = kcnt[t]; th.col = 0; th.la = 0.0;
+    if (th.cnt > 0) {
+        const size_t o = (size_t)t * k + (th.cnt - 1);
+        th.la = fabs(kval[o * 3]); th.col = kcol[o];
+    }
+    thr[t] = th;
+}
+
 struct RevArgs {
     int I, k, mode;
+    const KnnThr *thr;
+    const int *long_rows;        // [0] = count, then the rows with more than REV_LONG entries (or NULL)
     const long long *row_ptr;
     const int *col;
     const double *sim;
@@ -252,7 +269,10 @@ struct RevArgs {
 };
 
 __device__ __forceinline__ bool in_list(const RevArgs &A, int b, int l, int a, double abs_sim) {
-    int c = A.kcnt[(size_t)b * 2 + l];
+    KnnThr th;
+    th.cnt = 0; th.col = 0; th.la = 0.0;
+    if (A.thr) th = A.thr[(size_t)b * 2 + l];        // one 16-byte gather instead of count, last value, last column
+    int c = A.thr ? th.cnt : A.kcnt[(size_t)b * 2 + l];
     if (c == 0) return false;
     bool pred;
     if (A.cls[b] == 1) {
@@ -263,17 +283,58 @@ __device__ __forceinline__ bool in_list(const RevArgs &A, int b, int l, int a, d
     }
     if (!pred) return false;
     if (c < A.k) return true;
+    if (A.thr) return (abs_sim > th.la) || (abs_sim == th.la && a <= th.col);
     size_t o = ((size_t)b * 2 + l) * A.k + (c - 1);
     double la = fabs(A.kval[o * 3]);
     return (abs_sim > la) || (abs_sim == la && a <= A.kcol[o]);
 }
 
+// one entry p of row a: does b = col[p] list a?  (mode 0 attach, 1 src, 2 rnn; fl: the (t,s) is joint)
+__device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, long long hi, int &b, double &sv, uint8_t &fl) {
+    bool ok = false;
+    b = 0; sv = 0.0; fl = 0;
+    if (p < hi) {
+        b = A.col[p];
+        sv = A.sim[p];
+        double ab = fabs(sv);
+        int cb = A.cls[b];
+        if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
+            ok = (cb == 2) && in_list(A, b, 0, a, ab);
+        } else if (A.mode == 1) {    // src(t = a): s = b
+            ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
+                 (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
+            if (ok) {
+                bool joint = (A.cls[a] == 1) && (A.attach_ptr[a + 1] > A.attach_ptr[a]) &&
+                             (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
+                fl = joint ? 1 : 0;
+            }
+        } else {                     // rnn(y = a): x = b non-bridge record with a in NB_NN(x)
+            ok = (cb == 2) && in_list(A, b, 1, a, ab);
+        }
+    }
+    return ok;
+}
+__device__ __forceinline__ void rev_write(const RevArgs &A, int a, long long p, long long o, int b, double sv, uint8_t fl) {
+    double mu = (double)A.mutu[p];
+    A.ridx[o] = b;
+    A.rval[o * 3] = sv;
+    A.rval[o * 3 + 1] = mu;
+    A.rval[o * 3 + 2] = A.frac ? A.frac[p] : 1.0 * mu / (A.info[(size_t)a * 4 + 3] + A.info[(size_t)b * 4 + 3] - (double)A.nij[p]);
+    if (A.rflag) A.rflag[o] = fl;
+}
+
+// Rows up to REV_LONG entries: one wave per row.  The rows of the popular items have 10^5 entries and more; walked by
+// one wave each they were the whole duration of the pass (5 ms per pass for 0.2 ms of streaming): those rows are listed
+// (k_rev_long_rows) and walked by blocks of 16 waves, 1024 entries per step, in the same (row) order.
+constexpr int REV_LONG = 4096;
+constexpr int REV_WAVES = 16;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= A.I) return;
     int lane = lane_id();
     long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
+    if (A.long_rows && hi - lo > REV_LONG) return;
     bool row_ok = true;
     if (A.mode == 1) row_ok = (A.flags[a] & 2) != 0;  // "T:" in t
     long long out = FILL ? A.rptr[a] : 0;
@@ -281,45 +342,50 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     if (row_ok)
         for (long long base = lo; base < hi; base += 64) {
             long long p = base + lane;
-            bool ok = false;
-            int b = 0;
-            double sv = 0.0;
-            uint8_t fl = 0;
-            if (p < hi) {
-                b = A.col[p];
-                sv = A.sim[p];
-                double ab = fabs(sv);
-                int cb = A.cls[b];
-                if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
-                    ok = (cb == 2) && in_list(A, b, 0, a, ab);
-                } else if (A.mode == 1) {    // src(t = a): s = b
-                    ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
-                         (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
-                    if (ok) {
-                        bool joint = (A.cls[a] == 1) && (A.attach_ptr[a + 1] > A.attach_ptr[a]) &&
-                                     (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
-                        fl = joint ? 1 : 0;
-                    }
-                } else {                     // rnn(y = a): x = b non-bridge record with a in NB_NN(x)
-                    ok = (cb == 2) && in_list(A, b, 1, a, ab);
-                }
-            }
+            int b; double sv; uint8_t fl;
+            const bool ok = rev_entry(A, a, p, hi, b, sv, fl);
             unsigned long long m = __ballot(ok);
-            if (FILL && ok) {
-                long long o = out + __popcll(m & lanemask_lt());
-                double mu = (double)A.mutu[p];
-                A.ridx[o] = b;
-                A.rval[o * 3] = sv;
-                A.rval[o * 3 + 1] = mu;
-                A.rval[o * 3 + 2] = A.frac ? A.frac[p]
-                                           : 1.0 * mu / (A.info[(size_t)a * 4 + 3] + A.info[(size_t)b * 4 + 3] - (double)A.nij[p]);
-                if (A.rflag) A.rflag[o] = fl;
-            }
+            if (FILL && ok) rev_write(A, a, p, out + __popcll(m & lanemask_lt()), b, sv, fl);
             int c = __popcll(m);
             out += c;
             total += c;
         }
     if (!FILL && lane == 0) A.rcnt[a] = total;
+}
+
+__global__ __launch_bounds__(256) void k_rev_long_rows(int I, const long long *row_ptr, int *long_rows /*[0] = count*/) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < I && row_ptr[a + 1] - row_ptr[a] > REV_LONG) long_rows[1 + atomicAdd(&long_rows[0], 1)] = a;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64 * REV_WAVES) void k_reverse_long(RevArgs A) {
+    __shared__ int s_cnt[REV_WAVES];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int n_long = A.long_rows[0];
+    for (int r = blockIdx.x; r < n_long; r += gridDim.x) {
+        const int a = A.long_rows[1 + r];
+        const long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
+        const bool row_ok = (A.mode != 1) || ((A.flags[a] & 2) != 0);
+        long long out = FILL ? A.rptr[a] : 0;
+        int total = 0;
+        if (row_ok)
+            for (long long base = lo; base < hi; base += 64 * REV_WAVES) {
+                const long long p = base + threadIdx.x;
+                int b; double sv; uint8_t fl;
+                const bool ok = rev_entry(A, a, p, hi, b, sv, fl);
+                const unsigned long long m = __ballot(ok);
+                if (lane == 0) s_cnt[w] = __popcll(m);
+                __syncthreads();
+                int before = 0, all = 0;
+                for (int o = 0; o < REV_WAVES; o++) { const int c = s_cnt[o]; if (o < w) before += c; all += c; }
+                if (FILL && ok) rev_write(A, a, p, out + before + __popcll(m & lanemask_lt()), b, sv, fl);
+                out += all;
+                total += all;
+                __syncthreads();
+            }
+        if (!FILL && threadIdx.x == 0) A.rcnt[a] = total;
+    }
 }
 
 // =============================================================================================
@@ -1233,41 +1299,64 @@ int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t 
 static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, int top_k, const uint8_t *bb,
                           const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
                           const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
-                          const int64_t *attach_ptr, int32_t *rcnt, const int64_t *rptr, int32_t *ridx, double *rval,
-                          uint8_t *rflag) {
+                          const int64_t *attach_ptr, const void *thr, int32_t *long_rows, int32_t *rcnt, const int64_t *rptr,
+                          int32_t *ridx, double *rval, uint8_t *rflag) {
     XM_ARG(S && bb && cls && kcnt && kcol && kval && suffix_cls && contains_mask && flags);
     XM_ARG(mode >= 0 && mode <= 2);
     XM_ARG(mode != 1 || attach_ptr);
     if (S->n_items == 0) return XMAP_OK;
     RevArgs A;
-    A.I = S->n_items; A.k = top_k; A.mode = mode;
+    A.I = S->n_items; A.k = top_k; A.mode = mode; A.thr = (const KnnThr *)thr; A.long_rows = long_rows;
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
     A.info = S->info; A.frac = S->frac; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
     A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
     A.attach_ptr = (const long long *)attach_ptr;
     A.rcnt = rcnt; A.rptr = (const long long *)rptr; A.ridx = ridx; A.rval = rval; A.rflag = rflag;
     dim3 grid((unsigned)((S->n_items + 3) / 4)), block(256);
-    if (fill) k_reverse<true><<<grid, block, 0, (hipStream_t)stream>>>(A);
-    else k_reverse<false><<<grid, block, 0, (hipStream_t)stream>>>(A);
+    hipStream_t st = (hipStream_t)stream;
+    if (long_rows && !fill) {     // the count pass lists the long rows, the fill pass that follows reuses the list
+        XM_HIP(hipMemsetAsync(long_rows, 0, sizeof(int32_t), st));
+        k_rev_long_rows<<<dim3((unsigned)((S->n_items + 255) / 256)), dim3(256), 0, st>>>(S->n_items, (const long long *)S->row_ptr,
+                                                                                      long_rows);
+        XM_LAUNCH_CHECK();
+    }
+    if (fill) k_reverse<true><<<grid, block, 0, st>>>(A);
+    else k_reverse<false><<<grid, block, 0, st>>>(A);
+    XM_LAUNCH_CHECK();
+    if (long_rows) {
+        if (fill) k_reverse_long<true><<<dim3(512), dim3(64 * REV_WAVES), 0, st>>>(A);
+        else k_reverse_long<false><<<dim3(512), dim3(64 * REV_WAVES), 0, st>>>(A);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
+
+int xmap_knn_thresholds(void *stream, int32_t n_items, int top_k, const int32_t *kcnt, const int32_t *kcol, const double *kval,
+                        void *thr) {
+    XM_ARG(kcnt && kcol && kval && thr);
+    if (n_items == 0) return XMAP_OK;
+    k_knn_thresholds<<<dim3((unsigned)((2ll * n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        n_items, top_k, kcnt, kcol, kval, (KnnThr *)thr);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
 
 int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                        const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
-                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, int32_t *rcnt) {
+                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, const void *thr,
+                       int32_t *long_rows, int32_t *rcnt) {
     XM_ARG(rcnt);
     return reverse_common(stream, false, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
-                          attach_ptr, rcnt, nullptr, nullptr, nullptr, nullptr);
+                          attach_ptr, thr, long_rows, rcnt, nullptr, nullptr, nullptr, nullptr);
 }
 
 int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
-                      const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
-                      const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag) {
+                      const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, const void *thr,
+                      int32_t *long_rows, const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag) {
     XM_ARG(rptr && ridx && rval);
     return reverse_common(stream, true, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
-                          attach_ptr, nullptr, rptr, ridx, rval, rflag);
+                          attach_ptr, thr, long_rows, nullptr, rptr, ridx, rval, rflag);
 }
 
 int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end, const double *xs_val,

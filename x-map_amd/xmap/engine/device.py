@@ -506,7 +506,8 @@ class Engine(object):
         I = R.n_items
         rcnt = self._zeros(max(I, 1), torch.int32)
         args = (C.byref(S.c), mode, E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval),
-                vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(attach_ptr))
+                vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(attach_ptr), vp(getattr(E, "thr", None)),
+                vp(getattr(E, "long_rows", None)))
         check(lib.xmap_reverse_count(st, *args, vp(rcnt)))
         rptr = self._zeros(I + 1, torch.int64)
         tot = C.c_int64(0)
@@ -632,6 +633,9 @@ class Engine(object):
         E = self.knn(S, top_k)
         st = _stream(self.dev)
         with self.timed("reverse"):
+            E.thr = self._empty(max(I, 1) * 4, torch.float64)      # last entry of every list, 16 B each
+            check(lib.xmap_knn_thresholds(st, i32(I), E.k, vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(E.thr)))
+            E.long_rows = self._empty(max(I, 1) + 1, torch.int32)
             E.att = self._reverse(S, E, 0, None)
             E.src = self._reverse(S, E, 1, E.att[0])
             E.rnn = self._reverse(S, E, 2, None)
