@@ -345,3 +345,12 @@ def test_heavy_starts_with_long_candidate_lists(dev):
         assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
         for x, y in zip(_xsim_lists(E1, r.n_items), _xsim_lists(E2, r.n_items)):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_long_rows_of_the_reverse_lists(dev, method, monkeypatch):
+    """every row of more than 64 entries through the 16-wave form of k_reverse (XMAP_REV_LONG): all stages against the
+    oracle."""
+    monkeypatch.setenv("XMAP_REV_LONG", "64")
+    from xmap.engine import synth
+    _check_all_stages(dev, synth.make_two_domain(5, 2000, 400, 400), method, 5)

@@ -10,6 +10,7 @@
 //   k_paths         : streamed path enumeration, one wave per start item, fp64 (s_p, c_p) in
 //                     registers, per-start accumulators, fused top-10                      (ALU / latency bound)
 #include "common.h"
+#include <stdlib.h>
 
 namespace xmap {
 
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
 // membership of item a in list l of neighbour b, given |sim(a,b)| (bit-symmetric by construction):
 // a is in the list iff it passes the list's class predicate and sorts at or before the list's
 // last entry in the order (|sim| desc, col asc) -- or the list is not full.
-// the last entry of a top-k list: membership of a in the list of b is one comparison against it (the similarity is
-// bit-symmetric); 12.8 MB for 4e5 items -- resident in the Infinity Cache, where the lists themselves (1.1 GB) are not
+// KnnThr: that last entry of every list as one 16-byte record (12.8 MB for 4e5 items: resident in the Infinity Cache,
+// where the lists themselves, 1.1 GB, are not)
 struct KnnThr { double la; int col; int cnt; };
 __global__ __launch_bounds__(256) void k_knn_thresholds(int I, int k, const int *kcnt, const int *kcol, const double *kval, KnnThr *thr) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(256) void k_knn_thresholds(int I, int k, const int 
 struct RevArgs {
     int I, k, mode;
     const KnnThr *thr;
-    const int *long_rows;        // [0] = count, then the rows with more than REV_LONG entries (or NULL)
+    const int *long_rows;        // [0] = count, then the rows with more than rev_long entries (or NULL)
+    int rev_long;
     const long long *row_ptr;
     const int *col;
     const double *sim;
@@ -326,7 +328,7 @@ __device__ __forceinline__ void rev_write(const RevArgs &A, int a, long long p, 
 // Rows up to REV_LONG entries: one wave per row.  The rows of the popular items have 10^5 entries and more; walked by
 // one wave each they were the whole duration of the pass (5 ms per pass for 0.2 ms of streaming): those rows are listed
 // (k_rev_long_rows) and walked by blocks of 16 waves, 1024 entries per step, in the same (row) order.
-constexpr int REV_LONG = 4096;
+constexpr int REV_LONG = 4096;      // default of RevArgs::rev_long (XMAP_REV_LONG overrides it: tests walk every row both ways)
 constexpr int REV_WAVES = 16;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     if (a >= A.I) return;
     int lane = lane_id();
     long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
-    if (A.long_rows && hi - lo > REV_LONG) return;
+    if (A.long_rows && hi - lo > A.rev_long) return;
     bool row_ok = true;
     if (A.mode == 1) row_ok = (A.flags[a] & 2) != 0;  // "T:" in t
     long long out = FILL ? A.rptr[a] : 0;
@@ -353,9 +355,9 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     if (!FILL && lane == 0) A.rcnt[a] = total;
 }
 
-__global__ __launch_bounds__(256) void k_rev_long_rows(int I, const long long *row_ptr, int *long_rows /*[0] = count*/) {
+__global__ __launch_bounds__(256) void k_rev_long_rows(int I, const long long *row_ptr, int rev_long, int *long_rows /*[0] = count*/) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < I && row_ptr[a + 1] - row_ptr[a] > REV_LONG) long_rows[1 + atomicAdd(&long_rows[0], 1)] = a;
+    if (a < I && row_ptr[a + 1] - row_ptr[a] > rev_long) long_rows[1 + atomicAdd(&long_rows[0], 1)] = a;
 }
 
 template <bool FILL>
@@ -1307,6 +1309,8 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     if (S->n_items == 0) return XMAP_OK;
     RevArgs A;
     A.I = S->n_items; A.k = top_k; A.mode = mode; A.thr = (const KnnThr *)thr; A.long_rows = long_rows;
+    const char *rl = getenv("XMAP_REV_LONG");
+    A.rev_long = (rl && atoi(rl) > 0) ? atoi(rl) : REV_LONG;
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
     A.info = S->info; A.frac = S->frac; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
     A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
@@ -1317,7 +1321,7 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     if (long_rows && !fill) {     // the count pass lists the long rows, the fill pass that follows reuses the list
         XM_HIP(hipMemsetAsync(long_rows, 0, sizeof(int32_t), st));
         k_rev_long_rows<<<dim3((unsigned)((S->n_items + 255) / 256)), dim3(256), 0, st>>>(S->n_items, (const long long *)S->row_ptr,
-                                                                                      long_rows);
+                                                                                      A.rev_long, long_rows);
         XM_LAUNCH_CHECK();
     }
     if (fill) k_reverse<true><<<grid, block, 0, st>>>(A);
