@@ -11,3 +11,7 @@ echo fetch done
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${T}_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/${T}_write.json 2> gpurun_out/${T}_write.err || exit 1
 echo write done
 rm -f gpurun_out/${T}_stats/*/*kernel_trace.csv
+timeout -k 10 200 python3 bench.py --workload recsim --steps 3 --warmup 1 > gpurun_out/${T}_recsim.json 2> gpurun_out/${T}_recsim.err || exit 1
+timeout -k 10 200 python3 bench.py --workload dense --steps 3 --warmup 1 > gpurun_out/${T}_dense.json 2> gpurun_out/${T}_dense.err || exit 1
+timeout -k 10 200 python3 bench.py --workload c1 --steps 3 --warmup 1 > gpurun_out/${T}_c1.json 2> gpurun_out/${T}_c1.err || exit 1
+echo extra done
