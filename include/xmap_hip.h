@@ -139,10 +139,11 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]*/, int32_t *hid /*[I]*/, int32_t *hlist /*[1024]*/,
                      uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] x 8 B: item|flag, rating*/,
                      void *rc /*[nnz] x 16 B rater records in CSC order*/,
+                     uint64_t *Wp /*[I] out: contributions per row (sum of its raters' prefix lengths)*/,
                      int32_t dups /*1: a profile may hold an item more than once (AlterEgo rows)*/, int32_t *h_ctl /*[2]*/);
 int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const void *rc, const int64_t *pre,
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small /*[I]*/,
-                   uint64_t *Wp /*[I] out: contributions per row*/, int32_t *Qcat /*[5 I]*/, int64_t *uq_ptr /*[5 I + 1]*/,
+                   uint64_t *Wp /*[I] as left by xmap_sim2_layout*/, int32_t *Qcat /*[5 I]*/, int64_t *uq_ptr /*[5 I + 1]*/,
                    int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int64_t *h_counts /*[8], host*/);
 int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const int64_t *uq_ptr, int32_t *uq_item,
                     int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c);

@@ -198,41 +198,60 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
 // one thread per CSC entry (item i, its p-th rater u): position of i in u's sorted profile = number of heavier
 // co-rated items = length of the prefix this rater contributes.  No atomics; raters stay in ascending user order.
 __global__ __launch_bounds__(256) void k_rater_records(int I, long long nnz, const long long *iptr, const int *iuser,
-                                                       const long long *uptr, const int2 *ub, RaterRec *rc, int *taken) {
+                                                       const long long *uptr, const int2 *ub, RaterRec *rc, int *taken,
+                                                       unsigned long long *Wp) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nnz) return;
-    // item of CSC entry p: binary search in iptr
-    int lo = 0, hi = I;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (iptr[mid] <= p) lo = mid; else hi = mid;
-    }
-    const int i = lo;
-    const int u = iuser[p];
-    const long long a = uptr[u], b = uptr[u + 1];
-    RaterRec r;
-    r.e0 = (int)a; r.pos_ge = 0; r.rating = 0.f; r.user = u;
-    for (long long e = a; e < b; e++) {
-        int2 v = ub[e];
-        if ((v.x & 0x7fffffff) == i) {
-            // A profile may hold the item more than once (AlterEgo rows: a pass-through and a mapped rating); the
-            // copies are adjacent in the sorted profile and the item then has as many CSC entries for this user:
-            // each takes one copy (`taken`, zeroed, non-NULL only when the caller allows duplicates).
-            if (taken && e + 1 < b && (ub[e + 1].x & 0x7fffffff) == i) {
-                e += atomicAdd(&taken[e], 1);
-                v = ub[e];
-            }
-            const int pos = (b - a >= 2) ? (int)(e - a) : 0;   // users with >= 2 ratings only (baselinerSim.py:184-185)
-            r.pos_ge = (int)((unsigned)pos | ((unsigned)v.x & 0x80000000u));
-            r.rating = __int_as_float(v.y);
-            break;
+    const bool valid = p < nnz;
+    int i = -1;
+    long long pos_sum = 0;
+    if (valid) {
+        // item of CSC entry p: binary search in iptr
+        int lo = 0, hi = I;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (iptr[mid] <= p) lo = mid; else hi = mid;
         }
+        i = lo;
+        const int u = iuser[p];
+        const long long a = uptr[u], b = uptr[u + 1];
+        RaterRec r;
+        r.e0 = (int)a; r.pos_ge = 0; r.rating = 0.f; r.user = u;
+        for (long long e = a; e < b; e++) {
+            int2 v = ub[e];
+            if ((v.x & 0x7fffffff) == i) {
+                // A profile may hold the item more than once (AlterEgo rows: a pass-through and a mapped rating); the
+                // copies are adjacent in the sorted profile and the item then has as many CSC entries for this user:
+                // each takes one copy (`taken`, zeroed, non-NULL only when the caller allows duplicates).
+                if (taken && e + 1 < b && (ub[e + 1].x & 0x7fffffff) == i) {
+                    e += atomicAdd(&taken[e], 1);
+                    v = ub[e];
+                }
+                const int pos = (b - a >= 2) ? (int)(e - a) : 0;   // users with >= 2 ratings only (baselinerSim.py:184-185)
+                r.pos_ge = (int)((unsigned)pos | ((unsigned)v.x & 0x80000000u));
+                r.rating = __int_as_float(v.y);
+                pos_sum = pos;
+                break;
+            }
+        }
+        rc[p] = r;
     }
-    rc[p] = r;
+    // W+ of the item = sum of its raters' prefix lengths (the contributions of its row): the entries of an item are
+    // consecutive, so a wave adds up its runs and issues one atomic per run (exact integers: order does not matter).
+    // k_plan2 had walked the rater records of every item for this sum, the popular items' 1e5 records with one wave.
+    const int lane = lane_id();
+    const int i_prev = __shfl_up(i, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || i != i_prev);
+    long long incl = pos_sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const bool seg_end = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+    const int h = 63 - __clzll((long long)(heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))));
+    const long long before = __shfl(incl, h > 0 ? h - 1 : 0, 64);
+    if (seg_end && i >= 0) {
+        const long long seg = incl - (h > 0 ? before : 0);
+        if (seg) atomicAdd(&Wp[i], (unsigned long long)seg);
+    }
 }
-
-// light rows: Q partitions; heavy rows (in H): chunks of CH raters.  W+ = the sum of the item's prefix lengths: four
-// items per wave, those with at most 64 raters together (one per 16-lane group), the others on the whole wave.
 __device__ __forceinline__ void plan_item(int i, long long w, int I, const long long *iptr, const long long *pre, int HB,
                                           const int *hid, const int *CH, int target, int dups, int *Q, int *C,
                                           uint8_t *small, unsigned long long *Wp, int *Qcat) {
@@ -261,34 +280,9 @@ __device__ __forceinline__ void plan_item(int i, long long w, int I, const long 
 __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, const RaterRec *rc, const long long *pre,
                                                int HB, const int *hid, const int *CH, int target, int dups, int *Q, int *C,
                                                uint8_t *small, unsigned long long *Wp, int *Qcat) {
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (i0 >= I) return;
-    const int lane = lane_id();
-    {
-        const int i = i0 + (lane >> 4), gl = lane & 15;
-        const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
-        long long w = 0;
-        if (on) for (long long p = iptr[i] + gl; p < iptr[i + 1]; p += 16) w += rc[p].pos_ge & 0x7fffffff;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) w += __shfl_xor(w, m, 64);
-        if (on && gl == 0) plan_item(i, w, I, iptr, pre, HB, hid, CH, target, dups, Q, C, small, Wp, Qcat);
-    }
-    for (int t = 0; t < 4; t++) {
-        const int i = i0 + t;
-        if (i >= I) break;
-        const long long p0 = iptr[i], p1 = iptr[i + 1];
-        if (p1 - p0 <= 64) continue;
-        long long w = 0;
-        for (long long p = p0 + lane; p < p1; p += 64 * 8) {   // 8 loads in flight per lane (popular items: 1e5 raters)
-            int v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (p + 64 * u < p1) ? rc[p + 64 * u].pos_ge & 0x7fffffff : 0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) w += v[u];
-        }
-        w = wave_sum_ll(w);
-        if (lane == 0) plan_item(i, w, I, iptr, pre, HB, hid, CH, target, dups, Q, C, small, Wp, Qcat);
-    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // W+ comes summed from k_rater_records
+    if (i >= I) return;
+    plan_item(i, (long long)Wp[i], I, iptr, pre, HB, hid, CH, target, dups, Q, C, small, Wp, Qcat);
 }
 
 __global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Qcat, const long long *uq_ptr, int *uq_item, int *uq_q,
@@ -873,8 +867,8 @@ int xmap_debug_atrace(unsigned long long *host, long long n_units) {
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]: CH, n_heavy*/, int32_t *hid, int32_t *hlist /*[1024]*/,
                      uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] 8 B*/, void *rc /*[nnz] 16 B*/,
-                     int32_t dups, int32_t *h_ctl /*[2]*/) {
-    XM_ARG(R && info && hist && pre && ctl && hid && hlist && ub_key && ub && rc && ch_min >= 64);
+                     uint64_t *Wp /*[I] out*/, int32_t dups, int32_t *h_ctl /*[2]*/) {
+    XM_ARG(R && info && hist && pre && ctl && hid && hlist && ub_key && ub && rc && Wp && ch_min >= 64);
     XM_ARG(R->nnz < 0x7fffffffLL && R->n_users < 0x7ffffff0LL);
     hipStream_t st = (hipStream_t)stream;
     const int I = R->n_items;
@@ -904,13 +898,14 @@ int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, in
             (unsigned long long *)ub_key, (int2 *)ub);
         XM_LAUNCH_CHECK();
     }
+    XM_HIP(hipMemsetAsync(Wp, 0, sizeof(uint64_t) * (size_t)(I > 0 ? I : 1), st));
     if (R->nnz > 0) {
         // profiles that may hold an item twice: the sort is done with ub_key, which then serves as the (zeroed) copy
         // counters of k_rater_records
         if (dups) XM_HIP(hipMemsetAsync(ub_key, 0, sizeof(int32_t) * (size_t)R->nnz, st));
         k_rater_records<<<dim3((unsigned)((R->nnz + 255) / 256)), dim3(256), 0, st>>>(
             I, R->nnz, (const long long *)R->item_ptr, R->item_user, (const long long *)R->user_ptr, (const int2 *)ub,
-            (RaterRec *)rc, dups ? (int *)ub_key : nullptr);
+            (RaterRec *)rc, dups ? (int *)ub_key : nullptr, (unsigned long long *)Wp);
         XM_LAUNCH_CHECK();
     }
     if (h_ctl) {
@@ -934,7 +929,7 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
     const int I = R->n_items;
     XM_HIP(hipMemsetAsync(Qcat, 0, sizeof(int32_t) * (size_t)N_CLASSES * (size_t)(I > 0 ? I : 1), st));
     if (I > 0) {
-        k_plan2<<<dim3((unsigned)((I + 15) / 16)), dim3(256), 0, st>>>(
+        k_plan2<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(
             I, (const long long *)R->item_ptr, (const RaterRec *)rc, (const long long *)pre, (int)R->n_users + 2, hid, ctl,
             slot_target, dups, Q, C, small, (unsigned long long *)Wp, Qcat);
         XM_LAUNCH_CHECK();

@@ -269,8 +269,8 @@ class Engine(object):
         h_ctl = (C.c_int32 * 2)()
         with self.timed("tri_layout"):
             check(lib.xmap_sim2_layout(st, C.byref(R.c), vp(info), i32(ch_min), vp(L.hist), vp(L.pre), vp(L.ctl),
-                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub), vp(L.rc), i32(1 if dups else 0),
-                                       h_ctl))
+                                       vp(L.hid), vp(L.hlist), vp(L.ub_key), vp(L.ub), vp(L.rc), vp(L.Wp),
+                                       i32(1 if dups else 0), h_ctl))
         L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
         L.slot_target = slot_target
         self._tri_plan(L, slot_target)
