@@ -131,15 +131,24 @@ __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, 
         double su[UN], qu[UN], ah[UN], al[UN];
 #pragma unroll
         for (int t = 0; t < UN; t++) { su[t] = 0.0; qu[t] = 0.0; ah[t] = 0.0; al[t] = 0.0; }
-        for (long long p = p0 + gl; p < p1; p += 64 * UN) {
-            float rr[UN];
-            int uu[UN];
+        // software pipeline: the ratings and users of the NEXT round are requested before this round's user averages
+        // are gathered, so a round costs one dependent round trip, not two (156 rounds for the most popular item: the
+        // kernel's tail).  Same partial sums in the same order.
+        float rr[UN], nr[UN];
+        int uu[UN], nu[UN];
+        auto fetch = [&](long long p, float *r_, int *u_) {
 #pragma unroll
             for (int t = 0; t < UN; t++) {
                 const long long pp = p + 64 * t;
-                rr[t] = pp < p1 ? irating[pp] : 0.f;
-                uu[t] = pp < p1 ? iuser[pp] : -1;
+                r_[t] = pp < p1 ? irating[pp] : 0.f;
+                u_[t] = pp < p1 ? iuser[pp] : -1;
             }
+        };
+        fetch(p0 + gl, nr, nu);
+        for (long long p = p0 + gl; p < p1; p += 64 * UN) {
+#pragma unroll
+            for (int t = 0; t < UN; t++) { rr[t] = nr[t]; uu[t] = nu[t]; }
+            fetch(p + 64 * UN, nr, nu);      // out-of-range entries come back as (0, -1)
             double av[UN];
 #pragma unroll
             for (int t = 0; t < UN; t++) av[t] = uu[t] >= 0 ? u_avg[uu[t]] : 0.0;
