@@ -666,19 +666,23 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
 }
 
 // rows of H: chunk c of the raters, dense table over H (partners of a heavy row are heavier, hence in H)
+// HEAVY_WAVES waves share the unit's dense table (each takes every HEAVY_WAVES-th block of 64 raters): a unit is a chain
+// of dependent gathers (rater record -> prefix entry -> heavy id) and one wave per 26 KB table left 6 waves on a CU.
+constexpr int HEAVY_WAVES = 4;
 template <int METHOD>
-__global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
+__global__ __launch_bounds__(64 * HEAVY_WAVES) void k_pair_heavy(TriArgs A) {
     __shared__ uint32_t cnt[HMAX];
     __shared__ uint32_t mut[HMAX];
     __shared__ double dot[HMAX];
     __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? HMAX : 1];
-    __shared__ unsigned short claim[METHOD == XMAP_ADJUST_COSINE ? HMAX : 1];
-    const int lane = lane_id();
+    __shared__ unsigned lockw[METHOD == XMAP_ADJUST_COSINE ? HMAX : 1];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
     const int unit = blockIdx.x;
-    for (int s = lane; s < HMAX; s += 64) {
+    for (int s = threadIdx.x; s < HMAX; s += 64 * HEAVY_WAVES) {
         cnt[s] = 0; mut[s] = 0; dot[s] = 0.0;
-        if (METHOD == XMAP_ADJUST_COSINE) dlo[s] = 0.0;
+        if (METHOD == XMAP_ADJUST_COSINE) { dlo[s] = 0.0; lockw[s] = 0u; }
     }
+    __syncthreads();
     const int i = uniform(A.uc_item[unit]);
     const int c = uniform(A.uc_c[unit]);
     const int CH = uniform(*A.CH);
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
     const int p0 = base0 + c * CH;
     int p1 = uniform((int)A.iptr[i + 1]);
     if (p0 + CH < p1) p1 = p0 + CH;
-    for (int base = p0; base < p1; base += 64) {
+    for (int base = p0 + 64 * w; base < p1; base += 64 * HEAVY_WAVES) {
         const int p = base + lane;
         int e0 = 0, pw = 0;
         float r = 0.f;
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
             if (METHOD == XMAP_ADJUST_COSINE) au = A.u_avg[rr.user];
         }
         // one rater per lane: within H a rater's prefix is short (0.8 entries on average at BASELINE configs[1]), so
-        // every lane walks its own; lanes that meet on a partner use LDS atomics / the claim word
+        // every lane walks its own; lanes that meet on a partner use LDS atomics / a lock word per slot
         const int b1 = (p < p1) ? e0 + (pw & 0x7fffffff) : e0;
         const unsigned gei = ((unsigned)pw) >> 31;
         const double ri = (double)r;
@@ -716,22 +720,23 @@ __global__ __launch_bounds__(64) void k_pair_heavy(TriArgs A) {
                 else term = (ri - au) * ((double)rj - au);
             }
             if (METHOD == XMAP_ADJUST_COSINE) {
-                volatile unsigned short *vclaim = claim;
                 volatile double *vhi = dot, *vlo = dlo;
                 bool pending = act;
-                while (__ballot(pending)) {       // lanes that share a slot take turns
-                    if (pending) vclaim[h] = (unsigned short)lane;
-                    if (pending && vclaim[h] == (unsigned short)lane) {
+                while (__ballot(pending)) {       // a lock per slot: the holder releases in the same pass
+                    if (pending && atomicCAS(&lockw[h], 0u, 1u) == 0u) {
                         double hi = vhi[h], lo = vlo[h];
                         dd_add(hi, lo, term);
                         vhi[h] = hi; vlo[h] = lo;
+                        __threadfence_block();
+                        atomicExch(&lockw[h], 0u);
                         pending = false;
                     }
                 }
             }
         }
     }
-    for (int s = lane; s < HMAX; s += 64) {
+    __syncthreads();
+    for (int s = threadIdx.x; s < HMAX; s += 64 * HEAVY_WAVES) {
         size_t o = (size_t)unit * HMAX + s;
         A.hp_cnt[o] = (int)cnt[s];
         A.hp_mut[o] = (int)mut[s];
@@ -999,8 +1004,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.coo_aux = coo_ls;
     A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials
-        if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
-        else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64), 0, st>>>(A);
+        if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64 * HEAVY_WAVES), 0, st>>>(A);
+        else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64 * HEAVY_WAVES), 0, st>>>(A);
         XM_LAUNCH_CHECK();
     }
     if ((phases & 2) && unit_hi > unit_lo) {
