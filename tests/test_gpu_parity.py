@@ -354,3 +354,15 @@ def test_long_rows_of_the_reverse_lists(dev, method, monkeypatch):
     monkeypatch.setenv("XMAP_REV_LONG", "64")
     from xmap.engine import synth
     _check_all_stages(dev, synth.make_two_domain(5, 2000, 400, 400), method, 5)
+
+
+def test_rows_longer_than_one_knn_chunk(dev):
+    """similarity rows of several thousand entries (k_knn_classify streams what follows its first 2048-entry chunk
+    against the lists' thresholds): knn tables and everything downstream against the oracle."""
+    from xmap.engine import synth
+    r = synth.make_two_domain(17, 2500, 3000, 3000, overlap=0.5, mu=3.2, sigma=1.0)
+    eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs())
+    S = eng.item_sim("cosine", CAP)
+    ln = np.diff(S.row_ptr.cpu().numpy())
+    assert (ln > 2048).sum() > 200 and ln.max() > 4096
+    _check_all_stages(dev, r, "cosine", 3)

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void k_bridge_flags(int I, const long long *ro
 // =============================================================================================
 constexpr int K_THREADS = 256;
 constexpr int K_CH = 2048;  // entries sorted per chunk (32 KB of LDS)
+constexpr int K_WIN = 1024;  // entries streamed against the thresholds per step (rows longer than one chunk)
 
 __device__ __forceinline__ bool before(unsigned long long ka, int ca, unsigned long long kb, int cb) {
     return (ka > kb) || (ka == kb && ca < cb);
@@ -85,6 +86,8 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
     __shared__ int scol[K_CH];
     __shared__ int spos[K_CH];
     __shared__ long long sscan[4];
+    __shared__ unsigned long long s_thrk[2];
+    __shared__ int s_thrc[2], s_has[2], s_fill;
 
     const int i = blockIdx.x;
     const int tid = threadIdx.x;
@@ -101,17 +104,58 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
     }
     const bool isbb = A.bb[i] != 0;
     const int sc = A.suffix_cls[i];
+    if (tid < 2) s_has[tid] = 0;
     int nc = 0, consumed = 0;
     for (;;) {
-        const int take = (K_CH - nc) < (n - consumed) ? (K_CH - nc) : (n - consumed);
-        for (int t = tid; t < take; t += K_THREADS) {
-            int p = consumed + t;
-            double s = A.sim[lo + p];
-            skey[nc + t] = (unsigned long long)__double_as_longlong(fabs(s));
-            scol[nc + t] = A.col[lo + p];
-            spos[nc + t] = p;
+        int total;
+        if (consumed == 0 || K_CH - nc < K_WIN) {
+            const int take = (K_CH - nc) < (n - consumed) ? (K_CH - nc) : (n - consumed);
+            for (int t = tid; t < take; t += K_THREADS) {
+                int p = consumed + t;
+                double s = A.sim[lo + p];
+                skey[nc + t] = (unsigned long long)__double_as_longlong(fabs(s));
+                scol[nc + t] = A.col[lo + p];
+                spos[nc + t] = p;
+            }
+            total = nc + take;
+            consumed += take;
+        } else {
+            // Rows longer than one chunk (the popular items: 1e5 entries and more): after the first sort the k-th best of
+            // each list is known, and an entry that does not sort before it can never enter that list -- the rest of the
+            // row is streamed against the two thresholds, K_WIN entries per step, and only the survivors are buffered
+            // (a few hundred for 1e5 entries in random order) instead of sorting every 2048 of them.
+            if (tid == 0) s_fill = nc;
+            __syncthreads();
+            for (;;) {
+                const int f = s_fill;      // the same value for every thread: nobody is past the barrier below yet
+                __syncthreads();
+                if (consumed >= n || K_CH - f < K_WIN) break;
+#pragma unroll
+                for (int u = 0; u < K_WIN / K_THREADS; u++) {
+                    const int p = consumed + tid + K_THREADS * u;
+                    if (p < n) {
+                        const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(A.sim[lo + p]));
+                        const int c = A.col[lo + p];
+                        bool pa, pb;
+                        if (isbb) {
+                            bool has = (A.contains_mask[c] >> sc) & 1u;
+                            pa = !has; pb = has;
+                        } else {
+                            pa = A.bb[c] != 0; pb = true;
+                        }
+                        const bool keep = (pa && (!s_has[0] || before(key, c, s_thrk[0], s_thrc[0]))) ||
+                                          (pb && (!s_has[1] || before(key, c, s_thrk[1], s_thrc[1])));
+                        if (keep) {
+                            const int o = atomicAdd(&s_fill, 1);
+                            skey[o] = key; scol[o] = c; spos[o] = p;
+                        }
+                    }
+                }
+                consumed = (consumed + K_WIN) < n ? (consumed + K_WIN) : n;
+                __syncthreads();
+            }
+            total = s_fill;
         }
-        const int total = nc + take;
         int N = 2;
         while (N < total) N <<= 1;
         for (int t = total + tid; t < N; t += K_THREADS) {
@@ -159,7 +203,6 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
         long long ex = block_scan_ll(((long long)cB << 32) | (unsigned)cA, &tot, sscan);
         int rA = (int)(ex & 0xffffffffll), rB = (int)(ex >> 32);
         const int totA = (int)(tot & 0xffffffffll), totB = (int)(tot >> 32);
-        consumed += take;
         const bool last = consumed >= n;
         if (last) {
             for (int t = s0; t < s0 + per && t < total; t++) {
@@ -211,6 +254,8 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
                 pa = A.bb[c] != 0; pb = true;
             }
             if ((pa && rA < k) || (pb && rB < k)) { rk[nk] = skey[t]; rc[nk] = c; rp[nk] = spos[t]; nk++; }
+            if (pa && rA == k - 1) { s_thrk[0] = skey[t]; s_thrc[0] = c; s_has[0] = 1; }     // the k-th best of a list
+            if (pb && rB == k - 1) { s_thrk[1] = skey[t]; s_thrc[1] = c; s_has[1] = 1; }
             rA += pa; rB += pb;
         }
         long long tk;
