@@ -234,7 +234,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)    # the first pass of a fresh process allocates (and first-touches) ~120 GB of accumulator rows
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--method", default="adjust_cosine")   # parameters.yaml:17
     ap.add_argument("--k", type=int, default=0)
