@@ -94,6 +94,26 @@ def test_balanced_ranges():
     assert balanced_ranges(np.zeros(0), 3) == [(0, 0)] * 3
 
 
+def test_unit_cuts_of_the_sharded_stage_a():
+    """light units over the ranks: contiguous, complete, equal rater steps; the heavy rows count against rank 0."""
+    import torch
+    from xmap.engine.sharded import unit_cuts
+    steps = torch.tensor([3.0, 1, 1, 1, 2, 2, 2, 4, 4, 4, 1, 1, 1, 1, 4], dtype=torch.float64)
+    c = torch.cumsum(steps, 0)
+    for world in (1, 2, 3, 4, 8):
+        for wh in (None, torch.tensor(0.0, dtype=torch.float64), torch.tensor(8.0, dtype=torch.float64), torch.tensor(1e9, dtype=torch.float64)):
+            cuts = unit_cuts(c, wh, world)
+            assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == len(steps)
+            assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+    assert unit_cuts(c, None, 1).tolist() == [0, 15]
+    even = unit_cuts(c, None, 2).tolist()
+    assert abs(float(c[even[1] - 1]) - 16.0) <= 4.0                      # half of the 32 steps, to within one unit
+    shifted = unit_cuts(c, torch.tensor(8.0, dtype=torch.float64), 2).tolist()
+    assert shifted[1] < even[1]                                          # rank 0 gives light units away
+    assert unit_cuts(c, torch.tensor(1e9, dtype=torch.float64), 2).tolist() == [0, 0, 15]   # heavier than everything
+    assert unit_cuts(torch.zeros(0, dtype=torch.float64), None, 3).tolist() == [0, 0, 0, 0]
+
+
 def test_draw_picks_matches_sequential_reference_draws():
     from xmap.engine import hipabi  # noqa: F401  (device module needs the library)
     from xmap.engine.device import draw_picks

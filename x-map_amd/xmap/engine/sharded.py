@@ -35,6 +35,20 @@ def balanced_ranges(weights, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def unit_cuts(c, w_heavy, world):
+    """Cut points of the light work units over `world` ranks.  c: inclusive prefix sum (float64 tensor) of the units' rater
+    steps; w_heavy: rater visits of the heavy rows (0-d tensor or None), which rank 0 computes as well and which therefore
+    count against its share.  Returns world + 1 non-decreasing unit indices from 0 to len(c)."""
+    n = int(c.numel())
+    if n == 0:
+        return np.zeros(world + 1, np.int64)
+    wh = w_heavy if w_heavy is not None else torch.zeros((), dtype=torch.float64, device=c.device)
+    first = torch.minimum(((c[-1] + wh) / world - wh).clamp(min=0.0), c[-1])
+    tgt = first + (c[-1] - first) / max(world - 1, 1) * torch.arange(0, world - 1, dtype=torch.float64, device=c.device)
+    cuts = [0] + torch.searchsorted(c, tgt).clamp(max=n).tolist() + [n]
+    return np.maximum.accumulate(np.asarray(cuts, np.int64))
+
+
 class Comm(object):
     """Thin wrapper over torch.distributed that stages through the host for gloo."""
 
@@ -104,13 +118,8 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             if L.n_light:
                 n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
                 c = torch.cumsum(n_i[L.uq_item[:L.n_light].long()].double(), 0)
-                # rank 0 also computes the heavy rows (their chunk partials are merged per row, so they stay together):
-                # their rater visits count against its share of the light units
-                w_heavy = n_i[L.hlist[:L.n_heavy].long()].sum().double() if L.n_heavy else torch.zeros((), dtype=torch.float64, device=dev)
-                first = torch.minimum(((c[-1] + w_heavy) / world - w_heavy).clamp(min=0.0), c[-1])
-                tgt = first + (c[-1] - first) / max(world - 1, 1) * torch.arange(0, world - 1, dtype=torch.float64, device=dev)
-                cuts = [0] + torch.searchsorted(c, tgt).clamp(max=L.n_light).tolist() + [L.n_light]
-                cuts = np.maximum.accumulate(np.asarray(cuts, np.int64))
+                w_heavy = n_i[L.hlist[:L.n_heavy].long()].sum().double() if L.n_heavy else None
+                cuts = unit_cuts(c, w_heavy, world)
                 lo, hi = int(cuts[rank]), int(cuts[rank + 1])
             coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
                                                              do_heavy=(rank == 0), retry=False)
