@@ -303,6 +303,38 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
                        const int32_t *nb_id, const int32_t *nb_list, int32_t n_nb, const void *midX, const void *dir,
                        const int64_t *dir_ptr, const int32_t *ng);
 
+/* ---- extension, column form (default) ----------------------------------------------------------------------------
+ * Same work units and results as xmap_extend_paths2 (units = starts, heavy starts cut into unit_G chunks with dedicated
+ * rows), rebuilt around what bounds it: a column (start, x) is ONE set of lanes -- W ends x S record
+ * slices, S = 4 / 2 / 1 by the column's width -- and one row update; rows are indexed by the rank of the end among
+ * the n_ends items that can end a path at all (xmap_end_universe: urank[item] / uitem[rank]) instead of by item; the
+ * ends of a column come from one table of 32-byte records; sums are (value, error) pairs folded at the end.
+ * Scratch (zero-filled by the caller once, returned zeroed): acc [n_slots][n_ends][4] doubles, touched
+ * [n_slots][n_ends], hacc [rows][n_ends][4], htouched [rows][n_ends].  fast_div: every edge has a positive mutuality
+ * and |sim * mutu| within 2^+-400 (what stage A produces), so the division of a path is the bare
+ * reciprocal-refinement sequence.  Results as xmap_extend_paths (same exact sums). */
+typedef struct xmap_ext_tables {
+    int32_t n_items, top_k;
+    const uint8_t *cls; const int32_t *kcnt; const int32_t *kcol; const double *kval; const uint8_t *flags;
+    const int64_t *att_ptr; const int32_t *att_idx; const double *att_val;
+    const int64_t *src_ptr; const int32_t *src_idx; const double *src_val; const uint8_t *src_flag;
+    const int64_t *rnn_ptr; const int32_t *rnn_idx; const double *rnn_val;
+    int32_t n_nb; const int32_t *nb_id; const int32_t *nb_list; const void *midX; const void *dir; const int64_t *dir_ptr;
+    int32_t n_ends; const int32_t *urank; const int32_t *uitem;
+} xmap_ext_tables;
+typedef struct xmap_path_units {
+    int32_t n_units; const int32_t *unit_start; const int32_t *unit_c; const int32_t *unit_G; const int32_t *unit_row;
+    int32_t *unit_nt; int32_t n_heavy; const int32_t *heavy_unit0;
+} xmap_path_units;
+typedef struct xmap_path_rows { int32_t n_slots; double *acc; int32_t *touched; double *hacc; int32_t *htouched; } xmap_path_rows;
+typedef struct xmap_path_out {
+    int32_t *n_cand; int32_t *top_end; double *top_val; int64_t xs_cap; int64_t *xs_off; int32_t *xs_end; double *xs_val;
+} xmap_path_out;
+int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I] scratch*/, int64_t *rank /*[I+1] scratch*/,
+                      int32_t *urank /*[I]*/, int32_t *uitem /*[I]*/, int64_t *h_n_ends);
+int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *U, const xmap_path_rows *R,
+                      const xmap_path_out *O, int fast_div, int64_t *d_counters, int64_t *h_counters);
+
 /* Candidate arrays from explicit X-Sim lists (an extended_simRDD that did not come from this engine,
  * e.g. a canonically re-fed one): CSR (xs_ptr, xs_end, xs_val) -> n_cand, top_end, top_val as above. */
 int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end,

@@ -300,6 +300,7 @@ def test_determinism_and_partitions(dev):
     E2 = eng.extend(S, 5, full=True, chunk=64, n_slots=64)
     E3 = eng.extend(S, 5, full=True, algo="mid")               # middle lists + register-tile accumulation
     E4 = eng.extend(S, 5, full=True, algo="mid", chunk=64)
+    E6 = eng.extend(S, 5, full=True, algo="enum")              # one accumulate per path
     os.environ["XMAP_MID_TABLE"] = "1"                        # middle lists through the dense tile table (n_nb > 40 000 form)
     try:
         E5 = eng.extend(S, 5, full=True, algo="mid")
@@ -307,7 +308,7 @@ def test_determinism_and_partitions(dev):
         del os.environ["XMAP_MID_TABLE"]
     assert E5.mid.n_records == E3.mid.n_records and E5.mid.n_tiles == E3.mid.n_tiles
     assert np.array_equal(E5.mid.dir.view(-1, 3)[:, 0].cpu().numpy(), E3.mid.dir.view(-1, 3)[:, 0].cpu().numpy())   # (x, ne) per tile
-    for Ex in (E3, E4, E5):
+    for Ex in (E3, E4, E5, E6):
         assert Ex.n_paths == E1.n_paths and Ex.n_out == E1.n_out
         for x, y in zip(_xsim_lists(E1, r.n_items), _xsim_lists(Ex, r.n_items)):
             assert np.array_equal(x, y)

@@ -457,6 +457,9 @@ struct PathArgs {
     int *n_cand; int *top_end; double *top_val;
     long long xs_cap; long long *xs_off; int *xs_end; double *xs_val;
     unsigned long long *counters;  // [0] total candidates, [1] paths, [2] work cursor, [3] xs cursor
+    // rows of k_paths4 are indexed by the rank of an item among the items that can end a path (U of them) instead of by
+    // the item: uitem[rank] = item, urank[item] = rank.  The older kernels leave these NULL / U = I.
+    int U; const int *urank; const int *uitem;
 };
 
 struct Carry { double sm, mu, c; };  // sum sim*mutu, sum mutu, prod frac_mutu along the path so far
@@ -493,7 +496,8 @@ struct WaveAcc {
 
 // tails of one (t,s) after edge (t,s): end s is accumulated by the caller (vector step over s);
 // here: for x in attach(s): end x, then end y for y in NN(x)         (extender.py:134-138 / :154-158)
-__device__ __forceinline__ void tails(const PathArgs &A, WaveAcc &W, int s, Carry c_ts) {
+template <class ACC>
+__device__ __forceinline__ void tails(const PathArgs &A, ACC &W, int s, Carry c_ts) {
     const int lane = lane_id();
     const int k = A.k;
     long long a0 = A.att_ptr[s], a1 = A.att_ptr[s + 1];
@@ -517,7 +521,8 @@ __device__ __forceinline__ void tails(const PathArgs &A, WaveAcc &W, int s, Carr
 }
 
 // all (t,s) of src(t) behind a given head carry (head_len = number of edges in front of (t,s))
-__device__ __forceinline__ void through_t(const PathArgs &A, WaveAcc &W, int t, bool has_head, Carry head) {
+template <class ACC>
+__device__ __forceinline__ void through_t(const PathArgs &A, ACC &W, int t, bool has_head, Carry head) {
     const int lane = lane_id();
     long long s0 = A.src_ptr[t], s1 = A.src_ptr[t + 1];
     for (long long base = s0; base < s1; base += 64) {
@@ -627,7 +632,7 @@ __device__ __forceinline__ int fin_cut(FinBuf &F, int nbuf, int *out_e, double *
 // One wave's share of the pass: candidates b = 64 (w + j NW) + lane.  Leaves the best ns of them, in order, in
 // F.oe / F.ov and returns ns.
 __device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt,
-                                              unsigned long long off, bool full, int w, int NW) {
+                                              unsigned long long off, bool full, int w, int NW, int gs = 1, int mem = 0) {
     const int lane = lane_id();
     volatile double *bv = F.v;
     volatile int *be = F.e;
@@ -641,8 +646,9 @@ __device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, doub
         unsigned long long key = 0;
         if (act) {
             e = touched[b];
-            double *a = acc + (size_t)e * 4;
-            v = 1.0 * a[0] / a[2];
+            double *a = acc + ((size_t)e * gs + mem) * 4;
+            if (A.uitem) e = A.uitem[e];
+            v = 1.0 * (a[0] + a[1]) / (a[2] + a[3]);     // pairs of k_paths4 are not renormalised; a renormalised pair is its own sum
             a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
             key = xsim_key(v);
             if (full) { A.xs_end[off + b] = e; A.xs_val[off + b] = v; }
@@ -664,12 +670,13 @@ __device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, doub
     return fin_cut(F, nbuf, F.oe, F.ov);
 }
 
-__device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt, int start) {
+__device__ __forceinline__ int finalize_start(const PathArgs &A, FinBuf &F, double *acc, const int *touched, int nt, int start,
+                                              int gs = 1, int mem = 0) {
     const int lane = lane_id();
     if (lane == 0) A.n_cand[start] = nt;
     unsigned long long off;
     const bool full = fin_list_offset(A, nt, start, off);
-    const int ns = finalize_slice(A, F, acc, touched, nt, off, full, 0, 1);
+    const int ns = finalize_slice(A, F, acc, touched, nt, off, full, 0, 1, gs, mem);
     if (lane < ns) {
         A.top_end[(size_t)start * XMAP_TOPC + lane] = ((volatile int *)F.oe)[lane];
         A.top_val[(size_t)start * XMAP_TOPC + lane] = ((volatile double *)F.ov)[lane];
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A) {
 // path.  The edge products sim*mutu and the fractions are stored per edge, so a path's (sum sim*mutu, sum
 // mutu, prod frac) is rebuilt in the reference's left-to-right order, bit for bit.
 struct MidX { double sm2, sm3, sm4, f2, f3, f4, mu; int xid; int pad; };   // 64 B; xid = index of x in nb_list
-struct MidDir { int x; int ne; int cnt; int pad; long long off; };          // one tile of x': item x, 1+|NN(x)| ends, records [off, off+cnt)
+struct MidDir { int x; int ne; int cnt; int pad; long long off; };          // one tile of x': item x, 1+|NN(x)| ends, records [off, off+cnt); pad = index of x in nb_list
 
 struct MidArgs {
     int I, k;
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int *
         bins[i] = off;                                  // placement cursor of the tile
         if (c) {
             MidDir d;
-            d.x = A.nb_list[i]; d.ne = 1 + A.kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = 0; d.off = rbase + off;
+            d.x = A.nb_list[i]; d.ne = 1 + A.kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = i; d.off = rbase + off;
             dir[dbase + rank] = d;
             rank++;
             off += c;
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, 
         const unsigned long long m = __ballot(c > 0);
         if (FILL && c > 0) {
             MidDir d;
-            d.x = nb_list[xid]; d.ne = 1 + kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = 0; d.off = tile_off[row + xid];
+            d.x = nb_list[xid]; d.ne = 1 + kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = xid; d.off = tile_off[row + xid];
             dir[out + __popcll(m & lanemask_lt())] = d;
         }
         out += __popcll(m);
@@ -926,8 +933,10 @@ __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, 
     if (!FILL && lane == 0) ng[xpid] = total;
 }
 
+struct ColEnd { double sm, mu, f; int u; int pad; };     // one end of a column x: last edge (sim * mutu, mutu, frac; 0, 0, 1 for x itself), universe rank
 struct Path2Args {
     PathArgs P;
+    const ColEnd *cend;            // k_paths4: [n_nb][k + 1]
     const int *nb_id; const int *nb_list; int n_nb;
     const MidX *midX; const MidDir *dir; const long long *dir_ptr; const int *ng;
 };
@@ -949,7 +958,8 @@ __device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, doub
 }
 
 // paths [start -] x' - t - s of one head (end s): lanes over the joint (t,s) of each t in NB_BB(x')
-__device__ __forceinline__ void head_S(const PathArgs &A, WaveAcc &W, int xp, bool has_e1, Carry e1) {
+template <class ACC>
+__device__ __forceinline__ void head_S(const PathArgs &A, ACC &W, int xp, bool has_e1, Carry e1) {
     const int lane = lane_id();
     const int nb = A.kcnt[(size_t)xp * 2];
     for (int q = 0; q < nb; q++) {
@@ -1161,6 +1171,348 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
     }
 }
 
+// ---- helpers of k_paths4 -------------------------------------------------------------------------------------
+// a / b rounded to nearest for b > 0 and operands far from the ends of the exponent range: v_rcp_f64 + two Newton steps
+// + one correction of the quotient, i.e. the sequence the compiler emits for `/` without v_div_scale / v_div_fmas'
+// rescaling / v_div_fixup (which only act on operands near the ends of the range, zero, inf or nan)
+__device__ __forceinline__ double div_mid(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// two-sum, rounding errors collected in lo (not renormalised: hi + lo is the sum to ~2^-104 like dd_add's pair)
+__device__ __forceinline__ void acc2(double &hi, double &lo, double x) {
+    const double s = hi + x;
+    const double bb = s - hi;
+    lo += (hi - (s - bb)) + (x - bb);
+    hi = s;
+}
+
+// exchange inside a group of four adjacent lanes (DPP quad_perm: no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+
+// =============================================================================================
+// k_paths4 (default).  What the ablations of k_paths2 / k_paths3 at BASELINE configs[1] say (profiles/README.md, round 2):
+// a column (start, x) costs a fixed price -- merge step, end list, row update, bookkeeping -- that outweighs its
+// arithmetic (10 records x 22 ends on average), and the row updates are random 32-byte read-modify-writes.  Hence:
+//   * ONE row update per column: the lanes of a step are  W ends x S record slices  with S = 4 / 2 / 1 for a column of
+//     <= 16 / <= 32 / more ends, so every column is a single set of lanes whatever its width; the S slices of an end
+//     are adjacent lanes and are added up by one or two DPP exchanges;
+//   * rows are indexed by the rank of the end among the U items that can end a path at all (xmap_end_universe; ranks
+//     in column order, so that the ends of a column are neighbours in the row): 2.7x shorter rows, 5x less scratch;
+//   * the ends of a column come from one table of 32-byte records (k_col_ends: rank and last edge), not from three
+//     dependent gathers; the row entries are requested before the records are reduced;
+//   * prepared records of all participating heads are staged in LDS (128 per round); division and sums as in k_paths3.
+constexpr int Q_CAP = 128;                 // prepared records per round
+struct QLds {
+    double bsm[Q_CAP], bc[Q_CAP], bmu[Q_CAP];
+    double e_sm[64], e_mu[64], e_f[64];
+    int e_u[64];                           // universe rank of the end, -1 = none
+};
+
+struct QAcc {
+    double *acc; int *touched;             // the unit's row [U][4] and touched list [U]
+    const int *urank;
+    int nt;
+    unsigned long long paths;
+    __device__ __forceinline__ void add(bool active, int end, Carry p) {
+        bool first = false;
+        int u = 0;
+        if (active) {
+            u = urank[end];
+            const double sp = (p.mu != 0.0) ? 1.0 * p.sm / p.mu : 0.0;   // calculate_path_confidence (extender.py:83-89)
+            double *a = acc + (size_t)u * 4;
+            double s_hi = a[0], s_lo = a[1], c_hi = a[2], c_lo = a[3];
+            first = (c_hi == 0.0);
+            acc2(s_hi, s_lo, sp * p.c);
+            acc2(c_hi, c_lo, p.c);
+            a[0] = s_hi; a[1] = s_lo; a[2] = c_hi; a[3] = c_lo;
+        }
+        const unsigned long long m = __ballot(first);
+        if (first) touched[nt + __popcll(m & lanemask_lt())] = u;
+        nt += __popcll(m);
+        paths += __popcll(__ballot(active));
+    }
+};
+
+template <bool FASTDIV>
+__device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi) {
+    __shared__ QLds stageq[4];          // one per wave of the block; DS operations of a wave execute in order
+    const PathArgs &A = B.P;
+    QLds &L = stageq[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int k = A.k;
+    const int INF = 0x7fffffff;
+    // this lane's head
+    const long long h = h0 + lane;
+    const bool hv = h < nH;
+    double sm1 = 0.0, mu1 = 0.0, f1 = 1.0;
+    bool has_e1 = false;
+    long long dpos = 0, dend = 0;
+    if (hv) {
+        int xp = start;
+        if (h >= self) {
+            const long long rp = A.rnn_ptr[start] + (h - self);
+            xp = A.rnn_idx[rp];
+            const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1];
+            sm1 = sv * mu; mu1 = mu; f1 = A.rnn_val[rp * 3 + 2];
+            has_e1 = true;
+        }
+        const int xpid = B.nb_id[xp];
+        dpos = B.dir_ptr[xpid];
+        dend = B.dir_ptr[xpid + 1];
+        if (xlo > 0) {   // lower bound of xlo in this head's directory (sorted by x)
+            long long lo = dpos, hi = dend;
+            while (lo < hi) {
+                long long mid = (lo + hi) >> 1;
+                if (B.dir[mid].x < xlo) lo = mid + 1; else hi = mid;
+            }
+            dpos = lo;
+        }
+    }
+    MidDir cur;
+    cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
+    if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+    for (;;) {
+        int xmin = cur.x;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(xmin, m, 64); xmin = o < xmin ? o : xmin; }
+        if (xmin == INF) break;
+        const bool mine = cur.x == xmin;
+        const unsigned long long part = __ballot(mine);
+        const int first_l = __ffsll((long long)part) - 1;
+        const int ne = rl32(cur.ne, first_l);
+        const ColEnd *ce = B.cend + (size_t)rl32(cur.pad, first_l) * (k + 1);
+        for (int b = 0; b < ne; b += 64) {
+            const int nact = (ne - b) < 64 ? (ne - b) : 64;
+            const int sh = nact <= 16 ? 2 : (nact <= 32 ? 1 : 0);     // log2 of the record slices per end
+            const int ns = 1 << sh;
+            const int q = lane >> sh, slice = lane & (ns - 1);
+            {   // the block's ends (one 32-byte record each, prepared by k_col_ends), natural layout -> LDS
+                const int idx = b + lane;
+                ColEnd e;
+                e.sm = 0.0; e.mu = 0.0; e.f = 1.0; e.u = -1; e.pad = 0;
+                if (idx < ne) e = ce[idx];
+                L.e_u[lane] = e.u; L.e_sm[lane] = e.sm; L.e_mu[lane] = e.mu; L.e_f[lane] = e.f;
+                asm volatile("" ::: "memory");
+            }
+            const int eu = L.e_u[q];
+            const bool ok = eu >= 0;
+            const double sm5 = L.e_sm[q], mu5 = L.e_mu[q], f5 = L.e_f[q];
+            unsigned long long pm = part;
+            int pos = 0;                      // records of the current head already staged
+            while (pm) {
+                int fill = 0;
+                while (pm && fill < Q_CAP) {
+                    const int l = __ffsll((long long)pm) - 1;
+                    const int cnt = rl32(cur.cnt, l);
+                    const long long off = rl64(cur.off, l);
+                    const bool he1 = rl32((int)has_e1, l) != 0;
+                    const double hsm1 = rld(sm1, l), hmu1 = rld(mu1, l), hf1 = rld(f1, l);
+                    int n = cnt - pos;
+                    if (n > Q_CAP - fill) n = Q_CAP - fill;
+                    if (n > 64) n = 64;
+                    if (lane < n) {
+                        const MidX m = B.midX[off + pos + lane];
+                        double bsm, bc;
+                        if (he1) { bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4; bc = ((hf1 * m.f2) * m.f3) * m.f4; }
+                        else { bsm = (m.sm2 + m.sm3) + m.sm4; bc = (m.f2 * m.f3) * m.f4; }
+                        L.bsm[fill + lane] = bsm; L.bc[fill + lane] = bc; L.bmu[fill + lane] = m.mu + (he1 ? hmu1 : 0.0);
+                    }
+                    fill += n; pos += n;
+                    if (pos == cnt) { pm &= pm - 1; pos = 0; }
+                }
+                asm volatile("" ::: "memory");
+                // one round (a column with more than Q_CAP records, < 1 % of them, updates its row once per round).
+                // The row entry is requested before the records are reduced: its round trip runs under the loop.
+                const bool fl_ = ok && slice == 0;
+                double *a = W.acc + (size_t)(ok ? eu : 0) * 4;
+                double h0_ = 0.0, l0_ = 0.0, h1_ = 0.0, l1_ = 0.0;
+#ifndef Q_NOFLUSH
+                if (fl_) { h0_ = a[0]; l0_ = a[1]; h1_ = a[2]; l1_ = a[3]; }
+#endif
+                double a_sh = 0.0, a_sl = 0.0, a_ch = 0.0, a_cl = 0.0;
+                const int steps = (fill + ns - 1) >> sh;
+#ifdef Q_NOCOMPUTE
+                if (ok && slice < fill) { a_sh = 1.0; a_ch = 1.0; }
+                for (int it = 0; it < 0; it++) {
+#else
+                for (int it = 0; it < steps; it++) {
+#endif
+                    const int r = (it << sh) + slice;
+                    if (ok && r < fill) {
+                        const double sm = L.bsm[r] + sm5;
+                        const double c = L.bc[r] * f5;
+                        const double mu = L.bmu[r] + mu5;
+                        double sp;
+                        if (FASTDIV) sp = div_mid(sm, mu);
+                        else sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;      // calculate_path_confidence (extender.py:83-89)
+                        acc2(a_sh, a_sl, sp * c);
+                        acc2(a_ch, a_cl, c);
+                    }
+                }
+                // the slices of an end sit in adjacent lanes
+                if (sh >= 1) {
+                    const double o_sh = quad_swap<0xB1>(a_sh), o_sl = quad_swap<0xB1>(a_sl);      // lane ^ 1
+                    const double o_ch = quad_swap<0xB1>(a_ch), o_cl = quad_swap<0xB1>(a_cl);
+                    acc2(a_sh, a_sl, o_sh); a_sl += o_sl;
+                    acc2(a_ch, a_cl, o_ch); a_cl += o_cl;
+                }
+                if (sh == 2) {
+                    const double o_sh = quad_swap<0x4E>(a_sh), o_sl = quad_swap<0x4E>(a_sl);      // lane ^ 2
+                    const double o_ch = quad_swap<0x4E>(a_ch), o_cl = quad_swap<0x4E>(a_cl);
+                    acc2(a_sh, a_sl, o_sh); a_sl += o_sl;
+                    acc2(a_ch, a_cl, o_ch); a_cl += o_cl;
+                }
+                asm volatile("" ::: "memory");
+                bool first = false;
+#ifdef Q_NOFLUSH
+                if (fl_ && a_sh == 1.2345e300 && a_cl == 7.7e-300) W.acc[0] = a_sh + a_sl + a_ch + a_cl;
+#else
+                if (fl_) {
+                    first = (h1_ == 0.0);
+                    acc2(h0_, l0_, a_sh); l0_ += a_sl;
+                    acc2(h1_, l1_, a_ch); l1_ += a_cl;
+                    a[0] = h0_; a[1] = l0_; a[2] = h1_; a[3] = l1_;
+                }
+#endif
+                const unsigned long long fm = __ballot(first);
+                if (first) W.touched[W.nt + __popcll(fm & lanemask_lt())] = eu;
+                W.nt += __popcll(fm);
+                W.paths += (unsigned long long)fill * (unsigned long long)nact;
+            }
+        }
+        if (mine) {    // advance the heads that took part
+            dpos++;
+            cur.x = INF;
+            if (dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+        }
+    }
+}
+
+template <bool FASTDIV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_WAVES))) void k_paths4(Path2Args B) {
+    __shared__ FinBuf fin[4];
+    const PathArgs &A = B.P;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.n_slots) return;
+    const int lane = lane_id();
+    QAcc W;
+    W.paths = 0; W.urank = A.urank;
+    unsigned long long cand_total = 0;
+    for (;;) {
+        int u_ = 0;
+        if (lane == 0) u_ = (int)atomicAdd(&A.counters[2], 1ull);
+        const int unit = uniform(u_);
+        if (unit >= A.n_units) break;  // every wave reaches this exit: the cursor only grows
+        const int start = uniform(A.unit_start[unit]);
+        const int c = uniform(A.unit_c[unit]);
+        const int G = uniform(A.unit_G[unit]);
+        const int row = uniform(A.unit_row[unit]);
+        if (row < 0) {
+            W.acc = A.acc + (size_t)slot * A.U * 4;
+            W.touched = A.touched + (size_t)slot * A.U;
+        } else {
+            W.acc = A.hacc + (size_t)row * A.U * 4;
+            W.touched = A.htouched + (size_t)row * A.U;
+        }
+        W.nt = 0;
+        int ent = 0;  // work entries of a start: role T; per head its (t,s) part; per (64-head batch, column range) the tiles
+        if (A.flags[start] & 2) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
+            if (G == 1 || ent % G == c) {
+                Carry none; none.sm = 0; none.mu = 0; none.c = 0;
+                through_t(A, W, start, false, none);
+            }
+            ent++;
+        }
+        const long long r0 = uniform((int)A.rnn_ptr[start]), r1 = uniform((int)A.rnn_ptr[start + 1]);
+        const int self = (A.cls[start] == 2) ? 1 : 0;   // head 0 = the start itself (target_path, extender.py:160-163)
+        const long long nH = self + (r1 - r0);          // heads >= self: start in NN(x') (longest_path, :164-167)
+        for (long long h = 0; h < nH; h++) {
+            if (G == 1 || ent % G == c) {
+                const bool has_e1 = h >= self;
+                const int xp = has_e1 ? A.rnn_idx[r0 + h - self] : start;
+                Carry e1; e1.sm = 0; e1.mu = 0; e1.c = 1.0;
+                if (has_e1) e1 = first_edge(A.rnn_val[(r0 + h - self) * 3], A.rnn_val[(r0 + h - self) * 3 + 1],
+                                            A.rnn_val[(r0 + h - self) * 3 + 2]);
+                head_S(A, W, xp, has_e1, e1);
+            }
+            ent++;
+        }
+        const long long nbatch = (nH + 63) / 64;
+        const int RX = (nbatch > 0) ? (int)((G + nbatch - 1) / nbatch) : 1;   // column ranges: nbatch * RX >= G entries
+        const int n_nb = B.n_nb;
+        for (long long bt = 0; bt < nbatch; bt++)
+            for (int rx = 0; rx < RX; rx++) {
+                if (G == 1 || ent % G == c) {
+                    const int xlo = (rx == 0) ? 0 : B.nb_list[(long long)rx * n_nb / RX];
+                    const int xhi = (rx == RX - 1) ? 0x7fffffff : B.nb_list[(long long)(rx + 1) * n_nb / RX];
+                    heads_Q<FASTDIV>(B, W, start, bt * 64, nH, self, xlo, xhi);
+                }
+                ent++;
+            }
+        if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
+        else if (lane == 0) A.unit_nt[unit] = W.nt;
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], cand_total);
+        atomicAdd(&A.counters[1], W.paths);
+    }
+}
+
+// the ends of every column x (non-bridge record): x itself, then NN(x) in list order, as 32-byte records
+__global__ __launch_bounds__(256) void k_col_ends(int n_nb, int k, const int *nb_list, const int *kcnt, const int *kcol, const double *kval,
+                                                  const int *urank, ColEnd *cend) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_nb * (k + 1)) return;
+    const int xid = (int)(t / (k + 1)), idx = (int)(t % (k + 1));
+    const int x = nb_list[xid];
+    ColEnd e;
+    e.sm = 0.0; e.mu = 0.0; e.f = 1.0; e.u = -1; e.pad = 0;
+    if (idx == 0) e.u = urank[x];
+    else if (idx - 1 < kcnt[(size_t)x * 2 + 1]) {
+        const size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
+        const double v = kval[o * 3], m = kval[o * 3 + 1];
+        e.sm = v * m; e.mu = m; e.f = kval[o * 3 + 2]; e.u = urank[kcol[o]];
+    }
+    cend[t] = e;
+}
+
+// items that can end a path: the s of every src record, the x of every attach record, x and NN(x) of every non-bridge record
+__global__ __launch_bounds__(256) void k_mark_ends(int I, int k, const uint8_t *cls, const int *kcnt, const int *kcol, long long n_src,
+                                                   const int *src_idx, long long n_att, const int *att_idx, int *mark) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_src) mark[src_idx[t]] = 1;
+    if (t < n_att) mark[att_idx[t]] = 1;
+    if (t < (long long)I * k) {
+        const int x = (int)(t / k), q = (int)(t % k);
+        if (cls[x] == 2) {
+            if (q == 0) mark[x] = 1;
+            if (q < kcnt[(size_t)x * 2 + 1]) mark[kcol[((size_t)x * 2 + 1) * k + q]] = 1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_end_ranks(int I, const int *mark, const long long *rank64, int *urank, int *uitem) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    const int r = (int)rank64[i];
+    urank[i] = mark[i] ? r : -1;
+    if (mark[i]) uitem[r] = i;
+}
+
 // heavy starts: add the G partial rows into the first one (double-double merge), then finalise.  One block of
 // MERGE_WAVES waves per job: the touched entries of a partial row are distinct, so the waves take 64 of them at a
 // time side by side (a single wave per start had left a chain of G - 1 serial merges: 68 ms at BASELINE configs[1]);
@@ -1209,8 +1561,8 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void k_merge_groups(PathArgs A, i
         if (threadIdx.x == 0) s_nt = A.unit_nt[u0 + b];
         __syncthreads();
         for (int c = b + 1; c < e; c++)
-            merge_row(A.hacc + (size_t)(r0 + b) * A.I * 4, A.htouched + (size_t)(r0 + b) * A.I, &s_nt,
-                      A.hacc + (size_t)(r0 + c) * A.I * 4, A.htouched + (size_t)(r0 + c) * A.I, A.unit_nt[u0 + c]);
+            merge_row(A.hacc + (size_t)(r0 + b) * A.U * 4, A.htouched + (size_t)(r0 + b) * A.U, &s_nt,
+                      A.hacc + (size_t)(r0 + c) * A.U * 4, A.htouched + (size_t)(r0 + c) * A.U, A.unit_nt[u0 + c]);
         if (threadIdx.x == 0) A.unit_nt[u0 + b] = s_nt;
         __syncthreads();
     }
@@ -1225,13 +1577,13 @@ __global__ __launch_bounds__(64 * MERGE_WAVES) void k_merge(PathArgs A, int n_he
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int u0 = heavy_unit0[h];
     const int start = A.unit_start[u0], G = A.unit_G[u0], r0 = A.unit_row[u0];
-    double *acc0 = A.hacc + (size_t)r0 * A.I * 4;
-    int *touched0 = A.htouched + (size_t)r0 * A.I;
+    double *acc0 = A.hacc + (size_t)r0 * A.U * 4;
+    int *touched0 = A.htouched + (size_t)r0 * A.U;
     if (threadIdx.x == 0) s_nt = A.unit_nt[u0];
     __syncthreads();
     const int stride = G > MERGE_GROUP ? MERGE_GROUP : 1;     // group heads (k_merge_groups ran) or all rows
     for (int c = stride; c < G; c += stride)
-        merge_row(acc0, touched0, &s_nt, A.hacc + (size_t)(r0 + c) * A.I * 4, A.htouched + (size_t)(r0 + c) * A.I,
+        merge_row(acc0, touched0, &s_nt, A.hacc + (size_t)(r0 + c) * A.U * 4, A.htouched + (size_t)(r0 + c) * A.U,
                   A.unit_nt[u0 + c]);
     const int nt = s_nt;
     if (w == 0) {
@@ -1469,6 +1821,7 @@ static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items
         A.n_cand = n_cand; A.top_end = top_end; A.top_val = top_val;
         A.xs_cap = xs_cap; A.xs_off = (long long *)xs_off; A.xs_end = xs_end; A.xs_val = xs_val;
         A.counters = (unsigned long long *)d_counters;
+        A.U = n_items; A.urank = nullptr; A.uitem = nullptr;
         int slots = n_slots < n_units ? n_slots : n_units;
         A.n_slots = slots;
         if (mid) {
@@ -1630,6 +1983,95 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
     const long long waves = (long long)n_nb * top_k;
     k_mid_build<true><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
     XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I] scratch*/, int64_t *rank /*[I+1] scratch*/,
+                      int32_t *urank /*[I]*/, int32_t *uitem /*[I]*/, int64_t *h_n_ends) {
+    XM_ARG(T && mark && rank && urank && uitem && h_n_ends);
+    const int I = T->n_items, k = T->top_k;
+    *h_n_ends = 0;
+    if (I == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    long long h_n[2];
+    XM_HIP(hipMemcpyAsync(&h_n[0], T->src_ptr + I, sizeof(long long), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipMemcpyAsync(&h_n[1], T->att_ptr + I, sizeof(long long), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipMemsetAsync(mark, 0, sizeof(int32_t) * (size_t)I, st));
+    XM_HIP(hipStreamSynchronize(st));
+    long long n = (long long)I * k;
+    if (h_n[0] > n) n = h_n[0];
+    if (h_n[1] > n) n = h_n[1];
+    k_mark_ends<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(I, k, T->cls, T->kcnt, T->kcol, h_n[0], T->src_idx, h_n[1],
+                                                                          T->att_idx, mark);
+    XM_LAUNCH_CHECK();
+    int rc = xmap_exclusive_scan_i32_to_i64(stream, mark, rank, I, h_n_ends);
+    if (rc) return rc;
+    k_end_ranks<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, mark, (const long long *)rank, urank, uitem);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *Un, const xmap_path_rows *R,
+                      const xmap_path_out *O, int fast_div, int64_t *d_counters, int64_t *h_counters) {
+    XM_ARG(T && Un && R && O && d_counters);
+    XM_ARG(T->cls && T->kcnt && T->kcol && T->kval && T->flags && T->att_ptr && T->src_ptr && T->rnn_ptr);
+    XM_ARG(T->n_ends >= 0 && (T->n_items == 0 || (T->urank && T->uitem)));
+    XM_ARG(R->n_slots > 0 && R->acc && R->touched && O->n_cand && O->top_end && O->top_val);
+    XM_ARG(Un->n_units >= 0 && Un->n_heavy >= 0);
+    XM_ARG(Un->n_units == 0 || (Un->unit_start && Un->unit_c && Un->unit_G && Un->unit_row && Un->unit_nt));
+    XM_ARG(Un->n_units == 0 || T->n_nb == 0 || (T->nb_id && T->nb_list && T->midX && T->dir && T->dir_ptr));
+    XM_ARG(Un->n_heavy == 0 || (Un->heavy_unit0 && R->hacc && R->htouched));
+    XM_ARG(O->xs_cap == 0 || (O->xs_off && O->xs_end && O->xs_val));
+    hipStream_t st = (hipStream_t)stream;
+    XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+    if (Un->n_units > 0) {
+        Path2Args B;
+        memset(&B, 0, sizeof(B));
+        PathArgs &A = B.P;
+        A.I = T->n_items; A.k = T->top_k;
+        A.cls = T->cls; A.kcnt = T->kcnt; A.kcol = T->kcol; A.kval = T->kval; A.flags = T->flags;
+        A.att_ptr = (const long long *)T->att_ptr; A.att_idx = T->att_idx; A.att_val = T->att_val;
+        A.src_ptr = (const long long *)T->src_ptr; A.src_idx = T->src_idx; A.src_val = T->src_val; A.src_flag = T->src_flag;
+        A.rnn_ptr = (const long long *)T->rnn_ptr; A.rnn_idx = T->rnn_idx; A.rnn_val = T->rnn_val;
+        A.n_units = Un->n_units; A.unit_start = Un->unit_start; A.unit_c = Un->unit_c; A.unit_G = Un->unit_G;
+        A.unit_row = Un->unit_row; A.unit_nt = Un->unit_nt;
+        A.acc = R->acc; A.touched = R->touched; A.hacc = R->hacc; A.htouched = R->htouched;
+        A.n_cand = O->n_cand; A.top_end = O->top_end; A.top_val = O->top_val;
+        A.xs_cap = O->xs_cap; A.xs_off = (long long *)O->xs_off; A.xs_end = O->xs_end; A.xs_val = O->xs_val;
+        A.counters = (unsigned long long *)d_counters;
+        A.U = T->n_ends; A.urank = T->urank; A.uitem = T->uitem;
+        A.n_slots = R->n_slots < Un->n_units ? R->n_slots : Un->n_units;
+        B.nb_id = T->nb_id; B.nb_list = T->nb_list; B.n_nb = T->n_nb; B.midX = (const MidX *)T->midX; B.dir = (const MidDir *)T->dir;
+        B.dir_ptr = (const long long *)T->dir_ptr; B.ng = nullptr;
+        ColEnd *cend = nullptr;
+        if (T->n_nb > 0) {
+            const long long n = (long long)T->n_nb * (T->top_k + 1);
+            XM_HIP(hipMallocAsync((void **)&cend, sizeof(ColEnd) * (size_t)n, st));
+            k_col_ends<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(T->n_nb, T->top_k, T->nb_list, T->kcnt, T->kcol, T->kval,
+                                                                                 T->urank, cend);
+            XM_LAUNCH_CHECK();
+        }
+        B.cend = cend;
+        const dim3 grid((unsigned)((A.n_slots + 3) / 4)), block(256);
+        if (fast_div) k_paths4<true><<<grid, block, 0, st>>>(B);
+        else k_paths4<false><<<grid, block, 0, st>>>(B);
+        XM_LAUNCH_CHECK();
+        if (cend) XM_HIP(hipFreeAsync(cend, st));
+        if (Un->n_heavy > 0) {
+            k_merge_groups<<<dim3((unsigned)Un->n_heavy, 16), dim3(64 * MERGE_WAVES), 0, st>>>(A, Un->n_heavy, Un->heavy_unit0);
+            XM_LAUNCH_CHECK();
+            k_merge<<<dim3((unsigned)Un->n_heavy), dim3(64 * MERGE_WAVES), 0, st>>>(A, Un->n_heavy, Un->heavy_unit0);
+            XM_LAUNCH_CHECK();
+        }
+    }
+    if (h_counters) {
+        XM_HIP(hipMemcpyAsync(h_counters, d_counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        XM_HIP(hipStreamSynchronize(st));
+        if (O->xs_cap > 0 && h_counters[0] > O->xs_cap) {
+            set_error("candidate buffer too small: need %lld entries, have %lld", (long long)h_counters[0], (long long)O->xs_cap);
+            return XMAP_ERR_CAPACITY;
+        }
+    }
     return XMAP_OK;
 }
 }

@@ -574,6 +574,47 @@ class Engine(object):
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
+    def end_universe(self, E):
+        """items that can end a path, ranked by item index: E.urank [I] (-1: not an end), E.uitem [n_ends]"""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        T = self._ext_tables(E, None)
+        mark = self._empty(max(I, 1), torch.int32)
+        rank = self._empty(I + 1, torch.int64)
+        E.urank = self._empty(max(I, 1), torch.int32)
+        E.uitem = self._empty(max(I, 1), torch.int32)
+        n = C.c_int64(0)
+        check(lib.xmap_end_universe(st, C.byref(T), vp(mark), vp(rank), vp(E.urank), vp(E.uitem), C.byref(n)))
+        E.n_ends = int(n.value)
+        if os.environ.get("XMAP_URANK_HOME", "1") == "1" and E.n_ends:
+            # row order: the ends of a column side by side (a column's row update then touches few lines): every end is
+            # placed with the first column x whose end list {x} + NN(x) holds it
+            nU = E.n_ends
+            nb = torch.nonzero(E.cls[:I] == 2).flatten()
+            cnt = E.kcnt[nb, 1].long()
+            k = E.k
+            cols = torch.cat([nb, torch.repeat_interleave(nb, cnt)])
+            q = torch.arange(k, device=self.dev)[None, :] < cnt[:, None]
+            ends = torch.cat([nb, E.kcol[nb, 1, :][q].long()])
+            home = torch.full((max(I, 1),), 1 << 40, dtype=torch.int64, device=self.dev)
+            home.scatter_reduce_(0, ends, cols, "amin")
+            u = E.uitem[:nU].long()
+            o = torch.sort(home[u] * (1 << 20) + u).indices
+            E.uitem[:nU] = u[o].to(torch.int32)
+            E.urank[E.uitem[:nU].long()] = torch.arange(nU, dtype=torch.int32, device=self.dev)
+
+    def _ext_tables(self, E, M):
+        R = self.R
+        p = lambda t: (t.data_ptr() if t is not None else 0)
+        g = lambda o, n: getattr(o, n, None) if o is not None else None
+        return abi.ExtTables(R.n_items, E.k, p(E.cls), p(E.kcnt), p(E.kcol), p(E.kval), p(R.flags),
+                             p(E.att[0]), p(E.att[1]), p(E.att[2]), p(E.src[0]), p(E.src[1]), p(E.src[2]), p(E.src[3]),
+                             p(E.rnn[0]), p(E.rnn[1]), p(E.rnn[2]),
+                             (M.n_nb if M is not None else 0), p(g(M, "nb_id")), p(g(M, "nb_list")), p(g(M, "midX")),
+                             p(g(M, "dir")), p(g(M, "dir_ptr")),
+                             getattr(E, "n_ends", 0), p(getattr(E, "urank", None)), p(getattr(E, "uitem", None)))
+
     def mid_lists(self, E, table_budget=24 << 30, rows=None):
         """middle lists of all joint paths, one tile of records per (x', x) (stage_b.hip, second formulation).
         rows (default: whenever n_nb <= abi.MID_ROWS_MAX): built row-wise, one block per x' with the row's tile sizes in
@@ -625,8 +666,55 @@ class Engine(object):
             check(lib.xmap_mid_place(st, *common, vp(tile_cnt), vp(tile_off), vp(M.dir_ptr), vp(M.dir), vp(M.midX)))
         return M
 
+    def _extend_cols(self, E, U, M, full, xs_cap, start_range, n_slots):
+        """xmap_extend_cols: one set of lanes and one row update per column, rows indexed by end rank"""
+        R = self.R
+        I = R.n_items
+        st = _stream(self.dev)
+        with self.timed("paths_prep"):
+            self.end_universe(E)
+        nU = max(E.n_ends, 1)
+        slot_budget = int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "120")) * (1 << 30))
+        n_slots = int(os.environ.get("XMAP_N_SLOTS", n_slots))
+        n_slots = int(max(4, min(n_slots, slot_budget // (36 * nU), max(U.n_units, 4))))
+        acc = self._zero_scratch("qacc", n_slots * nU * 4, torch.float64)
+        touched = self._empty(n_slots * nU, torch.int32)
+        hacc = self._zero_scratch("qhacc", max(U.n_rows, 1) * nU * 4, torch.float64) if U.n_rows else None
+        htouched = self._empty(max(U.n_rows, 1) * nU, torch.int32) if U.n_rows else None
+        E.n_cand = self._zeros(max(I, 1), torch.int32)
+        E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=self.dev)
+        E.top_val = self._zeros((max(I, 1), abi.TOPC), torch.float64)
+        d_cnt = self._zeros(4, torch.int64)
+        h_cnt = (C.c_int64 * 4)()
+        T = self._ext_tables(E, M)
+        Un = abi.PathUnits(U.n_units, U.unit_start.data_ptr(), U.unit_c.data_ptr(), U.unit_G.data_ptr(), U.unit_row.data_ptr(),
+                           U.unit_nt.data_ptr(), U.n_heavy, U.heavy_unit0.data_ptr())
+        Rw = abi.PathRows(n_slots, acc.data_ptr(), touched.data_ptr(), hacc.data_ptr() if hacc is not None else 0,
+                          htouched.data_ptr() if htouched is not None else 0)
+        cap = 0
+        if full:
+            cap = int(xs_cap) if xs_cap else 1 << 22
+        fast = 0 if os.environ.get("XMAP_SLOW_DIV") == "1" else 1
+        while True:
+            xs_off = self._zeros(max(I, 1), torch.int64) if cap else None
+            xs_end = self._empty(max(cap, 1), torch.int32) if cap else None
+            xs_val = self._empty(max(cap, 1), torch.float64) if cap else None
+            O = abi.PathOut(E.n_cand.data_ptr(), E.top_end.data_ptr(), E.top_val.data_ptr(), cap,
+                            xs_off.data_ptr() if cap else 0, xs_end.data_ptr() if cap else 0, xs_val.data_ptr() if cap else 0)
+            with self.timed("paths"):
+                rc = lib.xmap_extend_cols(st, C.byref(T), C.byref(Un), C.byref(Rw), C.byref(O), fast, vp(d_cnt), h_cnt)
+            if rc == abi.ERR_CAPACITY:
+                cap = int(h_cnt[0])
+                continue
+            check(rc)
+            break
+        E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])
+        E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val
+        E.start_range = (0, I) if start_range is None else tuple(start_range)
+        return E
+
     def extend(self, S, top_k, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
-               start_split=None, algo="mid"):
+               start_split=None, algo="cols"):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
         R = self.R
         I = R.n_items
@@ -639,10 +727,14 @@ class Engine(object):
             E.att = self._reverse(S, E, 0, None)
             E.src = self._reverse(S, E, 1, E.att[0])
             E.rnn = self._reverse(S, E, 2, None)
+        M = self.mid_lists(E) if algo in ("mid", "cols") else None
+        if algo == "cols" and M is None:
+            algo = "enum"           # no non-bridge records (nothing joint) or the lists do not fit: per-path enumeration
         U = self.path_units(E, start_range, chunk, start_split=start_split)
         E.units = U
-        M = self.mid_lists(E) if algo == "mid" else None
         E.mid = M
+        if algo == "cols":
+            return self._extend_cols(E, U, M, full, xs_cap, start_range, n_slots)
         # one private accumulator row (36 B per item) per resident wave: 5 waves per SIMD = 5120 rows on 256 CUs
         slot_budget = int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "100")) * (1 << 30))
         n_slots = int(os.environ.get("XMAP_N_SLOTS", n_slots))

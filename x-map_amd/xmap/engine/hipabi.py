@@ -36,13 +36,40 @@ class Sim(C.Structure):
                 ("mutu", C.c_void_p), ("nij", C.c_void_p), ("info", C.c_void_p), ("frac", C.c_void_p)]
 
 
+class ExtTables(C.Structure):
+    """xmap_ext_tables: the stage-B tables of one pass (device pointers)"""
+    _fields_ = [("n_items", C.c_int32), ("top_k", C.c_int32),
+                ("cls", C.c_void_p), ("kcnt", C.c_void_p), ("kcol", C.c_void_p), ("kval", C.c_void_p), ("flags", C.c_void_p),
+                ("att_ptr", C.c_void_p), ("att_idx", C.c_void_p), ("att_val", C.c_void_p),
+                ("src_ptr", C.c_void_p), ("src_idx", C.c_void_p), ("src_val", C.c_void_p), ("src_flag", C.c_void_p),
+                ("rnn_ptr", C.c_void_p), ("rnn_idx", C.c_void_p), ("rnn_val", C.c_void_p),
+                ("n_nb", C.c_int32), ("nb_id", C.c_void_p), ("nb_list", C.c_void_p), ("midX", C.c_void_p), ("dir", C.c_void_p),
+                ("dir_ptr", C.c_void_p),
+                ("n_ends", C.c_int32), ("urank", C.c_void_p), ("uitem", C.c_void_p)]
+
+
+class PathUnits(C.Structure):
+    _fields_ = [("n_units", C.c_int32), ("unit_start", C.c_void_p), ("unit_c", C.c_void_p), ("unit_G", C.c_void_p),
+                ("unit_row", C.c_void_p), ("unit_nt", C.c_void_p), ("n_heavy", C.c_int32), ("heavy_unit0", C.c_void_p)]
+
+
+class PathRows(C.Structure):
+    _fields_ = [("n_slots", C.c_int32), ("acc", C.c_void_p), ("touched", C.c_void_p), ("hacc", C.c_void_p),
+                ("htouched", C.c_void_p)]
+
+
+class PathOut(C.Structure):
+    _fields_ = [("n_cand", C.c_void_p), ("top_end", C.c_void_p), ("top_val", C.c_void_p), ("xs_cap", C.c_int64),
+                ("xs_off", C.c_void_p), ("xs_end", C.c_void_p), ("xs_val", C.c_void_p)]
+
+
 EXPORTS = [
     "xmap_last_error", "xmap_version", "xmap_exclusive_scan_i64", "xmap_exclusive_scan_i32_to_i64",
     "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", "xmap_sim_plan", "xmap_sim_units", "xmap_sim_count",
     "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
     "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_bridge_flags", "xmap_knn_classify", "xmap_knn_thresholds", "xmap_reverse_count",
     "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", "xmap_mid_tally", "xmap_mid_place",
-    "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_extend_paths2", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
+    "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_extend_paths2", "xmap_end_universe", "xmap_extend_cols", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
 ]
 
 if not os.path.exists(LIB_PATH):
