@@ -375,7 +375,7 @@ int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32
 int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m);
 int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, const int64_t *off_t,
                        const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item,
-                       float *out_rating, int64_t *out_time);
+                       double *out_rating, int64_t *out_time);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,19 @@ def test_abi_exports_every_declared_symbol():
     assert [f[0] for f in hipabi.Ratings._fields_] == re.findall(
         r"(?:const\s+)?\w+\s+\*?(\w+);", hdr[hdr.index("typedef struct xmap_ratings {"):hdr.index("} xmap_ratings;")])
     assert ctypes.sizeof(hipabi.Sim) == 8 * 8
+    # every export carries argtypes generated from the header: a mis-typed or missing argument raises in ctypes
+    assert set(hipabi.PROTOTYPES) == names
+    for n in sorted(names):
+        f = getattr(hipabi.lib, n)
+        assert f.argtypes is not None and len(f.argtypes) == len(hipabi.PROTOTYPES[n]), n
+    assert hipabi.PROTOTYPES["xmap_exclusive_scan_i64"] == [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                            ctypes.c_void_p]
+    with pytest.raises((ctypes.ArgumentError, TypeError)):
+        hipabi.lib.xmap_exclusive_scan_i64(None, None, None)            # too few arguments
+    for st_name, cls in (("xmap_ext_tables", hipabi.ExtTables), ("xmap_path_units", hipabi.PathUnits),
+                         ("xmap_path_rows", hipabi.PathRows), ("xmap_path_out", hipabi.PathOut)):
+        body = hdr[hdr.index("typedef struct %s {" % st_name):hdr.index("} %s;" % st_name)]
+        assert [f[0] for f in cls._fields_] == re.findall(r"\*?(\w+)\s*[;,]", body.split("{", 1)[1]), st_name
 
 
 def test_item_attrs_predicates():

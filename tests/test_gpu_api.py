@@ -57,7 +57,23 @@ def test_three_pipelines(case, method):
         tag = "%s.k%d" % (method, k)
         ext_tool = ExtendSim(k)
         ext = extender_pipeline(sc, sqlContext, tool, ext_tool, item2item_simRDD)
+        # lazy handle: a Generator consumes the per-start candidate arrays; no (start, end) list exists until the RDD
+        # is iterated
+        assert not ext.materialised and ext.E.xs_end is None
+        if "priv" in gold.gen_tags(method, k):
+            generator_pipeline(Generator(1, 0.6, method, 0.1), trainRDD, ext, True).collect()
+            assert not ext.materialised
         gx = {s: dict(lst) for s, lst in ext.collect()}
+        assert ext.materialised
+        # the reference's own orchestration of the stage (assist.py:80-102) against xmap.core.*: classified lists ->
+        # extract_siminfo -> sim_extend -> get_final_extension
+        from xmap.utils.assist import extract_siminfo
+        bridges = sorted({key[0] for key, val in item2item_simRDD.collect() if val[3] == 1})
+        classified = ext_tool.find_knn_items(tool.get_item_sim(item2item_simRDD), sc.broadcast(bridges)).cache()
+        BB_info, NB_info, knn_BB_bd, knn_NB_bd = extract_siminfo(sc, classified)
+        assert set(knn_BB_bd.value) == set(bridges) & {i for i, _ in BB_info.collect()}
+        ext_b = ext_tool.get_final_extension(ext_tool.sim_extend(BB_info, NB_info, knn_BB_bd, knn_NB_bd)).cache()
+        assert {s: dict(lst) for s, lst in ext_b.collect()} == gx
         xh, xv = gold[tag + ".xsim_head"], gold[tag + ".xsim_val"]
         ex = {}
         for (s, e), v in zip(xh, xv):
@@ -85,7 +101,7 @@ def test_three_pipelines(case, method):
             assert len(rows) == len(eh)
             for (u, i, r, t), (eu, ei), rr, tt in zip(rows, eh, er, et):
                 assert u == gold.uids[eu] and i == iids[ei] and t == ts2dt(tt)
-                assert float(r) == pytest.approx(rr, abs=1e-5)
+                assert float(r) == rr            # np.float64 means, bit for bit
             assert all("T:" in i for (_, i, _, _) in rows)
             # Generator's own mapping methods + map_to_dict agree with the golden choices
             if not private:

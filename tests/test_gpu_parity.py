@@ -127,7 +127,7 @@ def test_golden_all_stages(dev, case, method):
             eh = gold[gtag + ".ae_head"]
             assert np.array_equal(G.user.cpu().numpy(), eh[:, 0])
             assert np.array_equal(G.item.cpu().numpy(), eh[:, 1])
-            np.testing.assert_allclose(G.rating.cpu().numpy(), gold[gtag + ".ae_rating"], rtol=0, atol=1e-5)
+            assert np.array_equal(G.rating.cpu().numpy(), gold[gtag + ".ae_rating"])      # fp64 means, bit for bit
             assert np.array_equal(G.time.cpu().numpy(), gold[gtag + ".ae_time"])
 
 
@@ -178,7 +178,7 @@ def _check_all_stages(dev, r, method, k, private=True, picks_seed=None, **sim_kw
     G = eng.alterego(mp)
     ae = xo.alterego(T, m_o)
     assert np.array_equal(G.user.cpu().numpy(), ae["user"]) and np.array_equal(G.item.cpu().numpy(), ae["item"])
-    np.testing.assert_allclose(G.rating.cpu().numpy(), ae["rating"], rtol=0, atol=1e-5)
+    assert np.array_equal(G.rating.cpu().numpy(), ae["rating"])
     assert np.array_equal(G.time.cpu().numpy(), ae["time"])
     assert eng.n_profiles(G) == ae["n_profiles"]
     xo.ext_free(Xo)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
                                                   const long long *time, const uint8_t *flags, const int *map,
                                                   int *cnt_t, int *cnt_m, const long long *off_t,
                                                   const long long *off_m, long long n_t_total, int *out_user,
-                                                  int *out_item, float *out_rating, long long *out_time) {
+                                                  int *out_item, double *out_rating, long long *out_time) {
     long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
     long long a = ptr[u], b = ptr[u + 1];
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
         int it = item[e];
         if (flags[it] & 2) {  // "T:" in iid: pass-through row
             if (FILL) {
-                out_user[ot] = (int)u; out_item[ot] = it; out_rating[ot] = rating[e]; out_time[ot] = time[e];
+                out_user[ot] = (int)u; out_item[ot] = it; out_rating[ot] = (double)rating[e]; out_time[ot] = time[e];
                 ot++;
             }
             ct++;
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
             int n = 0;
             for (long long f = e; f < b; f++)
                 if (map[item[f]] == m) { s += (double)rating[f]; n++; }
-            out_user[om] = (int)u; out_item[om] = m; out_rating[om] = (float)(s / (double)n); out_time[om] = time[e];
+            out_user[om] = (int)u; out_item[om] = m; out_rating[om] = s / (double)n;      // np.mean of the group (fp64, generator.py:134)
+            out_time[om] = time[e];
             om++;
         }
         cm++;
@@ -95,7 +96,7 @@ int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_
 }
 
 int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, const int64_t *off_t,
-                       const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item, float *out_rating,
+                       const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item, double *out_rating,
                        int64_t *out_time) {
     XM_ARG(R && map_src2tgt && off_t && off_m && out_user && out_item && out_rating && out_time);
     if (R->n_users == 0) return XMAP_OK;

@@ -45,12 +45,56 @@ class ExtendSim:
         return LocalRDD(out, getattr(rdd, "ctx", None))
 
     def sim_extend(self, BB_info, NB_info, knn_BB_bd, knn_NB_bd):
-        """The reference materialises one record per path here (:46-182); this engine streams the
-        paths inside extender_pipeline and never builds that RDD."""
-        raise NotImplementedError("paths are enumerated on the GPU inside xmap.utils.assist.extender_pipeline")
+        """cross-domain path extension over the classified lists -- reference :46-182.  The reference materialises one
+        record per path; here the records stay implicit: the returned handle holds the knn tables and reverse
+        adjacencies in HBM, and get_final_extension runs the enumeration.
+        BB_info: (bridge iid, (BB_BB, BB_NB))*, NB_info: (non-bridge iid, (NB_BB, NB_NN))* as find_knn_items /
+        extract_siminfo produce them (the two broadcasts repeat that information and are not needed)."""
+        bb, nb = records_of(BB_info), records_of(NB_info)
+        ids = {i for i, _ in bb} | {i for i, _ in nb}
+        for _, lists in list(bb) + list(nb):
+            for lst in lists:
+                ids.update(e[0] for e in lst)
+        st = _items_state(sorted(ids))
+        I, k = len(st.idt.iids), int(self.top_k)
+        cls = np.zeros(I, np.uint8)
+        kcnt = np.zeros((I, 2), np.int32)
+        kcol = np.zeros((I, 2, k), np.int32)
+        kval = np.zeros((I, 2, k, 3), np.float64)
+        for recs, c in ((bb, 1), (nb, 2)):
+            for iid, lists in recs:
+                a = st.idt.iidx[iid]
+                cls[a] = c
+                for l, lst in enumerate(lists):
+                    if len(lst) > k:
+                        raise ValueError("a neighbour list is longer than top_k")
+                    kcnt[a, l] = len(lst)
+                    for q, e in enumerate(lst):
+                        kcol[a, l, q] = st.idt.iidx[e[0]]
+                        kval[a, l, q] = e[1:4]
+        E = st.engine.ext_tables_from_knn(k, cls, kcnt, kcol, kval)
+        return CrossExtendedHandle(st, E, getattr(BB_info, "ctx", None))
 
     def get_final_extension(self, cross_extended):
-        raise NotImplementedError("see xmap.utils.assist.extender_pipeline")
+        """(start iid, [(end iid, xsim)*])* with xsim = sum(s_p c_p) / sum(c_p) over all paths of a pair -- reference
+        :184-217.  Returns the lazy extended_simRDD (see xmap.engine.session.ExtendedSimRDD)."""
+        from xmap.engine import session
+        if not isinstance(cross_extended, CrossExtendedHandle):
+            raise TypeError("get_final_extension expects the handle returned by sim_extend")
+        st = cross_extended.state
+        E = st.engine.extend_tables(cross_extended.E, full=False)
+        return session.ExtendedSimRDD(st, E, cross_extended.ctx)
+
+
+class CrossExtendedHandle(object):
+    """what sim_extend returns: the stage-B tables of one pass in HBM (the reference's RDD of per-path records is
+    never built)"""
+
+    def __init__(self, state, E, ctx=None):
+        self.state, self.E, self.ctx = state, E, ctx
+
+    def cache(self):
+        return self
 
 
 class _ItemsState(object):

@@ -713,11 +713,9 @@ class Engine(object):
         E.start_range = (0, I) if start_range is None else tuple(start_range)
         return E
 
-    def extend(self, S, top_k, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
-               start_split=None, algo="cols"):
-        """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
-        R = self.R
-        I = R.n_items
+    def ext_tables(self, S, top_k):
+        """B1-B5b: bridge flags, classified top-k lists and the three reverse adjacencies (attach / src / rnn)"""
+        I = self.R.n_items
         E = self.knn(S, top_k)
         st = _stream(self.dev)
         with self.timed("reverse"):
@@ -727,7 +725,92 @@ class Engine(object):
             E.att = self._reverse(S, E, 0, None)
             E.src = self._reverse(S, E, 1, E.att[0])
             E.rnn = self._reverse(S, E, 2, None)
-        M = self.mid_lists(E) if algo in ("mid", "cols") else None
+        return E
+
+    def ext_tables_from_knn(self, top_k, cls, kcnt, kcol, kval):
+        """The same tables from classified top-k lists alone (host arrays: cls [I], kcnt [I][2], kcol [I][2][k],
+        kval [I][2][k][3]) -- what ExtendSim.sim_extend is handed by a caller that ran find_knn_items /
+        extract_siminfo itself (reference core/extender.py:46-81,171-178).  The reverse lists are small (<= 2 k I
+        entries): built on the host, in list order."""
+        R = self.R
+        I, k = R.n_items, int(top_k)
+        dev = self.dev
+        flags = R.flags[:I].cpu().numpy()
+        cls = np.ascontiguousarray(cls, np.uint8)
+        kcnt = np.ascontiguousarray(kcnt, np.int32).reshape(I, 2)
+        kcol = np.ascontiguousarray(kcol, np.int32).reshape(I, 2, k)
+        kval = np.ascontiguousarray(kval, np.float64).reshape(I, 2, k, 3)
+
+        def entries(rows, lst):
+            """(row item, position) of the valid entries of list `lst` of the given rows"""
+            c = kcnt[rows, lst]
+            r = np.repeat(rows, c)
+            q = np.arange(int(c.sum())) - np.repeat(np.cumsum(c) - c, c)
+            return r, q
+
+        def csr(keys, idx, vals, flag=None):
+            o = np.argsort(keys, kind="stable")
+            ptr = np.zeros(I + 1, np.int64)
+            np.cumsum(np.bincount(keys, minlength=I), out=ptr[1:])
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a if len(a) else np.zeros((1,) + a.shape[1:]), dt)).to(dev)
+            return (torch.from_numpy(ptr).to(dev), t(idx[o], np.int32), t(vals[o], np.float64),
+                    t((flag[o] if flag is not None else np.zeros(len(o))), np.uint8), len(o))
+        nb = np.nonzero(cls == 2)[0]
+        # attach(b) = [x : x non-bridge record, b in NB_BB(x)];  rnn(y) = [x : y in NB_NN(x)]
+        x0, q0 = entries(nb, 0)
+        att = csr(kcol[x0, 0, q0].astype(np.int64), x0, kval[x0, 0, q0])
+        x1, q1 = entries(nb, 1)
+        rnn = csr(kcol[x1, 1, q1].astype(np.int64), x1, kval[x1, 1, q1])
+        natt = np.diff(att[0].cpu().numpy())
+        # src(t) = [s : s bridge, "S:" in s, attach(s) not empty, t in the lists of s, "T:" in t]; joint iff (t, s) is in TGT too
+        bs = np.nonzero((cls == 1) & ((flags & 1) != 0) & (natt > 0))[0]
+        s_, t_, v_ = [], [], []
+        for lst in (0, 1):
+            r, q = entries(bs, lst)
+            s_.append(r); t_.append(kcol[r, lst, q]); v_.append(kval[r, lst, q])
+        s_ = np.concatenate(s_) if s_ else np.zeros(0, np.int64)
+        t_ = np.concatenate(t_).astype(np.int64) if t_ else np.zeros(0, np.int64)
+        v_ = np.concatenate(v_) if v_ else np.zeros((0, 3))
+        keep = (flags[t_] & 2) != 0
+        s_, t_, v_ = s_[keep], t_[keep], v_[keep]
+        # TGT: t bridge, "T:" in t, attach(t) not empty, s in the lists of t
+        tgt_ok = (cls[t_] == 1) & (natt[t_] > 0)
+        in_t = np.zeros(len(t_), bool)
+        for lst in (0, 1):
+            m = (np.arange(k)[None, :] < kcnt[t_, lst][:, None]) & (kcol[t_, lst, :] == s_[:, None])
+            in_t |= m.any(axis=1)
+        src = csr(t_, s_, v_, (tgt_ok & in_t).astype(np.uint8))
+        E = ExtResult()
+        E.k = k
+        t = lambda a: torch.from_numpy(a).to(dev)
+        E.cls, E.kcnt, E.kcol, E.kval = t(cls), t(kcnt), t(kcol), t(kval)
+        E.bb = t((cls == 1).astype(np.uint8))
+        E.att, E.src, E.rnn = att, src, rnn
+        return E
+
+    def extend(self, S, top_k, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
+               start_split=None, algo="cols"):
+        """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
+        return self.extend_tables(self.ext_tables(S, top_k), full, start_range, n_slots, xs_cap, chunk, start_split, algo)
+
+    def extend_lists(self, E):
+        """the full X-Sim lists of a pass that kept the candidate arrays only (lazy extended_simRDD): the enumeration is
+        run once more with the list buffers sized exactly from n_cand"""
+        if getattr(E, "xs_end", None) is None:
+            total = int(E.n_cand.sum().item())
+            self.extend_tables(E, True, E.start_range, xs_cap=max(total, 1), algo=E.algo)
+        return E
+
+    def extend_tables(self, E, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
+                      start_split=None, algo="cols"):
+        """B5c-B6 on prepared tables: work units, middle lists, path enumeration, fused top-XMAP_TOPC"""
+        R = self.R
+        I = R.n_items
+        st = _stream(self.dev)
+        E.algo = algo
+        M = getattr(E, "mid", None)
+        if M is None:
+            M = self.mid_lists(E) if algo in ("mid", "cols") else None
         if algo == "cols" and M is None:
             algo = "enum"           # no non-bridge records (nothing joint) or the lists do not fit: per-path enumeration
         U = self.path_units(E, start_range, chunk, start_split=start_split)
@@ -862,7 +945,7 @@ class Engine(object):
         G = GenResult()
         G.user = self._empty(max(n, 1), torch.int32)
         G.item = self._empty(max(n, 1), torch.int32)
-        G.rating = self._empty(max(n, 1), torch.float32)
+        G.rating = self._empty(max(n, 1), torch.float64)      # pass-through ratings and np.mean of the merged ones (fp64)
         G.time = self._empty(max(n, 1), torch.int64)
         check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt.value),
                                      vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))

@@ -79,6 +79,44 @@ lib.xmap_last_error.restype = C.c_char_p
 for _n in EXPORTS:
     getattr(lib, _n)  # every symbol the header declares must be exported
 
+HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "..", "..", "include", "xmap_hip.h"))
+
+
+def header_prototypes(path=HEADER_PATH):
+    """{function: [ctypes type per parameter]} parsed from the declarations of include/xmap_hip.h (the single source of
+    the C ABI): a pointer of any kind -> c_void_p, int64_t -> c_int64, int / int32_t -> c_int32, float / double."""
+    import re
+    with open(path) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const\s+char\s*\*)\s*(xmap_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        types = []
+        for a in ([] if args in ("", "void") else args.split(",")):
+            if "*" in a:
+                types.append(C.c_void_p)
+            elif "int64_t" in a:
+                types.append(C.c_int64)
+            elif "double" in a:
+                types.append(C.c_double)
+            elif "float" in a:
+                types.append(C.c_float)
+            else:
+                types.append(C.c_int32)
+        out[name] = types
+    return out
+
+
+# argtypes of every export: a mis-ordered or mis-typed argument raises in ctypes instead of corrupting device memory
+PROTOTYPES = header_prototypes()
+for _n, _t in PROTOTYPES.items():
+    _f = getattr(lib, _n)
+    _f.argtypes = _t
+    if _n != "xmap_last_error":
+        _f.restype = C.c_int
+
 
 def check(rc):
     if rc != 0:

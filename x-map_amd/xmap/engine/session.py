@@ -131,13 +131,21 @@ def rec_sim_from_profiles(user_profiles, cap, ctx=None):
 
 
 class ExtendedSimRDD(LocalRDD):
-    """extended_simRDD: (start_iid, [(end_iid, xsim)*]) -- candidate lists live in HBM."""
+    """extended_simRDD: (start_iid, [(end_iid, xsim)*]) -- a LAZY handle.  The pass behind it keeps, per start item, the
+    number of candidates and the XMAP_TOPC best by |xsim| (all a Generator reads: generator.py:85,109) in HBM.  The full
+    lists (4.6e9 pairs at BASELINE configs[1]) are only produced when somebody iterates / collects this RDD: the
+    enumeration then runs once more with list buffers sized exactly from the candidate counts."""
 
     def __init__(self, state, E, ctx=None):
         LocalRDD.__init__(self, None, ctx, self._rows)
         self.state, self.E = state, E
 
+    @property
+    def materialised(self):
+        return getattr(self.E, "xs_end", None) is not None
+
     def _rows(self):
+        self.state.engine.extend_lists(self.E)
         E, iids = self.E, self.state.idt.iids
         I = len(iids)
         n_cand = E.n_cand.cpu().numpy()[:I]

@@ -61,19 +61,30 @@ def extender_pipeline(sc, sqlContext, itemsim_tool, extendsim_tool, item2item_si
         recs = records_of(item2item_simRDD)
         st = _items_state(sorted({k[0] for k, _ in recs} | {k[1] for k, _ in recs}))
         S = session.sim_from_records(st, recs)
-    E = extendsim_tool.extend(st, S, full=True)
+    # lazy: only the per-start candidate counts and top candidates are computed here (what generator_pipeline
+    # consumes); the (start, [(end, xsim)*]) lists materialise if the returned RDD is iterated
+    E = extendsim_tool.extend(st, S, full=False)
     return session.ExtendedSimRDD(st, E, sc).cache()
 
 
 def extract_siminfo(sc, classfied_items):
-    """reference utils/assist.py:105-133 (host-side; the engine keeps these tables in HBM instead)."""
-    BB_info = classfied_items.map(lambda line: (line[0], line[1])).filter(lambda line: line[1] is not None)
-    NB_info = classfied_items.map(lambda line: (line[0], line[2])).filter(lambda line: line[1] is not None)
-    BB_items_knn = BB_info.map(
-        lambda line: (line[0], dict((l[0], l[1:]) for l in line[1][0] + line[1][1]))).collectAsMap()
-    NB_items_knn = NB_info.map(
-        lambda line: (line[0], dict((l[0], l[1:]) for l in line[1][0] + line[1][1]))).collectAsMap()
-    return BB_info, NB_info, sc.broadcast(BB_items_knn), sc.broadcast(NB_items_knn)
+    """(BB_info, NB_info, knn_BB_bd, knn_NB_bd) of the classified items -- reference utils/assist.py:105-133.
+    BB_info: (bridge iid, (BB_BB, BB_NB))*, NB_info: (non-bridge iid, (NB_BB, NB_NN))*; the two broadcasts hold
+    {iid: {neighbour: (sim, mutu, frac_mutu)}} over both lists of an item (a neighbour listed twice keeps the entry
+    of the second list, as dict() does in the reference)."""
+    from xmap.engine.localrdd import LocalRDD, records_of
+    bb, nb, knn_bb, knn_nb = [], [], {}, {}
+    for iid, bridge_lists, other_lists in records_of(classfied_items):
+        for lists, info, table in ((bridge_lists, bb, knn_bb), (other_lists, nb, knn_nb)):
+            if lists is None:
+                continue
+            info.append((iid, lists))
+            table[iid] = {}
+            for lst in lists:
+                for entry in lst:
+                    table[iid][entry[0]] = tuple(entry[1:])
+    ctx = getattr(classfied_items, "ctx", None)
+    return LocalRDD(bb, ctx), LocalRDD(nb, ctx), sc.broadcast(knn_bb), sc.broadcast(knn_nb)
 
 
 def generator_pipeline(privatemap_tool, trainRDD, extended_simRDD, private):
