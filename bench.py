@@ -334,6 +334,15 @@ def main():
         # 12 E + 12 N_out); it is latency / random-access bound, paths/s is the figure of merit.
         paths_ms = float(np.mean(tm.get("paths", [0.0])))
         bytes_paths = 12.0 * res["knn_entries"] + 12.0 * res["n_out"]
+        tr_a, tr_b = pmc_traffic("k_pair_tri"), pmc_traffic("k_paths4")
+        ach_b = bytes_paths / (paths_ms * 1e-3) / 1e9 if paths_ms > 0 else 0.0
+        rf_b = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
+                "traffic": tr_b, "traffic_ratio": (tr_b / bytes_paths) if (tr_b and bytes_paths) else None,
+                "algorithmic_bytes_per_launch": bytes_paths, "launch_ms": paths_ms,
+                "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                "note": "per column (start, x): one set of lanes (W ends x S record slices) and one read-modify-write of the "
+                        "start's row (32-byte (value, error) pairs, rows indexed by end rank in column order); ablations "
+                        "(profiles/README.md): 464 ms without the row updates, 615 ms without the path arithmetic"}
         out = {
             "metric": "item_sim_pairs_per_s", "value": D / t_a if t_a > 0 else 0.0, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -347,20 +356,17 @@ def main():
             "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
             "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},
             "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
-            "roofline": {"bound": "hbm", "kernel": "k_pair_tri", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_pair_tri"),
-                         "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms,
-                         "stage_a_whole": {"algorithmic_bytes": bytes_a, "ms": stage["stage_a"],
-                                           "achieved": bytes_a / t_a / 1e9 if t_a > 0 else 0.0,
-                                           "frac": bytes_a / t_a / 1e9 / HBM_PEAK_GBS if t_a > 0 else 0.0}},
-            "roofline_stage_b": {"bound": "hbm", "kernel": "k_paths2", "achieved": bytes_paths / (paths_ms * 1e-3) / 1e9
-                                 if paths_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": (bytes_paths / (paths_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if paths_ms > 0 else 0.0,
-                                 "traffic": pmc_traffic("k_paths2"), "algorithmic_bytes_per_launch": bytes_paths,
-                                 "launch_ms": paths_ms, "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
-                                 "note": "bound by 32-byte double-double read-modify-writes at random places of the starts' rows (one per "
-                                         "(start, x, end) triple + one per distinct (start, end)); profiles/rand_rmw.hip measures "
-                                         "1.9e10 such updates/s for uniformly random places of a 64 GiB region"},
+            # the dominant kernel of the step (90 % of it): the path enumeration of stage B.  Its compulsory HBM bytes
+            # (12 E + 12 N_out -- knn tables in, (start, end, xsim) out) are a small part of what it moves:
+            # it accumulates 32-byte (value, error) pairs per (start, end) in HBM rows; paths/s is the figure of merit
+            "roofline": dict(rf_b, kernel="k_paths4"),
+            "roofline_stage_a": {"bound": "hbm", "kernel": "k_pair_tri", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr_a,
+                                 "traffic_ratio": (tr_a / bytes_tri) if (tr_a and bytes_tri) else None,
+                                 "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms,
+                                 "stage_a_whole": {"algorithmic_bytes": bytes_a, "ms": stage["stage_a"],
+                                                   "achieved": bytes_a / t_a / 1e9 if t_a > 0 else 0.0,
+                                                   "frac": bytes_a / t_a / 1e9 / HBM_PEAK_GBS if t_a > 0 else 0.0}},
         }
         if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(r, attrs, args.method, k=k)

@@ -64,23 +64,14 @@ def test_stage_a_full_size(c2):
     xo.sim_free(So)
 
 
-def test_stage_b_c_full_size(c2):
-    r, eng = c2
-    I = r.n_items
-    S = eng.item_sim("cosine", CAP)
-    k = 10
-    E1 = eng.extend(S, k, algo="mid")
-    E2 = eng.extend(S, k, algo="enum")            # one accumulate per path: independent formulation
-    assert E1.n_paths == E2.n_paths == E1.units.total and E1.n_out == E2.n_out
-    assert np.array_equal(E1.n_cand.cpu().numpy(), E2.n_cand.cpu().numpy())
-    assert np.array_equal(E1.top_end.cpu().numpy(), E2.top_end.cpu().numpy())
-    assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
-    n_cand = E1.n_cand.cpu().numpy()[:I]
-    top_end = E1.top_end.cpu().numpy()[:I]
-    top_val = E1.top_val.cpu().numpy()[:I]
+def _candidate_properties(r, E, I):
+    """size-independent properties of the per-start candidate arrays"""
+    n_cand = E.n_cand.cpu().numpy()[:I]
+    top_end = E.top_end.cpu().numpy()[:I]
+    top_val = E.top_val.cpu().numpy()[:I]
     flags = r.item_attrs()[3]
     has = n_cand > 0
-    assert int(n_cand.sum()) == E1.n_out
+    assert int(n_cand.sum()) == E.n_out
     # starts are target-side, candidates source-side; candidate lists are sorted by (|xsim| desc, end asc)
     assert (flags[np.nonzero(has)[0]] & 2).all()
     m = np.minimum(n_cand, 10)
@@ -93,6 +84,27 @@ def test_stage_b_c_full_size(c2):
             assert (a >= b).all()
             tie = a == b
             assert (top_end[sel, q - 1][tie] < top_end[sel, q][tie]).all()
+    return n_cand, top_end, top_val, flags, has
+
+
+@pytest.mark.parametrize("k", [10, 50])
+def test_stage_b_c_full_size(c2, k):
+    """BASELINE configs[1] at its own list length (k = 50) and at k = 10: the column form (default), the per-path
+    enumeration (independent formulation: one accumulate per path) and, at k = 10, the round-1 tile-major form agree
+    bit for bit on every per-start output."""
+    r, eng = c2
+    I = r.n_items
+    S = eng.item_sim("cosine" if k == 10 else "adjust_cosine", CAP)
+    E1 = eng.extend(S, k)                         # algo "cols"
+    E2 = eng.extend(S, k, algo="enum")            # one accumulate per path: independent formulation
+    others = [E2] + ([eng.extend(S, k, algo="mid")] if k == 10 else [])
+    for Ex in others:
+        assert E1.n_paths == Ex.n_paths == E1.units.total and E1.n_out == Ex.n_out
+        assert np.array_equal(E1.n_cand.cpu().numpy(), Ex.n_cand.cpu().numpy())
+        assert np.array_equal(E1.top_end.cpu().numpy(), Ex.top_end.cpu().numpy())
+        assert np.array_equal(E1.top_val.cpu().numpy(), Ex.top_val.cpu().numpy())
+    del others, E2
+    n_cand, top_end, top_val, flags, has = _candidate_properties(r, E1, I)
     # stage C: private mapping = candidate 0; map is the max start per chosen source; rows are conserved
     n_top, choice, mp_d = eng.select(E1, True)
     choice, mp = choice.cpu().numpy()[:I], mp_d.cpu().numpy()[:I]
@@ -111,3 +123,77 @@ def test_stage_b_c_full_size(c2):
     key = users[mapped] * np.int64(I) + mp[r.item][mapped]
     assert G.n_rows - n_t == len(np.unique(key))                      # one AlterEgo row per (user, mapped target)
     assert (rt >= 1).all() and (rt <= 5).all()
+
+
+def test_full_lists_at_full_size(c2):
+    """full=True (what iterating the lazy extended_simRDD triggers) at BASELINE configs[1], k = 50: 4.6e9 (start, end)
+    pairs in buffers sized exactly from the candidate counts of the first pass -- no capacity retry --, checked through
+    the list invariants and, on a sample of starts, against the candidate arrays."""
+    import torch
+    r, eng = c2
+    I = r.n_items
+    S = eng.item_sim("adjust_cosine", CAP)
+    E = eng.extend(S, 50)
+    n0, t0, v0 = E.n_cand.clone(), E.top_end.clone(), E.top_val.clone()
+    assert E.xs_end is None
+    eng.extend_lists(E)
+    assert np.array_equal(n0.cpu().numpy(), E.n_cand.cpu().numpy())
+    assert np.array_equal(t0.cpu().numpy(), E.top_end.cpu().numpy()) and np.array_equal(v0.cpu().numpy(), E.top_val.cpu().numpy())
+    n_cand = E.n_cand[:I].long()
+    total = int(n_cand.sum().item())
+    assert total == E.n_out and int(E.xs_end.numel()) == total            # exact allocation
+    off = E.xs_off[:I]
+    has = n_cand > 0
+    # the lists tile the buffer: offsets are a permutation-free packing of the counts
+    o = torch.sort(off[has]).indices
+    so, sn = off[has][o], n_cand[has][o]
+    assert int(so[0].item()) == 0 and bool((so[1:] == so[:-1] + sn[:-1]).all()) and int((so[-1] + sn[-1]).item()) == total
+    flags = torch.from_numpy(r.item_attrs()[3]).to(E.xs_end.device)
+    for lo in range(0, total, 1 << 28):                                   # every end is a source-side item, every value finite
+        hi = min(total, lo + (1 << 28))
+        assert bool((flags[E.xs_end[lo:hi].long()] & 1).all()) and bool(torch.isfinite(E.xs_val[lo:hi]).all())
+    rng = np.random.default_rng(5)
+    starts = np.nonzero(has.cpu().numpy())[0]
+    te, tv = E.top_end.cpu().numpy(), E.top_val.cpu().numpy()
+    for s in rng.choice(starts, 300, replace=False):
+        a, n = int(off[s].item()), int(n_cand[s].item())
+        e, v = E.xs_end[a:a + n].cpu().numpy(), E.xs_val[a:a + n].cpu().numpy()
+        assert len(np.unique(e)) == n                                     # distinct ends
+        order = np.lexsort((e, -np.abs(v)))[:10]
+        m = min(n, 10)
+        assert np.array_equal(e[order], te[s, :m]) and np.array_equal(v[order], tv[s, :m])
+
+
+def test_k100_full_size(c2):
+    """the list length of BASELINE configs[3] (k = 100) at configs[1] size, through the size-independent properties"""
+    r, eng = c2
+    S = eng.item_sim("adjust_cosine", CAP)
+    E = eng.extend(S, 100)
+    assert E.n_paths == E.units.total
+    kc = E.kcnt.cpu().numpy()
+    assert kc.max() <= 100 and (kc[:, 0] > 50).any()
+    _candidate_properties(r, E, r.n_items)
+
+
+def test_dense_full_size():
+    """BASELINE configs[4]: 200k x 200k item factors of dimension 128, k = 50 -- a row sample against the oracle (bit for
+    bit: same k-ordered fp32 chain), every row through the order invariants"""
+    import torch
+    from oracle import xmap_oracle as xo
+    from xmap.engine import synth, device
+    r = synth.make_two_domain(3, 60, 30, 30, overlap=0.5)
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs()))
+    n, K, k = 200000, 128, 50
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Ft = torch.randn(n, K, device="cuda", generator=g)
+    Fs = torch.randn(n, K, device="cuda", generator=g)
+    idx, val = eng.dense_topk(Ft, Fs, k)
+    a = val.abs()
+    assert bool((idx >= 0).all()) and bool((idx < n).all())
+    assert bool((a[:, :-1] >= a[:, 1:]).all())
+    tie = a[:, :-1] == a[:, 1:]
+    assert bool((idx[:, :-1][tie] < idx[:, 1:][tie]).all())
+    rows = np.random.default_rng(2).choice(n, 48, replace=False)
+    oi, ov = xo.dense_topk(xo.dense_normalize(Ft[rows].cpu().numpy()), xo.dense_normalize(Fs.cpu().numpy()), k, nthreads=8)
+    assert np.array_equal(idx[rows].cpu().numpy(), oi)
+    assert np.array_equal(val[rows].cpu().numpy().view(np.uint32), ov.view(np.uint32))

@@ -348,6 +348,13 @@ def test_heavy_starts_with_long_candidate_lists(dev):
             assert np.array_equal(x, y)
 
 
+def test_k50_vs_oracle(dev):
+    """the list length of BASELINE configs[1] (k = 50) against the CPU oracle, every stage bit for bit: 9.5e7 paths, the
+    largest case the one-thread oracle enumerates in about half a minute"""
+    from xmap.engine import synth
+    _check_all_stages(dev, synth.make_two_domain(11, 2000, 1000, 1000), "adjust_cosine", 50)
+
+
 @pytest.mark.parametrize("method", METHODS)
 def test_long_rows_of_the_reverse_lists(dev, method, monkeypatch):
     """every row of more than 64 entries through the 16-wave form of k_reverse (XMAP_REV_LONG): all stages against the
