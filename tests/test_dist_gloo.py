@@ -55,3 +55,50 @@ def test_comm_world2_gloo():
         assert cnt == [3, 6, 9]
         assert top == [7, 7, 8, 8]
         assert ranges == [(0, 5), (5, 8)]
+
+
+def _worker_groups(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmap.engine.sharded import Comm
+    from xmap.engine.multidomain import domain_groups
+    plan = domain_groups(2, world)                       # two domains on four ranks: groups {0,1} and {2,3}
+    groups = [dist.new_group(ranks) for ranks, _ in plan]
+    g = [i for i, (ranks, _) in enumerate(plan) if rank in ranks][0]
+    comm = Comm(dist, groups[g])
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    comm.all_reduce(t)                                   # sum inside the group only
+    parts = comm.all_gather_var(torch.arange(comm.rank + 1, dtype=torch.int32) + 10 * rank)
+    # collective error agreement: the second rank of group 1 fails, both ranks of THAT group raise, group 0 goes on
+    outcome = "ok"
+    try:
+        comm.agree(ValueError("boom") if rank == 3 else None, "stage X")
+    except ValueError:
+        outcome = "own"
+    except RuntimeError as e:
+        outcome = "peer" if "another rank" in str(e) else "other"
+    q.put((rank, g, comm.rank, comm.world, int(t.item()), parts.tolist(), outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_groups_and_error_agreement_world4_gloo():
+    from xmap.engine.multidomain import domain_groups
+    assert domain_groups(4, 8) == [([0, 1], [0]), ([2, 3], [1]), ([4, 5], [2]), ([6, 7], [3])]
+    assert domain_groups(4, 2) == [([0], [0, 2]), ([1], [1, 3])]
+    assert domain_groups(3, 4) == [([0, 1], [0]), ([2], [1]), ([3], [2])]
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_groups, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r, g, gr, gw) for r, g, gr, gw, _, _, _ in got] == [(0, 0, 0, 2), (1, 0, 1, 2), (2, 1, 0, 2), (3, 1, 1, 2)]
+    assert [t for *_, t, _, _ in got] == [3, 3, 7, 7]
+    assert got[0][5] == [0, 10, 11] and got[2][5] == [20, 30, 31]
+    assert [o for *_, o in got] == ["ok", "ok", "peer", "own"]

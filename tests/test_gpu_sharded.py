@@ -85,3 +85,49 @@ def test_world2_equals_world1():
     assert np.array_equal(rows[o], full_rows) and np.array_equal(cols[o], ref["col"])
     assert np.array_equal(sims[o], ref["sim"])
     assert all(len(out["part_row"]) > 0 for _, out in got)
+
+
+def _md_engine(d):
+    from xmap.engine import synth, device
+    r = synth.make_multi_domain(33, 3000, 500, 600, 3)[d]
+    return device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs())), r.n_src_items
+
+
+def _md_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmap.engine import multidomain
+    out = multidomain.run_multidomain(_md_engine, 3, "adjust_cosine", 50, 5, True, dist)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multidomain_rank_groups_equal_one_rank(world):
+    """BASELINE configs[3] shape (3 source domains -> one target): the domains dealt to rank groups (world 2: one rank
+    takes two domains; world 4: one domain is item-sharded over a group of two ranks) give exactly the union one rank
+    computes domain after domain."""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    from xmap.engine import multidomain
+    ref = multidomain.run_multidomain(_md_engine, 3, "adjust_cosine", 50, 5, True)
+    assert (ref["n_paths"] > 0).all() and (ref["n_rows"] > 0).all() and len(ref["user"]) == ref["n_rows"].sum()
+    assert sorted(set(ref["domain"].tolist())) == [0, 1, 2]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_md_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, out in got:
+        for key, v in ref.items():
+            assert np.array_equal(out[key], v), (rank, key)

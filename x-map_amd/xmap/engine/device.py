@@ -113,6 +113,11 @@ class Engine(object):
             self._scratch[name] = t
         return t
 
+    def _drop_scratch(self, *names):
+        """forget persistent zero-filled scratch (after a failed pass its rows may hold partial sums)"""
+        for n in names:
+            self._scratch.pop(n, None)
+
     def timed(self, name):
         return _Timed(self, name)
 
@@ -701,12 +706,16 @@ class Engine(object):
             xs_val = self._empty(max(cap, 1), torch.float64) if cap else None
             O = abi.PathOut(E.n_cand.data_ptr(), E.top_end.data_ptr(), E.top_val.data_ptr(), cap,
                             xs_off.data_ptr() if cap else 0, xs_end.data_ptr() if cap else 0, xs_val.data_ptr() if cap else 0)
-            with self.timed("paths"):
-                rc = lib.xmap_extend_cols(st, C.byref(T), C.byref(Un), C.byref(Rw), C.byref(O), fast, vp(d_cnt), h_cnt)
-            if rc == abi.ERR_CAPACITY:
-                cap = int(h_cnt[0])
-                continue
-            check(rc)
+            try:
+                with self.timed("paths"):
+                    rc = lib.xmap_extend_cols(st, C.byref(T), C.byref(Un), C.byref(Rw), C.byref(O), fast, vp(d_cnt), h_cnt)
+                if rc == abi.ERR_CAPACITY:      # the pass itself completed (rows are back to zero): lists did not fit
+                    cap = int(h_cnt[0])
+                    continue
+                check(rc)
+            except BaseException:
+                self._drop_scratch("qacc", "qhacc")    # a failed pass may leave partial sums behind
+                raise
             break
         E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])
         E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val
@@ -856,6 +865,8 @@ class Engine(object):
             if rc == abi.ERR_CAPACITY:
                 cap = int(h_cnt[0])
                 continue
+            if rc != 0:
+                self._drop_scratch("acc", "hacc")
             check(rc)
             break
         E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])

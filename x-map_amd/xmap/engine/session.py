@@ -15,7 +15,7 @@ import numpy as np
 from . import ids as xids
 from .localrdd import LocalRDD, records_of
 
-_engines = {}   # id(trainRDD) -> (weakref or None, TrainState)
+_engines = {}   # id(trainRDD) -> (weakref or None, TrainState, fingerprint or None)
 
 
 class TrainState(object):
@@ -43,18 +43,47 @@ class TrainState(object):
         self.engine = device.Engine(self.R)
 
 
+def _fingerprint(records):
+    """cheap content key of a record list: length and the first / last user ids and profile lengths"""
+    if not records:
+        return (0,)
+    a, b = records[0], records[-1]
+    return (len(records), a[0], len(a[1]), b[0], len(b[1]))
+
+
 def train_state(trainRDD):
+    """The TrainState (id dictionary + ratings in HBM + engine) of a trainRDD, shared by the three stages.  Cached per
+    trainRDD object through a weak reference; inputs that cannot be weak-referenced (plain lists) are keyed on a content
+    fingerprint and only the most recent one is kept, so a recycled id() can neither leak the previous engine nor be
+    mistaken for it.  release() drops everything."""
     key = id(trainRDD)
     hit = _engines.get(key)
-    if hit is not None and (hit[0] is None or hit[0]() is trainRDD):
-        return hit[1]
-    st = TrainState(records_of(trainRDD))
+    if hit is not None:
+        ref, st, fp = hit
+        if ref is not None and ref() is trainRDD:
+            return st
+        if ref is None and fp == _fingerprint(records_of(trainRDD)):
+            return st
+        _engines.pop(key, None)
+    recs = records_of(trainRDD)
+    st = TrainState(recs)
     try:
         ref = weakref.ref(trainRDD, lambda _r, k=key: _engines.pop(k, None))
+        fp = None
     except TypeError:
-        ref = None
-    _engines[key] = (ref, st)
+        ref, fp = None, _fingerprint(recs)
+        for k in [k for k, v in _engines.items() if v[0] is None]:      # one strong entry at most
+            _engines.pop(k, None)
+    _engines[key] = (ref, st, fp)
     return st
+
+
+def release(trainRDD=None):
+    """drop the cached engine of one trainRDD (or of all): frees its HBM buffers and accumulator scratch"""
+    if trainRDD is None:
+        _engines.clear()
+    else:
+        _engines.pop(id(trainRDD), None)
 
 
 # ---------------------------------------------------------------------------------------------

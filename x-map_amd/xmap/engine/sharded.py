@@ -52,44 +52,61 @@ def unit_cuts(c, w_heavy, world):
 class Comm(object):
     """Thin wrapper over torch.distributed that stages through the host for gloo."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, group=None):
+        """group: a torch.distributed process group (None = all ranks); rank / world are relative to it"""
         self.dist = dist
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
-        self.host = dist.get_backend() == "gloo"
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.host = dist.get_backend(group) == "gloo"
 
     def all_reduce(self, t, op="sum"):
         ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}
         if self.host and t.is_cuda:
             h = t.cpu()
-            self.dist.all_reduce(h, op=ops[op])
+            self.dist.all_reduce(h, op=ops[op], group=self.group)
             t.copy_(h)
         else:
-            self.dist.all_reduce(t, op=ops[op])
+            self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t
+
+    def agree(self, err, what):
+        """Collective error check: every rank calls it with its own exception (or None); if ANY rank failed, EVERY rank
+        raises, so that nobody is left waiting in the next collective."""
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int64)
+        if not self.host:
+            flag = flag.cuda()
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            if err is not None:
+                raise err
+            raise RuntimeError("%s failed on another rank (this is rank %d of %d)" % (what, self.rank, self.world))
 
     def all_gather_var(self, t):
         """Concatenate 1-D tensors of different lengths from all ranks, in rank order."""
         dev = t.device
         n = torch.tensor([t.numel()], dtype=torch.int64, device="cpu" if self.host else dev)
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
-        self.dist.all_gather(sizes, n)
+        self.dist.all_gather(sizes, n, group=self.group)
         sizes = [int(s.item()) for s in sizes]
         m = max(max(sizes), 1)
         src = t.cpu() if self.host else t
         pad = torch.zeros(m, dtype=t.dtype, device=src.device)
         pad[:t.numel()] = src
         parts = [torch.empty(m, dtype=t.dtype, device=src.device) for _ in range(self.world)]
-        self.dist.all_gather(parts, pad)
+        self.dist.all_gather(parts, pad, group=self.group)
         out = torch.cat([p[:s] for p, s in zip(parts, sizes)])
         return out.to(dev)
 
 
 # ----------------------------------------------------------------------------- the step
-def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=False):
-    """stage A -> B -> C once.  Returns the counters the bench reports."""
+def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=False, group=None):
+    """stage A -> B -> C once.  Returns the counters the bench reports.  group: the process group that shares this
+    problem (None: all ranks); rank / world are then taken from it."""
     I = eng.R.n_items
-    if dist is None:
+    if dist is not None and group is not None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if dist is None or world == 1:
         with eng.timed("stage_a"):
             S = eng.item_sim(method, cap)
         with eng.timed("stage_b"):
@@ -104,7 +121,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
                     n_paths=E.n_paths, n_out=E.n_out, n_rows=G.n_rows, n_profiles=n_prof,
                     knn_entries=int(E.kcnt.sum().item()), S=S, E=E, G=G, choice=choice, map=mp)
 
-    comm = Comm(dist)
+    comm = Comm(dist, group)
     dev = eng.dev
     # ---- stage A: every rank lays out the (replicated) ratings, computes the pairs of its share of the
     # work units into a half COO, the COO parts are all-gathered and mirrored into the full CSR everywhere
@@ -121,8 +138,13 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
                 w_heavy = n_i[L.hlist[:L.n_heavy].long()].sum().double() if L.n_heavy else None
                 cuts = unit_cuts(c, w_heavy, world)
                 lo, hi = int(cuts[rank]), int(cuts[rank + 1])
-            coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
-                                                             do_heavy=(rank == 0), retry=False)
+            err, ovf = None, 0
+            try:
+                coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
+                                                                 do_heavy=(rank == 0), retry=False)
+            except Exception as e:          # e.g. half-COO overflow on this rank only
+                err = e
+            comm.agree(err, "stage A (pair kernels)")
             flag = torch.tensor([ovf], dtype=torch.int64, device=dev)
             comm.all_reduce(flag, "max")
             if int(flag.item()) == 0:
@@ -152,8 +174,13 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             coo = [(rec[:, 0] & m32).to(torch.int32), (rec[:, 0] >> 32).to(torch.int32),
                    rec[:, 1].contiguous().view(torch.float64), (rec[:, 2] & m32).to(torch.int32),
                    (rec[:, 2] >> 32).to(torch.int32)]
-        S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
-        E = eng.extend(S, k, full=False, start_split=(rank, world))
+        err = None
+        try:
+            S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
+            E = eng.extend(S, k, full=False, start_split=(rank, world))
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage B (extension)")
         comm.all_reduce(E.n_cand)
         comm.all_reduce(E.top_end, "max")             # -1 outside the local range
         comm.all_reduce(E.top_val)                    # 0.0 outside the local range

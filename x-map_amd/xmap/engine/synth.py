@@ -127,10 +127,47 @@ def make_two_domain(seed, n_users, n_src_items, n_tgt_items, overlap=0.25,
                    src_numbers, tgt_numbers)
 
 
+def make_multi_domain(seed, n_users, n_src_items, n_tgt_items, n_sources, overlap=0.25,
+                      d_min=5, mu=0.7, sigma=1.0, zipf=0.8):
+    """N source domains against ONE target domain (BASELINE configs[3] shape; reference multidomain_demo.py:101-128 runs
+    every source as an independent two-domain problem against the same target).  Returns one Ratings per source: its
+    source entries + the shared target entries; users and target item numbers are common to all of them."""
+    rng = np.random.default_rng(seed)
+    all_u = np.arange(n_users)
+    in_tgt = rng.random(n_users) < 0.5 + overlap / 2
+    ut, itt = _domain_draws(rng, all_u[in_tgt], n_tgt_items, d_min, mu, sigma, zipf)
+    tgt_numbers, itt_c = np.unique(itt, return_inverse=True)
+    rt = (rng.choice(5, size=len(ut), p=RATING_P) + 1).astype(np.float32)
+    tt = rng.integers(T0, T1 + 1, size=len(ut), dtype=np.int64)
+    out = []
+    for d in range(n_sources):
+        r = rng.random(n_users)
+        in_src = np.where(in_tgt, r < 2 * overlap, r < 0.6)         # a share of the target's users, plus source-only ones
+        us, its = _domain_draws(rng, all_u[in_src], n_src_items, d_min, mu, sigma, zipf)
+        src_numbers, its_c = np.unique(its, return_inverse=True)
+        n_src = len(src_numbers)
+        rs = (rng.choice(5, size=len(us), p=RATING_P) + 1).astype(np.float32)
+        ts = rng.integers(T0, T1 + 1, size=len(us), dtype=np.int64)
+        u = np.concatenate([us, ut])
+        it = np.concatenate([its_c, itt_c + n_src]).astype(np.int32)
+        order = np.argsort(u, kind="stable")       # source entries first per user
+        cnt = np.bincount(u, minlength=n_users)
+        ptr = np.zeros(n_users + 1, np.int64)
+        np.cumsum(cnt, out=ptr[1:])
+        out.append(Ratings(ptr, it[order], np.concatenate([rs, rt])[order], np.concatenate([ts, tt])[order],
+                           n_src + len(tgt_numbers), n_src, src_numbers, tgt_numbers))
+    return out
+
+
 # named workloads (BASELINE.json configs)
 def config_c1(seed=1):
     """10k users / 2x5k items (BASELINE configs[0])."""
     return make_two_domain(seed, 10000, 5000, 5000)
+
+
+def config_c4(seed=4, n_sources=4):
+    """4 source domains -> 1 target, ~5M users in total (BASELINE configs[3]): every source problem has 1.25 M users."""
+    return make_multi_domain(seed, 1250000, 200000, 200000, n_sources)
 
 
 def config_c2(seed=2):
