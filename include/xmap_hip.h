@@ -335,6 +335,24 @@ int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I
 int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *U, const xmap_path_rows *R,
                       const xmap_path_out *O, int fast_div, int64_t *d_counters, int64_t *h_counters);
 
+/* ---- planning steps of stage B (round 1 did these with torch ops on the device) ----------------------------------
+ * xmap_nb_index : nb_list = the non-bridge records (cls == 2) in item order, nb_id[item] = position in it or -1.
+ * xmap_path_plan: work units of the enumeration from the exact per-start path counts (xmap_path_weights): starts in
+ *   [start_lo, start_hi) with more than `chunk` paths (chunk_div > 0: chunk = max(2^22, paths in the range / chunk_div))
+ *   are cut into ceil(paths / chunk) chunks with dedicated rows
+ *   (chunk doubles until their rows fit max_rows); units heaviest first (own stable radix sort), the chunks of a start
+ *   consecutive.  h_out = {units, heavy starts, rows, paths in the range, chunk used}; XMAP_ERR_CAPACITY with the
+ *   counts filled in when the unit arrays (cap_units entries each; heavy_unit0: one per heavy start) are too small
+ *   (call with cap_units = 0 and NULL arrays to size them).
+ * xmap_end_order: reorders the end universe (urank / uitem of xmap_end_universe, in place) so that every end sits
+ *   with the first column x whose end list {x} + NN(x) holds it: the ends of a column are then neighbours in a row. */
+int xmap_nb_index(void *stream, int32_t n_items, const uint8_t *cls, int32_t *nb_list, int32_t *nb_id, int64_t *h_n_nb);
+int xmap_path_plan(void *stream, int32_t n_items, const int64_t *paths, int32_t start_lo, int32_t start_hi, int64_t chunk,
+                   int64_t chunk_div, int64_t max_rows, int64_t cap_units, int32_t *unit_start, int32_t *unit_c, int32_t *unit_G,
+                   int32_t *unit_row, int32_t *heavy_unit0, int64_t *h_out);
+int xmap_end_order(void *stream, int32_t n_items, int top_k, int32_t n_nb, const int32_t *nb_list, const int32_t *kcnt,
+                   const int32_t *kcol, int32_t n_ends, int32_t *urank, int32_t *uitem);
+
 /* Candidate arrays from explicit X-Sim lists (an extended_simRDD that did not come from this engine,
  * e.g. a canonically re-fed one): CSR (xs_ptr, xs_end, xs_val) -> n_cand, top_end, top_val as above. */
 int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end,

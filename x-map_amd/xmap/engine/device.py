@@ -537,45 +537,28 @@ class Engine(object):
             check(lib.xmap_path_weights(st, i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(R.flags),
                                         vp(E.att[0]), vp(E.att[1]), vp(E.src[0]), vp(E.src[1]), vp(E.src[3]),
                                         vp(E.rnn[0]), vp(E.rnn[1]), vp(tmp), vp(P)))
-        # planning on the device (a numpy argsort of the starts alone was 15 ms of host time per pass)
-        p = P[:I].clone()
+        # planning in the library (xmap_path_plan: chunk counts, heaviest-first order by its own radix sort, unit arrays)
         if start_split is not None:   # (rank, world): contiguous start ranges of equal path counts
             from .sharded import balanced_ranges
-            start_range = balanced_ranges(p.cpu().numpy(), start_split[1])[start_split[0]]
+            start_range = balanced_ranges(P[:I].cpu().numpy(), start_split[1])[start_split[0]]
         lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
-        p[:lo] = 0
-        p[hi:] = 0
-        total = int(p.sum().item())
-        if chunk is None:
-            chunk = max(1 << 22, total // int(os.environ.get("XMAP_CHUNK_DIV", "8192")))
         row_bytes = 36 * max(I, 1)
         row_budget = int(float(os.environ.get("XMAP_ROW_BUDGET_GB", row_budget / (1 << 30))) * (1 << 30))
-        while True:
-            G = torch.where(p > chunk, (p + (chunk - 1)) // chunk, (p > 0).to(torch.int64))
-            n_rows = int(G[G > 1].sum().item())
-            if n_rows * row_bytes <= row_budget or chunk > total:
-                break
-            chunk *= 2
-        starts = torch.nonzero(G > 0).flatten()
-        cost = p[starts].double() / G[starts].clamp(min=1).double()
-        order = starts[torch.sort(-cost, stable=True).indices]
-        g = G[order]
-        unit_start = torch.repeat_interleave(order, g).to(torch.int32)
-        first = torch.cumsum(g, 0) - g
-        n_units = int(unit_start.numel())
-        unit_c = (torch.arange(n_units, dtype=torch.int64, device=self.dev) - torch.repeat_interleave(first, g)).to(torch.int32)
-        unit_G = torch.repeat_interleave(g, g).to(torch.int32)
-        heavy = g > 1
-        gh = torch.where(heavy, g, torch.zeros_like(g))
-        row0 = torch.cumsum(gh, 0) - gh
-        unit_row = torch.where(torch.repeat_interleave(heavy, g), torch.repeat_interleave(row0, g) + unit_c.long(),
-                               torch.full((n_units,), -1, dtype=torch.int64, device=self.dev)).to(torch.int32)
-        heavy_unit0 = first[heavy].to(torch.int32)
-        t = lambda a: a.contiguous() if a.numel() else torch.zeros(1, dtype=a.dtype, device=self.dev)
+        max_rows = max(row_budget // row_bytes, 2)
+        cap_units = max(I, 1) + max_rows
         U = ExtResult()
-        U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = n_units, int(heavy_unit0.numel()), n_rows, total, int(chunk)
-        U.unit_start, U.unit_c, U.unit_G, U.unit_row = t(unit_start), t(unit_c), t(unit_G), t(unit_row)
-        U.heavy_unit0 = t(heavy_unit0)
+        U.unit_start = self._empty(cap_units, torch.int32)
+        U.unit_c = self._empty(cap_units, torch.int32)
+        U.unit_G = self._empty(cap_units, torch.int32)
+        U.unit_row = self._empty(cap_units, torch.int32)
+        U.heavy_unit0 = self._empty(max(I, 1), torch.int32)
+        h = (C.c_int64 * 5)()
+        with self.timed("path_plan"):
+            check(lib.xmap_path_plan(st, i32(I), vp(P), i32(lo), i32(hi), i64(chunk or 0),
+                                     i64(0 if chunk else int(os.environ.get("XMAP_CHUNK_DIV", "8192"))), i64(max_rows),
+                                     i64(cap_units), vp(U.unit_start), vp(U.unit_c), vp(U.unit_G), vp(U.unit_row),
+                                     vp(U.heavy_unit0), h))
+        U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = int(h[0]), int(h[1]), int(h[2]), int(h[3]), int(h[4])
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
@@ -592,22 +575,11 @@ class Engine(object):
         n = C.c_int64(0)
         check(lib.xmap_end_universe(st, C.byref(T), vp(mark), vp(rank), vp(E.urank), vp(E.uitem), C.byref(n)))
         E.n_ends = int(n.value)
-        if os.environ.get("XMAP_URANK_HOME", "1") == "1" and E.n_ends:
-            # row order: the ends of a column side by side (a column's row update then touches few lines): every end is
-            # placed with the first column x whose end list {x} + NN(x) holds it
-            nU = E.n_ends
-            nb = torch.nonzero(E.cls[:I] == 2).flatten()
-            cnt = E.kcnt[nb, 1].long()
-            k = E.k
-            cols = torch.cat([nb, torch.repeat_interleave(nb, cnt)])
-            q = torch.arange(k, device=self.dev)[None, :] < cnt[:, None]
-            ends = torch.cat([nb, E.kcol[nb, 1, :][q].long()])
-            home = torch.full((max(I, 1),), 1 << 40, dtype=torch.int64, device=self.dev)
-            home.scatter_reduce_(0, ends, cols, "amin")
-            u = E.uitem[:nU].long()
-            o = torch.sort(home[u] * (1 << 20) + u).indices
-            E.uitem[:nU] = u[o].to(torch.int32)
-            E.urank[E.uitem[:nU].long()] = torch.arange(nU, dtype=torch.int32, device=self.dev)
+        M = getattr(E, "mid", None)
+        if os.environ.get("XMAP_URANK_HOME", "1") == "1" and E.n_ends and M is not None:
+            # row order: the ends of a column side by side (a column's row update then touches few lines)
+            check(lib.xmap_end_order(st, i32(I), E.k, i32(M.n_nb), vp(M.nb_list), vp(E.kcnt), vp(E.kcol), i32(E.n_ends),
+                                     vp(E.urank), vp(E.uitem)))
 
     def _ext_tables(self, E, M):
         R = self.R
@@ -628,16 +600,19 @@ class Engine(object):
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
-        nb_list = torch.nonzero(E.cls[:I] == 2).flatten().to(torch.int32).contiguous()
-        n_nb = int(nb_list.numel())
+        nb_list = self._empty(max(I, 1), torch.int32)
+        nb_id = self._empty(max(I, 1), torch.int32)
+        nn = C.c_int64(0)
+        check(lib.xmap_nb_index(st, i32(I), vp(E.cls), vp(nb_list), vp(nb_id), C.byref(nn)))
+        n_nb = int(nn.value)
+        nb_list = nb_list[:n_nb]
         if rows is None:
             rows = n_nb <= abi.MID_ROWS_MAX and os.environ.get("XMAP_MID_TABLE") != "1"
         if n_nb == 0 or (not rows and n_nb * n_nb * 12 > table_budget):
             return None
         M = ExtResult()
         M.n_nb, M.nb_list = n_nb, nb_list
-        M.nb_id = torch.full((max(I, 1),), -1, dtype=torch.int32, device=self.dev)
-        M.nb_id[nb_list.long()] = torch.arange(n_nb, dtype=torch.int32, device=self.dev)
+        M.nb_id = nb_id
         common = (i32(I), E.k, vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(R.flags), vp(E.att[0]), vp(E.att[1]),
                   vp(E.att[2]), vp(E.src[0]), vp(E.src[1]), vp(E.src[2]), vp(E.src[3]), i32(n_nb), vp(M.nb_list),
                   vp(M.nb_id))
