@@ -395,6 +395,44 @@ int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_s
                        const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item,
                        double *out_rating, int64_t *out_time);
 
+/* ==== coarse, handle-based entry points =============================================================
+ * What a host in any language binds to replace the three pipelines: plain host buffers in, plain host buffers out,
+ * sizes reported by the stage call; the library owns every device buffer, prefix sum, overflow retry and work-unit
+ * plan (csrc/api.hip).  All ids are int32 indices into the caller's lexicographically sorted id tables; the four
+ * per-item predicate arrays are the string tests of the reference evaluated once per item (xmap/engine/ids.py):
+ * prefix_cls (iid[:2] class, baselinerSim.py:191), suffix_cls (iid[-2:] class), contains_mask (bit c: the suffix of
+ * class c occurs in the id, extender.py:29-35), flags (bit 0 "S:" in iid, bit 1 "T:" in iid).
+ *   xmap_ctx_upload_ratings : trainRDD in index space, CSR by user in trainRDD / profile order      (assist.py:66)
+ *   xmap_ctx_item_sim       : baseliner_calculate_sim_pipeline (assist.py:66-77) -> n_kept directed pairs kept
+ *   xmap_ctx_sim_download   : CSR by first item (row_ptr [I+1], col/sim/mutu/n_ij [n_kept]; rows not sorted), item info
+ *                             [I][4], user averages [U]; any pointer may be NULL
+ *   xmap_ctx_extend         : extender_pipeline (assist.py:80-102), lazy: per start item the number of candidates and
+ *                             the XMAP_TOPC best by (|xsim| desc, end asc); n_out = sum of the candidate counts
+ *   xmap_ctx_ext_lists      : the (start, [(end, xsim)*]) lists themselves (xs_off [I], xs_end/xs_val [n_out]): the
+ *                             enumeration runs once more into buffers of exactly n_out entries
+ *   xmap_ctx_candidates     : n_top[start] = min(candidates, 4): what cross_nonprivate_mapping draws from
+ *                             (generator.py:109-110); the caller draws picks[start] in [0, n_top - 1) itself
+ *   xmap_ctx_generate       : generator_pipeline (assist.py:136-150): private: arg-max |xsim|; else picks [I];
+ *                             choice [I] (or NULL) receives the chosen source item per start (-1: none)
+ *   xmap_ctx_gen_download   : AlterEgo rows (user, item, rating fp64, time), pass-through target rows first
+ * Errors: negative return code, text in xmap_last_error(). */
+typedef struct xmap_ctx xmap_ctx;
+int xmap_ctx_create(int device, xmap_ctx **out);
+void xmap_ctx_destroy(xmap_ctx *ctx);
+int xmap_ctx_upload_ratings(xmap_ctx *ctx, int64_t n_users, int32_t n_items, const int64_t *user_ptr, const int32_t *item,
+                            const float *rating, const int64_t *time, const int32_t *prefix_cls, const int32_t *suffix_cls,
+                            const uint32_t *contains_mask, const uint8_t *flags);
+int xmap_ctx_item_sim(xmap_ctx *ctx, int method, int cap, int64_t *n_kept, int64_t *n_evaluated);
+int xmap_ctx_sim_download(xmap_ctx *ctx, int64_t *row_ptr, int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *info,
+                          double *user_avg);
+int xmap_ctx_extend(xmap_ctx *ctx, int top_k, int64_t *n_out, int64_t *n_paths);
+int xmap_ctx_ext_download(xmap_ctx *ctx, int32_t *n_cand, int32_t *top_end, double *top_val);
+int xmap_ctx_ext_lists(xmap_ctx *ctx, int64_t *xs_off, int32_t *xs_end, double *xs_val);
+int xmap_ctx_candidates(xmap_ctx *ctx, int32_t *n_top);
+int xmap_ctx_generate(xmap_ctx *ctx, int private_flag, const int32_t *picks, int32_t *choice, int64_t *n_rows,
+                      int64_t *n_target_rows);
+int xmap_ctx_gen_download(xmap_ctx *ctx, int32_t *user, int32_t *item, double *rating, int64_t *time);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,10 @@ void set_error(const char *fmt, ...);
         }                                                                   \
     } while (0)
 
+// Temporaries of one entry-point call: the library's own per-stream arenas (util.hip), not hipMallocAsync.
+hipError_t xm_malloc_async(void **p, size_t bytes, hipStream_t st);
+hipError_t xm_free_async(void *p, hipStream_t st);
+
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

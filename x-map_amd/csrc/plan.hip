@@ -68,8 +68,8 @@ static int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals,
     const int n_blocks = (int)((n + RS_TILE - 1) / RS_TILE);
     int *hist = nullptr;
     long long *off = nullptr;
-    XM_HIP(hipMallocAsync((void **)&hist, sizeof(int) * (size_t)16 * n_blocks, st));
-    XM_HIP(hipMallocAsync((void **)&off, sizeof(long long) * ((size_t)16 * n_blocks + 1), st));
+    XM_HIP(xm_malloc_async((void **)&hist, sizeof(int) * (size_t)16 * n_blocks, st));
+    XM_HIP(xm_malloc_async((void **)&off, sizeof(long long) * ((size_t)16 * n_blocks + 1), st));
     unsigned long long *ka = keys, *kb = keys_tmp;
     int *va = vals, *vb = vals_tmp;
     int passes = 0;
@@ -87,8 +87,8 @@ static int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals,
         XM_HIP(hipMemcpyAsync(keys, ka, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, st));
         XM_HIP(hipMemcpyAsync(vals, va, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
-    XM_HIP(hipFreeAsync(hist, st));
-    XM_HIP(hipFreeAsync(off, st));
+    XM_HIP(xm_free_async(hist, st));
+    XM_HIP(xm_free_async(off, st));
     return XMAP_OK;
 }
 
@@ -185,8 +185,8 @@ int xmap_nb_index(void *stream, int32_t n_items, const uint8_t *cls, int32_t *nb
     hipStream_t st = (hipStream_t)stream;
     int *flag = nullptr;
     long long *rank = nullptr;
-    XM_HIP(hipMallocAsync((void **)&flag, sizeof(int) * (size_t)n_items, st));
-    XM_HIP(hipMallocAsync((void **)&rank, sizeof(long long) * ((size_t)n_items + 1), st));
+    XM_HIP(xm_malloc_async((void **)&flag, sizeof(int) * (size_t)n_items, st));
+    XM_HIP(xm_malloc_async((void **)&rank, sizeof(long long) * ((size_t)n_items + 1), st));
     const dim3 grid((unsigned)((n_items + 255) / 256)), block(256);
     k_flag_cls<<<grid, block, 0, st>>>(n_items, cls, 2, flag);
     XM_LAUNCH_CHECK();
@@ -194,8 +194,8 @@ int xmap_nb_index(void *stream, int32_t n_items, const uint8_t *cls, int32_t *nb
     if (rc) return rc;
     k_nb_fill<<<grid, block, 0, st>>>(n_items, flag, rank, nb_list, nb_id);
     XM_LAUNCH_CHECK();
-    XM_HIP(hipFreeAsync(flag, st));
-    XM_HIP(hipFreeAsync(rank, st));
+    XM_HIP(xm_free_async(flag, st));
+    XM_HIP(xm_free_async(rank, st));
     return XMAP_OK;
 }
 
@@ -212,11 +212,11 @@ int xmap_path_plan(void *stream, int32_t n_items, const int64_t *paths, int32_t 
     int *ibuf = nullptr;
     long long *lbuf = nullptr;
     unsigned long long *keys = nullptr;
-    XM_HIP(hipMallocAsync((void **)&ibuf, sizeof(int) * (size_t)I * 7, st));
+    XM_HIP(xm_malloc_async((void **)&ibuf, sizeof(int) * (size_t)I * 7, st));
     int *G = ibuf, *flag = G + I, *vals = flag + I, *vals_t = vals + I, *gs = vals_t + I, *gh = gs + I, *ish = gh + I;
-    XM_HIP(hipMallocAsync((void **)&lbuf, sizeof(long long) * ((size_t)4 * (I + 1) + 2), st));
+    XM_HIP(xm_malloc_async((void **)&lbuf, sizeof(long long) * ((size_t)4 * (I + 1) + 2), st));
     long long *cnt = lbuf, *rank = cnt + 2, *uoff = rank + (I + 1), *roff = uoff + (I + 1), *hrank = roff + (I + 1);
-    XM_HIP(hipMallocAsync((void **)&keys, sizeof(unsigned long long) * (size_t)I * 2, st));
+    XM_HIP(xm_malloc_async((void **)&keys, sizeof(unsigned long long) * (size_t)I * 2, st));
     unsigned long long *keys_t = keys + I;
     long long h_cnt[2];
     if (chunk_div > 0) {    // chunk from the total: max(2^22, paths in the range / chunk_div)
@@ -260,9 +260,9 @@ int xmap_path_plan(void *stream, int32_t n_items, const int64_t *paths, int32_t 
             XM_LAUNCH_CHECK();
         }
     }
-    XM_HIP(hipFreeAsync(ibuf, st));
-    XM_HIP(hipFreeAsync(lbuf, st));
-    XM_HIP(hipFreeAsync(keys, st));
+    XM_HIP(xm_free_async(ibuf, st));
+    XM_HIP(xm_free_async(lbuf, st));
+    XM_HIP(xm_free_async(keys, st));
     h_out[0] = n_units; h_out[1] = n_heavy; h_out[2] = n_rows; h_out[3] = h_cnt[1]; h_out[4] = chunk;
     if (n_units > cap_units) {
         set_error("unit arrays too small: need %lld, have %lld", (long long)n_units, (long long)cap_units);
@@ -279,9 +279,9 @@ int xmap_end_order(void *stream, int32_t n_items, int top_k, int32_t n_nb, const
     hipStream_t st = (hipStream_t)stream;
     int *home = nullptr, *vt = nullptr;
     unsigned long long *keys = nullptr;
-    XM_HIP(hipMallocAsync((void **)&home, sizeof(int) * ((size_t)n_items + n_ends), st));
+    XM_HIP(xm_malloc_async((void **)&home, sizeof(int) * ((size_t)n_items + n_ends), st));
     vt = home + n_items;
-    XM_HIP(hipMallocAsync((void **)&keys, sizeof(unsigned long long) * (size_t)n_ends * 2, st));
+    XM_HIP(xm_malloc_async((void **)&keys, sizeof(unsigned long long) * (size_t)n_ends * 2, st));
     XM_HIP(hipMemsetAsync(home, 0x7f, sizeof(int) * (size_t)n_items, st));      // 0x7f7f7f7f: after every column
     const long long n = (long long)n_nb * (top_k + 1);
     k_end_home<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n_nb, top_k, nb_list, kcnt, kcol, home);
@@ -293,8 +293,8 @@ int xmap_end_order(void *stream, int32_t n_items, int top_k, int32_t n_nb, const
     if (rc) return rc;
     k_inverse<<<grid, block, 0, st>>>(n_ends, uitem, urank);
     XM_LAUNCH_CHECK();
-    XM_HIP(hipFreeAsync(home, st));
-    XM_HIP(hipFreeAsync(keys, st));
+    XM_HIP(xm_free_async(home, st));
+    XM_HIP(xm_free_async(keys, st));
     return XMAP_OK;
 }
 }

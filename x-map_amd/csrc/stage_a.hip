@@ -548,7 +548,7 @@ int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int3
     XM_ARG(R && Q && W && unit_ptr && slot_target > 0 && slot_target <= SLOTS);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d_contrib = nullptr;
-    XM_HIP(hipMallocAsync((void **)&d_contrib, sizeof(unsigned long long), st));
+    XM_HIP(xm_malloc_async((void **)&d_contrib, sizeof(unsigned long long), st));
     XM_HIP(hipMemsetAsync(d_contrib, 0, sizeof(unsigned long long), st));
     if (R->n_items > 0) {
         k_plan<<<dim3((unsigned)((R->n_items + 3) / 4)), dim3(256), 0, st>>>(
@@ -561,7 +561,7 @@ int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int3
     unsigned long long hc = 0;
     XM_HIP(hipMemcpyAsync(&hc, d_contrib, sizeof(hc), hipMemcpyDeviceToHost, st));
     XM_HIP(hipStreamSynchronize(st));
-    XM_HIP(hipFreeAsync(d_contrib, st));
+    XM_HIP(xm_free_async(d_contrib, st));
     if (h_contrib) *h_contrib = (int64_t)hc;
     return XMAP_OK;
 }
@@ -624,11 +624,11 @@ int xmap_sim_fill(void *stream, const xmap_ratings *R, int method, int cap, cons
     A.nij = nij;
     unsigned long long *dummy = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    XM_HIP(hipMallocAsync((void **)&dummy, 4 * sizeof(unsigned long long), st));
+    XM_HIP(xm_malloc_async((void **)&dummy, 4 * sizeof(unsigned long long), st));
     XM_HIP(hipMemsetAsync(dummy, 0, 4 * sizeof(unsigned long long), st));
     A.counters = dummy;
     int rc = launch_pair(st, method, true, A);
-    XM_HIP(hipFreeAsync(dummy, st));
+    XM_HIP(xm_free_async(dummy, st));
     return rc;
 }
 }

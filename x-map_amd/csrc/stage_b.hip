@@ -2046,7 +2046,7 @@ int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_uni
         ColEnd *cend = nullptr;
         if (T->n_nb > 0) {
             const long long n = (long long)T->n_nb * (T->top_k + 1);
-            XM_HIP(hipMallocAsync((void **)&cend, sizeof(ColEnd) * (size_t)n, st));
+            XM_HIP(xm_malloc_async((void **)&cend, sizeof(ColEnd) * (size_t)n, st));
             k_col_ends<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(T->n_nb, T->top_k, T->nb_list, T->kcnt, T->kcol, T->kval,
                                                                                  T->urank, cend);
             XM_LAUNCH_CHECK();
@@ -2056,7 +2056,7 @@ int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_uni
         if (fast_div) k_paths4<true><<<grid, block, 0, st>>>(B);
         else k_paths4<false><<<grid, block, 0, st>>>(B);
         XM_LAUNCH_CHECK();
-        if (cend) XM_HIP(hipFreeAsync(cend, st));
+        if (cend) XM_HIP(xm_free_async(cend, st));
         if (Un->n_heavy > 0) {
             k_merge_groups<<<dim3((unsigned)Un->n_heavy, 16), dim3(64 * MERGE_WAVES), 0, st>>>(A, Un->n_heavy, Un->heavy_unit0);
             XM_LAUNCH_CHECK();

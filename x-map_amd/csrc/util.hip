@@ -1,5 +1,7 @@
 // util.hip -- error plumbing and the prefix sums every count->fill pair needs.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <vector>
 
 #include "common.h"
 
@@ -10,6 +12,52 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- temporaries of the library ----------------------------------------------------------------------------------------
+// Scratch that lives for one entry-point call (scan tile sums, sort histograms, planning arrays, the column end table).
+// Round 1 took it from the stream-ordered allocator (hipMallocAsync / hipFreeAsync).  Under the ROCm 7.2 runtime of this
+// image that gave wrong results from the second pass of a process on (a block handed out again while kernels of the
+// same stream still read it; not with the 7.0 runtime PyTorch bundles -- INTEGRATION.md, "HIP runtime versions"), so
+// the library keeps its own arenas instead: one per (thread, device, stream), bump allocation inside a call, everything
+// recycled when the last temporary of the call is released.  Reuse is ordered by the stream itself: a later call on the
+// same stream runs after the kernels of the earlier one.
+namespace {
+struct Chunk { char *base; size_t size, used; };
+struct Arena { int dev; hipStream_t st; std::vector<Chunk> chunks; size_t live; };
+thread_local std::vector<Arena> g_arenas;
+Arena *arena_of(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (Arena &a : g_arenas) if (a.dev == dev && a.st == st) return &a;
+    g_arenas.push_back(Arena{dev, st, {}, 0});
+    return &g_arenas.back();
+}
+}  // namespace
+
+hipError_t xm_malloc_async(void **p, size_t bytes, hipStream_t st) {
+    Arena *a = arena_of(st);
+    if (!a) return hipErrorInvalidDevice;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (Chunk &c : a->chunks)
+        if (c.size - c.used >= bytes) { *p = c.base + c.used; c.used += bytes; a->live++; return hipSuccess; }
+    Chunk c;
+    c.size = bytes > ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
+    c.used = bytes;
+    hipError_t e = hipMalloc((void **)&c.base, c.size);
+    if (e != hipSuccess) return e;
+    a->chunks.push_back(c);
+    *p = c.base;
+    a->live++;
+    return hipSuccess;
+}
+hipError_t xm_free_async(void *p, hipStream_t st) {
+    (void)p;
+    Arena *a = arena_of(st);
+    if (!a || a->live == 0) return hipErrorInvalidValue;
+    if (--a->live == 0) for (Chunk &c : a->chunks) c.used = 0;
+    return hipSuccess;
 }
 
 // ---- three-kernel exclusive scan: tile sums -> scan of tile sums (one block) -> tile scans ----
@@ -93,7 +141,7 @@ static int exclusive_scan(hipStream_t st, const TIn *in, int64_t *out, int64_t n
     // out[n] doubles as the grand total; tile offsets live in a small temporary
     int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     long long *tile = nullptr;
-    XM_HIP(hipMallocAsync((void **)&tile, sizeof(long long) * (size_t)(n_tiles + 1), st));
+    XM_HIP(xm_malloc_async((void **)&tile, sizeof(long long) * (size_t)(n_tiles + 1), st));
     if (n_tiles > 0) {
         k_tile_sums<TIn><<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st>>>(in, n, tile);
         XM_LAUNCH_CHECK();
@@ -104,7 +152,7 @@ static int exclusive_scan(hipStream_t st, const TIn *in, int64_t *out, int64_t n
         k_tile_scan<TIn><<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st>>>(in, n, tile, (long long *)out);
         XM_LAUNCH_CHECK();
     }
-    XM_HIP(hipFreeAsync(tile, st));
+    XM_HIP(xm_free_async(tile, st));
     if (h_total) {
         XM_HIP(hipMemcpyAsync(h_total, out + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         XM_HIP(hipStreamSynchronize(st));

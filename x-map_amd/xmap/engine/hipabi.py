@@ -70,6 +70,8 @@ EXPORTS = [
     "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_bridge_flags", "xmap_knn_classify", "xmap_knn_thresholds", "xmap_reverse_count",
     "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", "xmap_mid_tally", "xmap_mid_place",
     "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_extend_paths2", "xmap_end_universe", "xmap_extend_cols", "xmap_nb_index", "xmap_path_plan", "xmap_end_order", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
+    "xmap_ctx_create", "xmap_ctx_destroy", "xmap_ctx_upload_ratings", "xmap_ctx_item_sim", "xmap_ctx_sim_download", "xmap_ctx_extend",
+    "xmap_ctx_ext_download", "xmap_ctx_ext_lists", "xmap_ctx_candidates", "xmap_ctx_generate", "xmap_ctx_gen_download",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -91,7 +93,7 @@ def header_prototypes(path=HEADER_PATH):
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
     out = {}
-    for m in re.finditer(r"\b(?:int|const\s+char\s*\*)\s*(xmap_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|const\s+char\s*\*)\s*(xmap_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         name, args = m.group(1), " ".join(m.group(2).split())
         types = []
         for a in ([] if args in ("", "void") else args.split(",")):
@@ -114,7 +116,9 @@ PROTOTYPES = header_prototypes()
 for _n, _t in PROTOTYPES.items():
     _f = getattr(lib, _n)
     _f.argtypes = _t
-    if _n != "xmap_last_error":
+    if _n == "xmap_ctx_destroy":
+        _f.restype = None
+    elif _n != "xmap_last_error":
         _f.restype = C.c_int
 
 
