@@ -338,6 +338,7 @@ def main():
         ach_b = bytes_paths / (paths_ms * 1e-3) / 1e9 if paths_ms > 0 else 0.0
         rf_b = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
                 "traffic": tr_b, "traffic_ratio": (tr_b / bytes_paths) if (tr_b and bytes_paths) else None,
+                "traffic_fetch_x1": pmc_traffic("k_paths4_fetch_x1"),     # FETCH_SIZE as is: exact for lone 32-byte reads (profiles/README.md)
                 "algorithmic_bytes_per_launch": bytes_paths, "launch_ms": paths_ms,
                 "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
                 "note": "per column (start, x): one set of lanes (W ends x S record slices) and one read-modify-write of the "

@@ -38,7 +38,10 @@ def main(fetch_csv, write_csv, tag, dense_fetch=None, dense_write=None):
                        "passes, profiles/%s_c2_pmc_*.csv); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction); "
                        "k_pair_tri = sum over its table-class launches (one logical pass)" % tag,
            "k_pair_tri": tot(lambda k: k.startswith("k_pair_tri")),
-           "k_paths4": tot(lambda k: k.startswith("k_paths4")), "k_paths2": tot(lambda k: k == "k_paths2"), "k_scatter": tot(lambda k: k == "k_scatter"),
+           "k_paths4": tot(lambda k: k.startswith("k_paths4")),
+           # lower reading for k_paths4: FETCH_SIZE taken as is (exact for 32- and 64-byte random reads, measured with
+           # profiles/rand_rmw_grp.hip under --pmc: README, "FETCH_SIZE correction")
+           "k_paths4_fetch_x1": sum(v["FETCH_SIZE_bytes"] + v["WRITE_SIZE_bytes"] for k, v in raw.items() if k.startswith("k_paths4")), "k_paths2": tot(lambda k: k == "k_paths2"), "k_scatter": tot(lambda k: k == "k_scatter"),
            "k_knn_classify": tot(lambda k: k == "k_knn_classify"), "k_sort_profiles": tot(lambda k: k == "k_sort_profiles"),
            "k_csc_fill": tot(lambda k: k == "k_csc_fill"), "k_dense_topk": tot(lambda k: k.startswith("k_dense_topk")) or None,
            "raw": raw}
