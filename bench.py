@@ -164,6 +164,64 @@ def bench_dense(args, rank, world, local, dist):
         emit(out)
 
 
+def bench_multidomain(args, rank, world, local, dist):
+    """--workload c4: BASELINE.json configs[3] shape -- 4 source domains -> 1 target, ~5M users in total (1.25 M per
+    two-domain problem), top-k 100, private mapping.  The domains are dealt to rank groups (xmap.engine.multidomain);
+    a step = all domains once + the union of the AlterEgo rows.  Ratings are generated and uploaded inside the step's
+    make_engine (one domain resident at a time on a rank); that set-up is timed separately and excluded."""
+    from xmap.engine import device, synth, multidomain
+    dev = "cuda:%d" % local
+    k = args.k or 100
+    n_dom = 4
+    t0 = time.time()
+    doms = synth.config_c4()
+    log("setup: %d domains generated in %.1f s" % (n_dom, time.time() - t0))
+    engines = {}
+    up = [0.0]
+
+    def make_engine(d):
+        t1 = time.time()
+        if d not in engines:
+            engines.clear()                 # one domain resident at a time
+            torch.cuda.empty_cache()
+            r = doms[d]
+            engines[d] = (device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev)),
+                          r.n_src_items)
+            torch.cuda.synchronize()
+        up[0] += time.time() - t1
+        return engines[d]
+
+    walls = []
+    out = None
+    for it in range(args.warmup + args.steps):
+        up[0] = 0.0
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t1 = time.time()
+        out = multidomain.run_multidomain(make_engine, n_dom, args.method, CAP, k, True, dist)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        if it >= args.warmup:
+            walls.append(time.time() - t1 - up[0])
+    wall = float(np.sum(walls))
+    if dist:
+        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    if rank == 0:
+        users = len(np.unique(out["user"]))
+        emit({"metric": "alterego_profiles_per_s", "value": users * args.steps / wall, "unit": "profiles/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": "4 source domains -> 1 target, 1.25M users per two-domain problem, top-k=%d, private mapping "
+                                     "(BASELINE configs[3] shape)" % k,
+                         "parallelism": "domains dealt to %d rank group(s)" % min(world, n_dom), "domains": n_dom,
+                         "paths_per_domain": [int(x) for x in out["n_paths"]], "rows_per_domain": [int(x) for x in out["n_rows"]],
+                         "alterego_rows": int(len(out["user"])), "profiles": users}})
+
+
 def bench_recsim(args, rank, world, local, dist):
     """--workload recsim: RecommenderSim.calculate_sim over the AlterEgo rows the hot path produces at
     BASELINE configs[1] (one GPU; the rows come out of one untimed pass of the three pipelines)."""
@@ -270,6 +328,12 @@ def main():
 
     if args.workload == "recsim":
         bench_recsim(args, rank, world, local, dist)
+        return
+    if args.workload == "c4":
+        bench_multidomain(args, rank, world, local, dist)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if args.workload == "dense":
         bench_dense(args, rank, world, local, dist)

@@ -82,7 +82,8 @@ int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *
  * Only the complete-rows formulation (xmap_sim_count / xmap_sim_fill) reads them: pass both NULL to skip them. */
 int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info /*[I][4]*/,
                     double *norms /*[2][I] dense copies of norm2 / adjnorm2, may be NULL*/,
-                    int32_t *ua_item /*[nnz] or NULL*/, int32_t *ia_user /*[nnz] or NULL*/);
+                    int32_t *ua_item /*[nnz] or NULL*/, int32_t *ia_user /*[nnz] or NULL*/,
+                    int32_t item_lo, int32_t item_hi /*items [lo, hi): a rank's share when items are sharded (0, n_items: all)*/);
 
 /* Work decomposition for the pair kernel: unit = (item i, hash partition q of its partner space),
  * Q[i] = ceil(min(W_i, I-1) / slot_target), W_i = sum over raters of (profile length - 1).
@@ -193,7 +194,8 @@ int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls
  * cls[i] = 0 none, 1 bridge record, 2 non-bridge record. kval = (sim, mutu, frac_mutu) fp64. */
 int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt /*[I][2]*/,
-                      int32_t *kcol /*[I][2][k]*/, double *kval /*[I][2][k][3]*/);
+                      int32_t *kcol /*[I][2][k]*/, double *kval /*[I][2][k][3]*/,
+                      int32_t row_lo, int32_t row_hi /*rows [lo, hi): a rank's share (0, n_items: all)*/);
 
 /* Reverse adjacencies of the knn tables, built deterministically in row order:
  *   mode 0 ATTACH: attach(b) = [x : x non-bridge record, b in NB_BB(x)]   (core/extender.py:48-59,171-173)

@@ -245,7 +245,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     XM_ALLOCZ(c->p_sim, c->info, (size_t)I * 4);
     T_ALLOCZ(norms, (size_t)2 * I);
     XM_TRY(xmap_user_stats(c->st, &R, c->u_avg, c->u_norm));
-    XM_TRY(xmap_item_stats(c->st, &R, c->u_avg, c->info, norms, nullptr, nullptr));
+    XM_TRY(xmap_item_stats(c->st, &R, c->u_avg, c->info, norms, nullptr, nullptr, 0, I));
     // layout of the "tri" formulation
     int32_t *hist, *ctl, *hid, *hlist;
     int64_t *pre;
@@ -378,7 +378,7 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
     XM_ALLOCZ(c->p_ext, bb, I); XM_ALLOCZ(c->p_ext, cls, I); XM_ALLOCZ(c->p_ext, kcnt, (size_t)I * 2);
     XM_ALLOCZ(c->p_ext, kcol, (size_t)I * 2 * k); XM_ALLOCZ(c->p_ext, kval, (size_t)I * 2 * k * 3);
     XM_TRY(xmap_bridge_flags(c->st, &c->S, c->R.prefix_cls, bb));
-    XM_TRY(xmap_knn_classify(c->st, &c->S, k, bb, c->R.suffix_cls, c->R.contains_mask, cls, kcnt, kcol, kval));
+    XM_TRY(xmap_knn_classify(c->st, &c->S, k, bb, c->R.suffix_cls, c->R.contains_mask, cls, kcnt, kcol, kval, 0, I));
     T.cls = cls; T.kcnt = kcnt; T.kcol = kcol; T.kval = kval;
     // B5a/b: reverse adjacencies
     double *thr;

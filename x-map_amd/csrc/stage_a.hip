@@ -200,19 +200,20 @@ __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, 
 
 // four items per wave: the ones with at most 64 raters (99 % at BASELINE configs[1]; the median item has 10) together,
 // one per 16-lane group; the others one after the other on the whole wave
-__global__ __launch_bounds__(256) void k_item_stats(int I, const long long *iptr, const int *iuser, const float *irating,
+// items [lo, hi) (a rank's share when the items are sharded: the per-item results are all-gathered afterwards)
+__global__ __launch_bounds__(256) void k_item_stats(int I, int lo, int hi, const long long *iptr, const int *iuser, const float *irating,
                                                     const double *u_avg, double *info, double *norms, int *ia_user) {
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (i0 >= I) return;
+    const int i0 = lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (i0 >= hi) return;
     const int lane = lane_id();
     {
         const int i = i0 + (lane >> 4);
-        const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
+        const bool on = i < hi && iptr[i + 1] - iptr[i] <= 64;
         item_stats_group<16>(on, i, lane & 15, I, iptr, iuser, irating, u_avg, info, norms, ia_user);
     }
     for (int t = 0; t < 4; t++) {
         const int i = i0 + t;
-        if (i >= I) break;
+        if (i >= hi) break;
         if (iptr[i + 1] - iptr[i] <= 64) continue;
         item_stats_group<64>(true, i, lane, I, iptr, iuser, irating, u_avg, info, norms, ia_user);
     }
@@ -526,13 +527,13 @@ int xmap_user_stats(void *stream, const xmap_ratings *R, double *u_avg, double *
 }
 
 int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, double *info, double *norms,
-                    int32_t *ua_item, int32_t *ia_user) {
+                    int32_t *ua_item, int32_t *ia_user, int32_t item_lo, int32_t item_hi) {
     XM_ARG(R && u_avg && info && ((ua_item != nullptr) == (ia_user != nullptr)));
-    XM_ARG(R->nnz < 0x7fffffffLL);
+    XM_ARG(R->nnz < 0x7fffffffLL && item_lo >= 0 && item_lo <= item_hi && item_hi <= R->n_items);
     hipStream_t st = (hipStream_t)stream;
-    if (R->n_items > 0) {
-        k_item_stats<<<dim3((unsigned)((R->n_items + 15) / 16)), dim3(256), 0, st>>>(
-            R->n_items, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, norms, ia_user);
+    if (item_hi > item_lo) {
+        k_item_stats<<<dim3((unsigned)((item_hi - item_lo + 15) / 16)), dim3(256), 0, st>>>(
+            R->n_items, item_lo, item_hi, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, norms, ia_user);
         XM_LAUNCH_CHECK();
     }
     if (R->nnz > 0 && ua_item) {

@@ -64,7 +64,7 @@ __device__ __forceinline__ long long block_scan_ll(long long v, long long *total
 }
 
 struct KnnArgs {
-    int I, k;
+    int I, k, row_lo;
     const long long *row_ptr;
     const int *col;
     const double *sim;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
     __shared__ unsigned long long s_thrk[2];
     __shared__ int s_thrc[2], s_has[2], s_fill;
 
-    const int i = blockIdx.x;
+    const int i = blockIdx.x + A.row_lo;
     const int tid = threadIdx.x;
     const long long lo = A.row_ptr[i];
     const int n = (int)(A.row_ptr[i + 1] - lo);
@@ -1290,6 +1290,9 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
         int xmin = cur.x;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(xmin, m, 64); xmin = o < xmin ? o : xmin; }
+#ifdef Q_UNIMIN
+        xmin = uniform(xmin);
+#endif
         if (xmin == INF) break;
         const bool mine = cur.x == xmin;
         const unsigned long long part = __ballot(mine);
@@ -1681,16 +1684,18 @@ int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls
 }
 
 int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const int32_t *suffix_cls,
-                      const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt, int32_t *kcol, double *kval) {
+                      const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt, int32_t *kcol, double *kval,
+                      int32_t row_lo, int32_t row_hi) {
     XM_ARG(S && bb && suffix_cls && contains_mask && cls && kcnt && kcol && kval);
     XM_ARG(top_k >= 1 && 2 * top_k <= K_CH / 2);
-    if (S->n_items == 0) return XMAP_OK;
+    XM_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= S->n_items);
+    if (row_hi == row_lo) return XMAP_OK;
     KnnArgs A;
-    A.I = S->n_items; A.k = top_k;
+    A.I = S->n_items; A.k = top_k; A.row_lo = row_lo;
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
     A.info = S->info; A.frac = S->frac; A.bb = bb; A.suffix_cls = suffix_cls; A.contains_mask = contains_mask;
     A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
-    k_knn_classify<<<dim3((unsigned)S->n_items), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+    k_knn_classify<<<dim3((unsigned)(row_hi - row_lo)), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

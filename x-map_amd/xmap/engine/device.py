@@ -148,9 +148,10 @@ class Engine(object):
                                      vp(R.user_rating), vp(cnt), vp(R.item_ptr), vp(R.item_user), vp(R.item_rating)))
         R.csc_ready = True
 
-    def stats(self, packed=False):
+    def stats(self, packed=False, item_range=None):
         """A2 + A3: CSC layout, user info, item info and (packed=True: the complete-rows formulation needs them)
-        the flag-packed index copies."""
+        the flag-packed index copies.  item_range = (lo, hi): item info of that share only (item-sharded ranks
+        all-gather the rest: xmap.engine.sharded)."""
         R = self.R
         st = _stream(self.dev)
         self.build_csc()
@@ -161,7 +162,8 @@ class Engine(object):
         self.norms = self._out(2 * max(R.n_items, 1), torch.float64, R.n_items > 0)
         ua_item = self._empty(max(R.nnz, 1), torch.int32) if packed else None
         ia_user = self._empty(max(R.nnz, 1), torch.int32) if packed else None
-        check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user)))
+        lo, hi = (0, R.n_items) if item_range is None else (int(item_range[0]), int(item_range[1]))
+        check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user), i32(lo), i32(hi)))
         return u_avg, u_norm, info, ua_item, ia_user
 
     def plan(self, slot_target=640):
@@ -412,7 +414,7 @@ class Engine(object):
             zero_avg = self._zeros(max(R.n_users, 1), torch.float64)
             info = self._zeros((max(R.n_items, 1), 4), torch.float64)
             self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
-            check(lib.xmap_item_stats(st, C.byref(R.c), vp(zero_avg), vp(info), vp(self.norms), None, None))
+            check(lib.xmap_item_stats(st, C.byref(R.c), vp(zero_avg), vp(info), vp(self.norms), None, None, i32(0), i32(R.n_items)))
         stats = (zero_avg, None, info, None, None)
         L = self.tri_layout(stats, slot_target, ch_min=max(64, R.n_users + 2), dups=True)
         coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
@@ -484,8 +486,9 @@ class Engine(object):
         return S
 
     # ------------------------------------------------------------------ stage B
-    def knn(self, S, top_k, bb=None):
-        """B1-B4: bridge flags (computed, or given by the caller) + classified top-k lists."""
+    def knn(self, S, top_k, bb=None, rows=None):
+        """B1-B4: bridge flags (computed, or given by the caller) + classified top-k lists.  rows = (lo, hi): the lists of
+        that share of the items only (item-sharded ranks all-gather the tables)."""
         R = self.R
         st = _stream(self.dev)
         I, k = R.n_items, int(top_k)
@@ -501,8 +504,9 @@ class Engine(object):
         E.kcol = self._zeros((max(I, 1), 2, k), torch.int32)
         E.kval = self._zeros((max(I, 1), 2, k, 3), torch.float64)
         with self.timed("knn_classify"):
+            lo, hi = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
             check(lib.xmap_knn_classify(st, C.byref(S.c), k, vp(E.bb), vp(R.suffix_cls), vp(R.contains_mask),
-                                        vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval)))
+                                        vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval), i32(lo), i32(hi)))
         return E
 
     def _reverse(self, S, E, mode, attach_ptr):
@@ -697,10 +701,27 @@ class Engine(object):
         E.start_range = (0, I) if start_range is None else tuple(start_range)
         return E
 
-    def ext_tables(self, S, top_k):
-        """B1-B5b: bridge flags, classified top-k lists and the three reverse adjacencies (attach / src / rnn)"""
+    def ext_tables(self, S, top_k, comm=None):
+        """B1-B5b: bridge flags, classified top-k lists and the three reverse adjacencies (attach / src / rnn).
+        comm (xmap.engine.sharded.Comm of several ranks): every rank classifies a share of the rows -- contiguous ranges of
+        equal entry counts -- and the tables are all-gathered (the reference broadcasts them, utils/assist.py:93-95)."""
         I = self.R.n_items
-        E = self.knn(S, top_k)
+        rows = None
+        if comm is not None and comm.world > 1 and I > 0:
+            w = comm.world
+            tgt = (S.row_ptr[I].double() * torch.arange(1, w, dtype=torch.float64, device=self.dev) / w).long()
+            cuts = [0] + torch.searchsorted(S.row_ptr[:I + 1].contiguous(), tgt).clamp(max=I).tolist() + [I]
+            cuts = np.maximum.accumulate(np.asarray(cuts))
+            rows = (int(cuts[comm.rank]), int(cuts[comm.rank + 1]))
+        E = self.knn(S, top_k, rows=rows)
+        if rows is not None:
+            lo, hi = rows
+            with self.timed("knn_gather"):
+                k = E.k
+                E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
+                E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
+                E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)
+                E.kval[:I] = comm.all_gather_var(E.kval[lo:hi].reshape(-1)).view(I, 2, k, 3)
         st = _stream(self.dev)
         with self.timed("reverse"):
             E.thr = self._empty(max(I, 1) * 4, torch.float64)      # last entry of every list, 16 B each
@@ -773,9 +794,9 @@ class Engine(object):
         return E
 
     def extend(self, S, top_k, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
-               start_split=None, algo="cols"):
+               start_split=None, algo="cols", comm=None):
         """extender_pipeline: knn tables, reverse adjacencies, streamed path enumeration."""
-        return self.extend_tables(self.ext_tables(S, top_k), full, start_range, n_slots, xs_cap, chunk, start_split, algo)
+        return self.extend_tables(self.ext_tables(S, top_k, comm), full, start_range, n_slots, xs_cap, chunk, start_split, algo)
 
     def extend_lists(self, E):
         """the full X-Sim lists of a pass that kept the candidate arrays only (lazy extended_simRDD): the enumeration is

@@ -1,14 +1,16 @@
 """One pass of the hot path, optionally item-sharded over the ranks of one node.
 
 Sharding: inputs (CSR + CSC) are replicated in every GPU's HBM; the work is sharded by
-item.  Stage A: the work units (item, partition) of the pair kernel are split into contiguous ranges of
+item.  Stage A: the per-item statistics are computed for a share of the items and all-gathered (32 B x I: the all-gather of
+item norms); the work units (item, partition) of the pair kernel are split into contiguous ranges of
 equal rater-steps; each rank appends the kept pairs of its units to a half COO (every unordered pair is
 owned by exactly one unit, so there are no cross-GPU partials) and mirrors them into a CSR of its own:
 that is the rank's partition of item2item_simRDD (both directions of its pairs), and where stage A ends.  Stage B starts with the exchange its input needs (the reference
 broadcasts the knn tables, utils/assist.py:88-101): the per-item row counts are all-reduced, the COO parts
 all-gathered (S4/S6 of SURVEY 2.3) and every rank mirrors the full COO into the CSR; then
-the knn tables are derived from the full CSR on every rank (one HBM pass, cheaper than
-exchanging them), the path enumeration is sharded by start item (ranges of equal path counts), and the
+every rank classifies the top-k lists of a share of the rows and the knn tables are all-gathered (S7; round 1 rebuilt them
+everywhere), the reverse and middle lists are still derived on every rank, the path enumeration is sharded by start item
+(ranges of equal path counts), and the
 fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
 passes over nnz and is replicated.
 
@@ -126,7 +128,16 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
     # ---- stage A: every rank lays out the (replicated) ratings, computes the pairs of its share of the
     # work units into a half COO, the COO parts are all-gathered and mirrored into the full CSR everywhere
     with eng.timed("stage_a"):
-        stats = eng.stats()
+        # per-item statistics of a share of the items, then ONE all-gather of the 32-byte item records and the two dense
+        # norm columns (S3 of SURVEY 2.3: the reference collects and broadcasts item_info, utils/assist.py:71-73)
+        ilo, ihi = I * rank // world, I * (rank + 1) // world
+        stats = eng.stats(item_range=(ilo, ihi))
+        with eng.timed("stats_gather"):
+            info = stats[2]
+            info[:I] = comm.all_gather_var(info[ilo:ihi].reshape(-1)).view(I, 4)
+            nI = max(I, 1)
+            for c0 in (0, nI):
+                eng.norms[c0:c0 + I] = comm.all_gather_var(eng.norms[c0 + ilo:c0 + ihi].contiguous())
         L = eng.tri_layout(stats)
         while True:
             # contiguous unit ranges of equal rater-steps: prefix sum and cut points on the device (the units are listed
@@ -177,7 +188,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         err = None
         try:
             S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
-            E = eng.extend(S, k, full=False, start_split=(rank, world))
+            E = eng.extend(S, k, full=False, start_split=(rank, world), comm=comm)
         except Exception as e:
             err = e
         comm.agree(err, "stage B (extension)")
