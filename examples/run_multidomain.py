@@ -88,7 +88,8 @@ def main(argv=None):
         sim = assist.baseliner_calculate_sim_pipeline(sc, sim_tool, trainRDD)
         ext = assist.extender_pipeline(sc, sqlContext, sim_tool, ExtendSim(args.topk), sim)
         profile = assist.generator_pipeline(gen_tool, trainRDD, ext, True)
-        print("source %d: %d sim pairs, %d start items, %d AlterEgo rows" % (d + 1, sim.count(), ext.count(), profile.count()))
+        n_starts = int((ext.E.n_cand > 0).sum().item())     # the lazy handle's candidate counts (ext.count() would build the lists)
+        print("source %d: %d sim pairs, %d start items, %d AlterEgo rows" % (d + 1, sim.count(), n_starts, profile.count()))
         alterEgo = profile if alterEgo is None else alterEgo.union(profile)
     rsim = RecommenderSim("cosine_item", 50)
     _, _, ubd, ibd, uinfo, iinfo, alterEgo_sim = assist.recommender_calculate_sim_pipeline(sc, rsim, alterEgo.distinct())

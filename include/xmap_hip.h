@@ -332,6 +332,10 @@ typedef struct xmap_path_rows { int32_t n_slots; double *acc; int32_t *touched; 
 typedef struct xmap_path_out {
     int32_t *n_cand; int32_t *top_end; double *top_val; int64_t xs_cap; int64_t *xs_off; int32_t *xs_end; double *xs_val;
 } xmap_path_out;
+/* fast_div precondition of xmap_extend_cols over a similarity matrix: *h_fast_ok = 1 iff every kept pair has mutu >= 1
+ * and sim * mutu is zero or within 2^+-400 (always true for what stage A produces; 0 for a matrix that carries its own
+ * frac column, i.e. generic records).  One pass over the pairs; synchronises. */
+int xmap_edge_ranges(void *stream, const xmap_sim *S, int32_t *h_fast_ok);
 int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I] scratch*/, int64_t *rank /*[I+1] scratch*/,
                       int32_t *urank /*[I]*/, int32_t *uitem /*[I]*/, int64_t *h_n_ends);
 int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *U, const xmap_path_rows *R,

@@ -52,6 +52,7 @@ struct xmap_ctx {
     int32_t *touched = nullptr, *htouched = nullptr;
     int64_t acc_slots = 0, acc_len = 0, hacc_rows = 0, hacc_len = 0;
     int32_t n_slots = 0;
+    int32_t fast_div = 0;
     // stage C
     bool have_gen = false;
     int32_t *g_user = nullptr, *g_item = nullptr;
@@ -143,7 +144,7 @@ static int run_enumeration(xmap_ctx *c, int64_t xs_cap, int64_t *xs_off, int32_t
     int64_t h_cnt[4] = {0, 0, 0, 0};
     int rc;
     if (c->T.n_nb > 0) {
-        rc = xmap_extend_cols(c->st, &c->T, &c->Un, &Rw, &O, 1, d_cnt, h_cnt);
+        rc = xmap_extend_cols(c->st, &c->T, &c->Un, &Rw, &O, c->fast_div, d_cnt, h_cnt);
     } else {    // nothing joint: the per-path kernel over item-indexed rows (the same row buffers, U = I)
         rc = xmap_extend_paths(c->st, I, c->top_k, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->T.flags, c->T.att_ptr, c->T.att_idx,
                                c->T.att_val, c->T.src_ptr, c->T.src_idx, c->T.src_val, c->T.src_flag, c->T.rnn_ptr, c->T.rnn_idx,
@@ -380,6 +381,7 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
     XM_TRY(xmap_bridge_flags(c->st, &c->S, c->R.prefix_cls, bb));
     XM_TRY(xmap_knn_classify(c->st, &c->S, k, bb, c->R.suffix_cls, c->R.contains_mask, cls, kcnt, kcol, kval, 0, I));
     T.cls = cls; T.kcnt = kcnt; T.kcol = kcol; T.kval = kval;
+    XM_TRY(xmap_edge_ranges(c->st, &c->S, &c->fast_div));
     // B5a/b: reverse adjacencies
     double *thr;
     int32_t *long_rows;

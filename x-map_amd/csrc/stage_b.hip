@@ -1476,6 +1476,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
     }
 }
 
+// precondition of the bare division sequence (div_mid): every kept pair has a positive, finite mutuality within 2^+-100
+// and a product sim * mutu that is zero or within 2^+-400 -- then a path's mutuality sum is never zero and no operand is
+// near the ends of the exponent range.  What stage A produces always qualifies; records fed by a caller are checked.
+__global__ __launch_bounds__(256) void k_edge_ranges(long long n, const double *sim, const int *mutu, int *bad) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double m = (double)mutu[p], sm = fabs(sim[p] * m);
+    const bool ok = (m >= 1.0) && (sm == 0.0 || (sm > 0x1p-400 && sm < 0x1p400));      // mutu is an int32 count: >= 1 is "positive"
+    if (!ok) atomicOr(bad, 1);
+}
+
 // the ends of every column x (non-bridge record): x itself, then NN(x) in list order, as 32-byte records
 __global__ __launch_bounds__(256) void k_col_ends(int n_nb, int k, const int *nb_list, const int *kcnt, const int *kcol, const double *kval,
                                                   const int *urank, ColEnd *cend) {
@@ -1988,6 +1999,29 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
     const long long waves = (long long)n_nb * top_k;
     k_mid_build<true><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(A);
     XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_edge_ranges(void *stream, const xmap_sim *S, int32_t *h_fast_ok) {
+    XM_ARG(S && h_fast_ok);
+    *h_fast_ok = 1;
+    if (S->n_items == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    long long n = 0;
+    XM_HIP(hipMemcpyAsync(&n, S->row_ptr + S->n_items, sizeof(long long), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    if (n == 0) return XMAP_OK;
+    if (S->frac) { *h_fast_ok = 0; return XMAP_OK; }      // caller-supplied fractions: generic records, take the checked division
+    int *bad = nullptr;
+    XM_HIP(xm_malloc_async((void **)&bad, sizeof(int), st));
+    XM_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+    k_edge_ranges<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, S->sim, S->mutu, bad);
+    XM_LAUNCH_CHECK();
+    int h = 0;
+    XM_HIP(hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    XM_HIP(xm_free_async(bad, st));
+    *h_fast_ok = h ? 0 : 1;
     return XMAP_OK;
 }
 

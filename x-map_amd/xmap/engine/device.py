@@ -678,7 +678,7 @@ class Engine(object):
         cap = 0
         if full:
             cap = int(xs_cap) if xs_cap else 1 << 22
-        fast = 0 if os.environ.get("XMAP_SLOW_DIV") == "1" else 1
+        fast = 0 if os.environ.get("XMAP_SLOW_DIV") == "1" else int(getattr(E, "fast_div", 0))
         while True:
             xs_off = self._zeros(max(I, 1), torch.int64) if cap else None
             xs_end = self._empty(max(cap, 1), torch.int32) if cap else None
@@ -714,6 +714,9 @@ class Engine(object):
             cuts = np.maximum.accumulate(np.asarray(cuts))
             rows = (int(cuts[comm.rank]), int(cuts[comm.rank + 1]))
         E = self.knn(S, top_k, rows=rows)
+        ok = C.c_int32(1)
+        check(lib.xmap_edge_ranges(_stream(self.dev), C.byref(S.c), C.byref(ok)))
+        E.fast_div = int(ok.value)       # the bare division sequence of k_paths4 is the division for these edge values
         if rows is not None:
             lo, hi = rows
             with self.timed("knn_gather"):
@@ -791,6 +794,9 @@ class Engine(object):
         E.cls, E.kcnt, E.kcol, E.kval = t(cls), t(kcnt), t(kcol), t(kval)
         E.bb = t((cls == 1).astype(np.uint8))
         E.att, E.src, E.rnn = att, src, rnn
+        valid = np.arange(k)[None, None, :] < kcnt[:, :, None]
+        mu, smv = kval[..., 1][valid], np.abs(kval[..., 0][valid] * kval[..., 1][valid])
+        E.fast_div = int(bool(np.all(mu >= 1.0) and np.all((smv == 0) | ((smv > 2.0 ** -400) & (smv < 2.0 ** 400)))))
         return E
 
     def extend(self, S, top_k, full=False, start_range=None, n_slots=5120, xs_cap=None, chunk=None,
