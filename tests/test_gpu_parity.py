@@ -306,9 +306,15 @@ def test_determinism_and_partitions(dev):
         E5 = eng.extend(S, 5, full=True, algo="mid")
     finally:
         del os.environ["XMAP_MID_TABLE"]
+    os.environ["XMAP_SLOW_DIV"] = "1"                         # k_paths4<false>: the IEEE division of calculate_path_confidence
+    try:
+        E7 = eng.extend(S, 5, full=True)
+    finally:
+        del os.environ["XMAP_SLOW_DIV"]
+    assert E1.fast_div == 1                                   # stage A's output always meets div_mid's precondition
     assert E5.mid.n_records == E3.mid.n_records and E5.mid.n_tiles == E3.mid.n_tiles
     assert np.array_equal(E5.mid.dir.view(-1, 3)[:, 0].cpu().numpy(), E3.mid.dir.view(-1, 3)[:, 0].cpu().numpy())   # (x, ne) per tile
-    for Ex in (E3, E4, E5, E6):
+    for Ex in (E3, E4, E5, E6, E7):
         assert Ex.n_paths == E1.n_paths and Ex.n_out == E1.n_out
         for x, y in zip(_xsim_lists(E1, r.n_items), _xsim_lists(Ex, r.n_items)):
             assert np.array_equal(x, y)

@@ -1024,6 +1024,11 @@ __device__ __forceinline__ void heads_X(const Path2Args &B, WaveAcc &W, int star
     MidDir cur;
     cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
     if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+#ifdef Q_PREFETCH
+    MidDir nxt;                          // the entry behind cur, requested one column ahead of its use
+    nxt.x = INF; nxt.ne = 0; nxt.cnt = 0; nxt.pad = 0; nxt.off = 0;
+    if (hv && dpos + 1 < dend) nxt = B.dir[dpos + 1];
+#endif
     for (;;) {
         int xmin = cur.x;
 #pragma unroll
@@ -1286,6 +1291,11 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     MidDir cur;
     cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
     if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+#ifdef Q_PREFETCH
+    MidDir nxt;                          // the entry behind cur, requested one column ahead of its use
+    nxt.x = INF; nxt.ne = 0; nxt.cnt = 0; nxt.pad = 0; nxt.off = 0;
+    if (hv && dpos + 1 < dend) nxt = B.dir[dpos + 1];
+#endif
     for (;;) {
         int xmin = cur.x;
 #pragma unroll
@@ -1400,8 +1410,15 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
         }
         if (mine) {    // advance the heads that took part
             dpos++;
+#ifdef Q_PREFETCH
+            cur = nxt;
+            if (cur.x >= xhi) cur.x = INF;
+            nxt.x = INF;
+            if (dpos + 1 < dend) nxt = B.dir[dpos + 1];
+#else
             cur.x = INF;
             if (dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+#endif
         }
     }
 }
