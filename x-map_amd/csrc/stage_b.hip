@@ -1024,11 +1024,6 @@ __device__ __forceinline__ void heads_X(const Path2Args &B, WaveAcc &W, int star
     MidDir cur;
     cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
     if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
-#ifdef Q_PREFETCH
-    MidDir nxt;                          // the entry behind cur, requested one column ahead of its use
-    nxt.x = INF; nxt.ne = 0; nxt.cnt = 0; nxt.pad = 0; nxt.off = 0;
-    if (hv && dpos + 1 < dend) nxt = B.dir[dpos + 1];
-#endif
     for (;;) {
         int xmin = cur.x;
 #pragma unroll
@@ -1220,7 +1215,11 @@ __device__ __forceinline__ double quad_swap(double v) {
 //     in column order, so that the ends of a column are neighbours in the row): 2.7x shorter rows, 5x less scratch;
 //   * the ends of a column come from one table of 32-byte records (k_col_ends: rank and last edge), not from three
 //     dependent gathers; the row entries are requested before the records are reduced;
-//   * prepared records of all participating heads are staged in LDS (128 per round); division and sums as in k_paths3.
+//   * prepared records of all participating heads are staged in LDS (128 per round) in sets of 64, one record per lane
+//     whichever head it belongs to: the records of all the heads of a column are ONE round trip (a trip per head had been
+//     2.5 dependent trips per column), requested together with the end records; the row entries are requested next, before
+//     the records are prepared.  Loads are unconditional (clamped indices) and consumed at unconditional places -- see the
+//     comment in heads_Q; division and sums as in k_paths3.
 constexpr int Q_CAP = 128;                 // prepared records per round
 struct QLds {
     double bsm[Q_CAP], bc[Q_CAP], bmu[Q_CAP];
@@ -1291,18 +1290,14 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     MidDir cur;
     cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
     if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
-#ifdef Q_PREFETCH
-    MidDir nxt;                          // the entry behind cur, requested one column ahead of its use
-    nxt.x = INF; nxt.ne = 0; nxt.cnt = 0; nxt.pad = 0; nxt.off = 0;
-    if (hv && dpos + 1 < dend) nxt = B.dir[dpos + 1];
-#endif
     for (;;) {
+        // smallest column among the heads: xor butterfly inside each half of the wave (ds_swizzle: no address registers),
+        // then the two halves
         int xmin = cur.x;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(xmin, m, 64); xmin = o < xmin ? o : xmin; }
-#ifdef Q_UNIMIN
-        xmin = uniform(xmin);
-#endif
+#define XM_SWZ_MIN(PAT) { const int o = __builtin_amdgcn_ds_swizzle(xmin, PAT); xmin = o < xmin ? o : xmin; }
+        XM_SWZ_MIN(0x041F) XM_SWZ_MIN(0x081F) XM_SWZ_MIN(0x101F) XM_SWZ_MIN(0x201F) XM_SWZ_MIN(0x401F)
+#undef XM_SWZ_MIN
+        { const int x0 = rl32(xmin, 0), x1 = rl32(xmin, 32); xmin = x0 < x1 ? x0 : x1; }
         if (xmin == INF) break;
         const bool mine = cur.x == xmin;
         const unsigned long long part = __ballot(mine);
@@ -1314,49 +1309,74 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             const int sh = nact <= 16 ? 2 : (nact <= 32 ? 1 : 0);     // log2 of the record slices per end
             const int ns = 1 << sh;
             const int q = lane >> sh, slice = lane & (ns - 1);
-            {   // the block's ends (one 32-byte record each, prepared by k_col_ends), natural layout -> LDS
-                const int idx = b + lane;
-                ColEnd e;
-                e.sm = 0.0; e.mu = 0.0; e.f = 1.0; e.u = -1; e.pad = 0;
-                if (idx < ne) e = ce[idx];
-                L.e_u[lane] = e.u; L.e_sm[lane] = e.sm; L.e_mu[lane] = e.mu; L.e_f[lane] = e.f;
-                asm volatile("" ::: "memory");
-            }
-            const int eu = L.e_u[q];
-            const bool ok = eu >= 0;
-            const double sm5 = L.e_sm[q], mu5 = L.e_mu[q], f5 = L.e_f[q];
+            // Memory round trips of a column: {end records, first set of merged records} together, then the row entries
+            // (under the preparation and reduction of the records).  Every load is unconditional (clamped index) and is
+            // consumed at one unconditional place: a load whose use sits behind a branch stays "pending" on the other
+            // path, and the compiler then waits for ALL outstanding loads at the next join, which serialises the trips.
+            const ColEnd e = ce[(b + lane < ne) ? b + lane : ne - 1];      // one 32-byte record per end (k_col_ends)
             unsigned long long pm = part;
             int pos = 0;                      // records of the current head already staged
-            while (pm) {
-                int fill = 0;
-                while (pm && fill < Q_CAP) {
+            int set_n, my_h;
+            long long my_rec;
+            // a set = up to 64 records, one per lane, of whichever participating head the lane falls to
+            auto assign = [&]() {
+                set_n = 0; my_h = 0;
+                my_rec = rl64(cur.off, __ffsll((long long)pm) - 1);     // lanes beyond the set: any record
+                for (;;) {
+                    // (pm, pos and set_n are wave-uniform; said explicitly, or the loop is compiled as a divergent one)
+                    pm = ((unsigned long long)(unsigned)uniform((int)(pm >> 32)) << 32) | (unsigned)uniform((int)pm);
+                    pos = uniform(pos); set_n = uniform(set_n);
+                    if (pm == 0 || set_n >= 64) break;
                     const int l = __ffsll((long long)pm) - 1;
                     const int cnt = rl32(cur.cnt, l);
                     const long long off = rl64(cur.off, l);
-                    const bool he1 = rl32((int)has_e1, l) != 0;
-                    const double hsm1 = rld(sm1, l), hmu1 = rld(mu1, l), hf1 = rld(f1, l);
                     int n = cnt - pos;
-                    if (n > Q_CAP - fill) n = Q_CAP - fill;
-                    if (n > 64) n = 64;
-                    if (lane < n) {
-                        const MidX m = B.midX[off + pos + lane];
-                        double bsm, bc;
-                        if (he1) { bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4; bc = ((hf1 * m.f2) * m.f3) * m.f4; }
-                        else { bsm = (m.sm2 + m.sm3) + m.sm4; bc = (m.f2 * m.f3) * m.f4; }
-                        L.bsm[fill + lane] = bsm; L.bc[fill + lane] = bc; L.bmu[fill + lane] = m.mu + (he1 ? hmu1 : 0.0);
-                    }
-                    fill += n; pos += n;
+                    if (n > 64 - set_n) n = 64 - set_n;
+                    if (lane >= set_n && lane < set_n + n) { my_rec = off + pos + (lane - set_n); my_h = l; }
+                    set_n += n; pos += n;
                     if (pos == cnt) { pm &= pm - 1; pos = 0; }
                 }
-                asm volatile("" ::: "memory");
-                // one round (a column with more than Q_CAP records, < 1 % of them, updates its row once per round).
-                // The row entry is requested before the records are reduced: its round trip runs under the loop.
-                const bool fl_ = ok && slice == 0;
-                double *a = W.acc + (size_t)(ok ? eu : 0) * 4;
+            };
+            // prepared form of a record: first edge of its head (from the head's lane) + the three middle edges
+            auto prepare = [&](const MidX &m, int fill) {
+                const bool he1 = __shfl((int)has_e1, my_h, 64) != 0;
+                const double hsm1 = __shfl(sm1, my_h, 64), hmu1 = __shfl(mu1, my_h, 64), hf1 = __shfl(f1, my_h, 64);
+                asm volatile("" :: "v"(m.sm2), "v"(m.sm3), "v"(m.sm4), "v"(m.f2), "v"(m.f3), "v"(m.f4), "v"(m.mu));
+                double bsm, bc;
+                if (he1) { bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4; bc = ((hf1 * m.f2) * m.f3) * m.f4; }
+                else { bsm = (m.sm2 + m.sm3) + m.sm4; bc = (m.f2 * m.f3) * m.f4; }
+                const double bmu = m.mu + (he1 ? hmu1 : 0.0);
+                if (lane < set_n) { L.bsm[fill + lane] = bsm; L.bc[fill + lane] = bc; L.bmu[fill + lane] = bmu; }
+            };
+            assign();
+            MidX m0 = B.midX[my_rec];
+            // ends: natural layout -> LDS -> (end, slice) layout
+            {
+                int eu_ = e.u;
+                asm volatile("" : "+v"(eu_));          // (keeps the select below, and with it the wait for e, down here)
+                L.e_u[lane] = (b + lane < ne) ? eu_ : -1; L.e_sm[lane] = e.sm; L.e_mu[lane] = e.mu; L.e_f[lane] = e.f;
+            }
+            asm volatile("" ::: "memory");
+            const int eu = L.e_u[q];
+            const bool ok = eu >= 0;
+            const double sm5 = L.e_sm[q], mu5 = L.e_mu[q], f5 = L.e_f[q];
+            const bool fl_ = ok && slice == 0;
+            double *a = W.acc + (size_t)(ok ? eu : 0) * 4;
+            for (;;) {
+                // one round = up to Q_CAP prepared records (a column with more, < 1 % of them, updates its row once per round)
                 double h0_ = 0.0, l0_ = 0.0, h1_ = 0.0, l1_ = 0.0;
 #ifndef Q_NOFLUSH
-                if (fl_) { h0_ = a[0]; l0_ = a[1]; h1_ = a[2]; l1_ = a[3]; }
+                h0_ = a[0]; l0_ = a[1]; h1_ = a[2]; l1_ = a[3];     // requested before the records are prepared and reduced
 #endif
+                prepare(m0, 0);
+                int fill = set_n;
+                while (pm && fill < Q_CAP) {
+                    assign();
+                    const MidX m = B.midX[my_rec];
+                    prepare(m, fill);
+                    fill += set_n;
+                }
+                asm volatile("" ::: "memory");
                 double a_sh = 0.0, a_sl = 0.0, a_ch = 0.0, a_cl = 0.0;
                 const int steps = (fill + ns - 1) >> sh;
 #ifdef Q_NOCOMPUTE
@@ -1390,7 +1410,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                     acc2(a_sh, a_sl, o_sh); a_sl += o_sl;
                     acc2(a_ch, a_cl, o_ch); a_cl += o_cl;
                 }
-                asm volatile("" ::: "memory");
+                asm volatile("" :: "v"(h0_), "v"(l0_), "v"(h1_), "v"(l1_) : "memory");
                 bool first = false;
 #ifdef Q_NOFLUSH
                 if (fl_ && a_sh == 1.2345e300 && a_cl == 7.7e-300) W.acc[0] = a_sh + a_sl + a_ch + a_cl;
@@ -1406,19 +1426,15 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 if (first) W.touched[W.nt + __popcll(fm & lanemask_lt())] = eu;
                 W.nt += __popcll(fm);
                 W.paths += (unsigned long long)fill * (unsigned long long)nact;
+                if (!pm) break;
+                assign();
+                m0 = B.midX[my_rec];
             }
         }
         if (mine) {    // advance the heads that took part
             dpos++;
-#ifdef Q_PREFETCH
-            cur = nxt;
-            if (cur.x >= xhi) cur.x = INF;
-            nxt.x = INF;
-            if (dpos + 1 < dend) nxt = B.dir[dpos + 1];
-#else
             cur.x = INF;
             if (dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
-#endif
         }
     }
 }
