@@ -101,7 +101,7 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4, k=0):
     return out
 
 
-def bench_dense(args, rank, world, local, dist):
+def bench_dense(args, rank, world, local, dist, sink=None):
     """--workload dense: BASELINE.json configs[4], 200k x 200k item factors of dimension 128, top-k 50.  The target
     rows are split over the ranks (no exchange: every rank ranks its rows against all source items)."""
     from xmap.engine import device, synth
@@ -161,7 +161,7 @@ def bench_dense(args, rank, world, local, dist):
             out["cpu_baseline"] = dict(value=rows * float(n_s) / dt, unit="pairs/s", cores=threads, kind="port",
                                        sample="oracle dense top-k on target rows [0,%d) x all %d sources: %.1f s, OpenMP %d threads"
                                               % (rows, n_s, dt, threads))
-        emit(out)
+        (sink or emit)(out)
 
 
 def bench_multidomain(args, rank, world, local, dist):
@@ -222,7 +222,7 @@ def bench_multidomain(args, rank, world, local, dist):
                          "alterego_rows": int(len(out["user"])), "profiles": users}})
 
 
-def bench_recsim(args, rank, world, local, dist):
+def bench_recsim(args, rank, world, local, dist, sink=None):
     """--workload recsim: RecommenderSim.calculate_sim over the AlterEgo rows the hot path produces at
     BASELINE configs[1] (one GPU; the rows come out of one untimed pass of the three pipelines)."""
     from xmap.engine import device, synth, ids
@@ -285,7 +285,7 @@ def bench_recsim(args, rank, world, local, dist):
                                    sample="oracle rec_sim on the rows of the first %d users: %d pairs in %.1f s, 1 thread"
                                           % (users, int(O.row_ptr[-1]), dt))
         xo.rec_free(O)
-    emit(out)
+    (sink or emit)(out)
 
 
 def main():
@@ -297,6 +297,7 @@ def main():
     ap.add_argument("--method", default="adjust_cosine")   # parameters.yaml:17
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")   # default c2 run at N = 1: skip the short recsim / dense lines
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -435,6 +436,25 @@ def main():
         }
         if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(r, attrs, args.method, k=k)
+        if world == 1 and args.workload == "c2" and not args.no_extra:
+            # the two other full-size workloads (`--workload recsim`, `--workload dense`), three steps each, so that every
+            # run of the default command records them; their full lines (with cpu_baseline) come from their own flags
+            res = None
+            eng._scratch.clear()            # 26 GB of accumulator rows
+            torch.cuda.empty_cache()
+            a2 = argparse.Namespace(**dict(vars(args), steps=3, warmup=1, no_cpu=True, k=0))
+            other = {}
+            for name, fn in (("recsim", bench_recsim), ("dense", bench_dense)):
+                try:
+                    fn(a2, rank, world, local, None, sink=lambda o, name=name: other.__setitem__(name, o))
+                    o = other[name]
+                    other[name] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                                   "steps": o["steps"], "warmup": o["warmup"], "dtype": o["dtype"], "workload": o["config"]["workload"],
+                                   "roofline": {x: o["roofline"][x] for x in ("bound", "kernel", "achieved", "peak", "unit", "frac")}}
+                except Exception as e:      # the headline line must not depend on the side workloads
+                    other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
+            out["other_workloads"] = other
         emit(out)
     if dist:
         dist.barrier()

@@ -4,11 +4,11 @@ T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err || exit 1
 echo bench done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/${T}_bench_under_rocprof.json 2> gpurun_out/${T}_stats.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extra > gpurun_out/${T}_bench_under_rocprof.json 2> gpurun_out/${T}_stats.err || exit 1
 echo stats done
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${T}_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/${T}_fetch.json 2> gpurun_out/${T}_fetch.err || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${T}_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra > gpurun_out/${T}_fetch.json 2> gpurun_out/${T}_fetch.err || exit 1
 echo fetch done
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${T}_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/${T}_write.json 2> gpurun_out/${T}_write.err || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${T}_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra > gpurun_out/${T}_write.json 2> gpurun_out/${T}_write.err || exit 1
 echo write done
 rm -f gpurun_out/${T}_stats/*/*kernel_trace.csv
 timeout -k 10 200 python3 bench.py --workload recsim --steps 3 --warmup 1 > gpurun_out/${T}_recsim.json 2> gpurun_out/${T}_recsim.err || exit 1
