@@ -1198,8 +1198,8 @@ __device__ __forceinline__ void acc2(double &hi, double &lo, double x) {
 template <int CTRL>
 __device__ __forceinline__ double quad_swap(double v) {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
