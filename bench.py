@@ -391,7 +391,10 @@ def main():
         # DESIGN.md 4): 8 B per directed co-rating contribution it processes + CSR and rater records read once
         # (16 B per rating) + item stats (32 B per item) + the kept pairs it emits (24 B per unordered pair).
         tri_ms = float(np.mean(tm.get("pair_tri", [0.0])))
-        bytes_tri = 8.0 * res["n_contrib_light"] + 16.0 * nnz + 32.0 * I + 12.0 * res["n_kept_local"]
+        # (the bracket covers the rows of the heavy set too unless XMAP_SPLIT_PHASES=1: they run on a side stream next to the
+        # class launches, and their contributions are then part of the bytes)
+        split = "pair_heavy" in tm
+        bytes_tri = 8.0 * (res["n_contrib_light"] if split or world > 1 else P) + 16.0 * nnz + 32.0 * I + 12.0 * res["n_kept_local"]
         ach = bytes_tri / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
         # SURVEY.md 8d states the whole-stage figure too: B_A = 8 P + 16 nnz + 32 I + 20 D' over t_A
         bytes_a = 8.0 * P + 16.0 * nnz + 32.0 * I + 20.0 * Dk
@@ -426,7 +429,7 @@ def main():
             # (12 E + 12 N_out -- knn tables in, (start, end, xsim) out) are a small part of what it moves:
             # it accumulates 32-byte (value, error) pairs per (start, end) in HBM rows; paths/s is the figure of merit
             "roofline": dict(rf_b, kernel="k_paths4"),
-            "roofline_stage_a": {"bound": "hbm", "kernel": "k_pair_tri", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline_stage_a": {"bound": "hbm", "kernel": "k_pair_tri" if split else "k_pair_tri + k_pair_heavy / k_heavy_merge (side stream)", "achieved": ach, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr_a,
                                  "traffic_ratio": (tr_a / bytes_tri) if (tr_a and bytes_tri) else None,
                                  "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms,

@@ -129,7 +129,8 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
  *            of class rank 0..4, light units} (cls_ptr of xmap_sim2_pairs = h_counts + 2).
  *   pairs  : phases bit 8 = reset counters/rowcnt, 1 = k_pair_heavy (chunk partials of the rows of H), 2 = k_pair_tri
  *            (light units [unit_lo, unit_hi), one launch per table class; 16 / 4 / 2 waves share a 1024 / 1024 / 512-slot table),
- *            4 = k_heavy_merge, 16 = fold the heavy items' row-count replicas (last);
+ *            4 = k_heavy_merge, 16 = fold the heavy items' row-count replicas (last); with 1 | 2 | 4 in one call the
+ *            heavy rows (partials, then merge) run on a side stream next to the class launches of the light rows;
  *            kept pairs (i lighter, j heavier) ->
  *            half COO: coo_cap entries cut into 4096 shards with a cursor each (d_shards[0][s]; unused entries keep
  *            coo_i = -1), rowcnt[i]++ / rowcnt[j]++; d_shards[1][s] sums to the unordered pairs evaluated;

@@ -292,11 +292,10 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
         const size_t hp = (size_t)(n_hu ? n_hu : 1) * 1024;
         T_ALLOC(hp_hi, hp); T_ALLOC(hp_lo, hp); T_ALLOC(hp_cnt, hp); T_ALLOC(hp_mut, hp);
         T_ALLOCZ(d_cnt, 4); T_ALLOC(d_shards, 2 * 4096); T_ALLOC(rowcnt_h, 64 * 1024);
-        const int phases[3] = {8 | 1, 2, 4 | 16};
-        for (int ph = 0; ph < 3; ph++)
-            XM_TRY(xmap_sim2_pairs(c->st, &R, method, cap, c->u_avg, norms, rcrec, ub, Q, small, uq_item, uq_q, hc + 2, 0, n_light, hid, hlist,
-                                   ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, phases[ph], hp_hi, hp_lo, hp_cnt, hp_mut,
-                                   cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, rowcnt, rowcnt_h, d_shards, d_cnt));
+        // all phases in one call: the heavy rows run on a side stream next to the class launches of the light rows
+        XM_TRY(xmap_sim2_pairs(c->st, &R, method, cap, c->u_avg, norms, rcrec, ub, Q, small, uq_item, uq_q, hc + 2, 0, n_light, hid, hlist,
+                               ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, 8 | 1 | 2 | 4 | 16, hp_hi, hp_lo, hp_cnt, hp_mut,
+                               cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, rowcnt, rowcnt_h, d_shards, d_cnt));
         int64_t h_cnt[4];
         XM_TRY(d2h(h_cnt, d_cnt, 4, c->st));
         XM_HIP(hipStreamSynchronize(c->st));

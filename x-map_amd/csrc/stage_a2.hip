@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, 
 using namespace xmap;
 
 // forked streams for the per-class pair kernels (created once per process and device; never destroyed)
-struct SideStreams { hipStream_t s[N_CLASSES]; hipEvent_t fork, done[N_CLASSES]; int dev; };
+struct SideStreams { hipStream_t s[N_CLASSES + 1]; hipEvent_t fork, done[N_CLASSES + 1]; int dev; };   // + one for the heavy rows
 static SideStreams *side_streams() {
     static thread_local SideStreams *cur[64] = {nullptr};
     int dev = 0;
@@ -879,7 +879,7 @@ static SideStreams *side_streams() {
     SideStreams *p = new SideStreams();
     p->dev = dev;
     bool ok = hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) == hipSuccess;
-    for (int c = 0; c < N_CLASSES && ok; c++)
+    for (int c = 0; c <= N_CLASSES && ok; c++)
         ok = hipStreamCreateWithFlags(&p->s[c], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&p->done[c], hipEventDisableTiming) == hipSuccess;
     if (!ok) { set_error("could not create the side streams"); delete p; return nullptr; }
@@ -1031,18 +1031,38 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.coo_aux = coo_ls;
     A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
+    // phases 1 | 2 | 4 in one call: the heavy rows (chunk partials, then their merge) run on a side stream of their own,
+    // next to the class launches of the light rows -- they share nothing but the atomic COO cursors and counters
+    const bool heavy_aside = (phases & 7) == 7 && n_heavy_units > 0 && unit_hi > unit_lo;
+    hipStream_t hs = st;
+    SideStreams *side = nullptr;
+    if (((phases & 2) && unit_hi > unit_lo) || heavy_aside) {
+        side = side_streams();
+        if (!side) return XMAP_ERR_HIP;
+        XM_HIP(hipEventRecord(side->fork, st));
+    }
+    if (heavy_aside) {
+        hs = side->s[N_CLASSES];
+        XM_HIP(hipStreamWaitEvent(hs, side->fork, 0));
+    }
     if ((phases & 1) && n_heavy_units > 0) {   // heavy rows: chunk partials
-        if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64 * HEAVY_WAVES), 0, st>>>(A);
-        else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64 * HEAVY_WAVES), 0, st>>>(A);
+        if (method == XMAP_COSINE) k_pair_heavy<XMAP_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64 * HEAVY_WAVES), 0, hs>>>(A);
+        else k_pair_heavy<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy_units), dim3(64 * HEAVY_WAVES), 0, hs>>>(A);
         XM_LAUNCH_CHECK();
+    }
+    if (heavy_aside && n_heavy > 0) {
+        if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, hs>>>(A, n_heavy);
+        else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, hs>>>(A, n_heavy);
+        XM_LAUNCH_CHECK();
+    }
+    if (heavy_aside) {
+        XM_HIP(hipEventRecord(side->done[N_CLASSES], hs));
+        XM_HIP(hipStreamWaitEvent(st, side->done[N_CLASSES], 0));
     }
     if ((phases & 2) && unit_hi > unit_lo) {
         // one launch per table class: the class's units within [unit_lo, unit_hi).  The classes are independent (they
         // only share the COO cursors, which are atomic) and each ends in a tail of long rows at low occupancy: they
         // run side by side on forked streams and the caller's stream joins them.
-        SideStreams *side = side_streams();
-        if (!side) return XMAP_ERR_HIP;
-        XM_HIP(hipEventRecord(side->fork, st));
         for (int c = 0; c < N_CLASSES; c++) {
             const long long lo = unit_lo > cls_ptr[c] ? unit_lo : cls_ptr[c];
             const long long hi = unit_hi < cls_ptr[c + 1] ? unit_hi : cls_ptr[c + 1];
@@ -1076,7 +1096,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         }
         A.unit_lo = unit_lo; A.unit_hi = unit_hi;
     }
-    if ((phases & 4) && n_heavy_units > 0 && n_heavy > 0) {
+    if ((phases & 4) && !heavy_aside && n_heavy_units > 0 && n_heavy > 0) {
         if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, st>>>(A, n_heavy);
         else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, st>>>(A, n_heavy);
         XM_LAUNCH_CHECK();

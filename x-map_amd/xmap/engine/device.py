@@ -347,12 +347,16 @@ class Engine(object):
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
                     vp(coo_mutu), vp(coo_nij), vp(coo_ls), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
-            with self.timed("pair_heavy"):
-                run(8 | (1 if do_heavy else 0))
-            with self.timed("pair_tri"):
-                run(2)
-            with self.timed("heavy_merge"):
-                run((4 if do_heavy else 0) | 16)
+            if os.environ.get("XMAP_SPLIT_PHASES") == "1":        # one timer per phase (analysis)
+                with self.timed("pair_heavy"):
+                    run(8 | (1 if do_heavy else 0))
+                with self.timed("pair_tri"):
+                    run(2)
+                with self.timed("heavy_merge"):
+                    run((4 if do_heavy else 0) | 16)
+            else:       # the heavy rows (chunk partials + merge) on a side stream next to the class launches of the light rows
+                with self.timed("pair_tri"):
+                    run(8 | 2 | 16 | (5 if do_heavy else 0))
             h = d_cnt.tolist()
             if h[2]:
                 if L.slot_target <= 32:
