@@ -297,6 +297,8 @@ def main():
     ap.add_argument("--method", default="adjust_cosine")   # parameters.yaml:17
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--layout", default="items", choices=["items", "users"])   # N > 1: replicated ratings + item-sharded work
+    #                                             (default), or user-sharded ratings + exchange of the partial similarities
     ap.add_argument("--no-extra", action="store_true")   # default c2 run at N = 1: skip the short recsim / dense lines
     args = ap.parse_args()
 
@@ -348,12 +350,22 @@ def main():
     t0 = time.time()
     r = wl["gen"]()
     attrs = r.item_attrs()
-    R = device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs, dev)
+    by_users = args.layout == "users" and dist is not None and world > 1
+    u_lo = 0
+    if by_users:       # this rank's share of the users (complete profiles), items indexed globally
+        u_lo, u_hi = r.n_users * rank // world, r.n_users * (rank + 1) // world
+        e0, e1 = int(r.user_ptr[u_lo]), int(r.user_ptr[u_hi])
+        R = device.DeviceRatings((r.user_ptr[u_lo:u_hi + 1] - r.user_ptr[u_lo]).astype(np.int64), r.item[e0:e1].copy(),
+                                 r.rating[e0:e1].copy(), r.time[e0:e1].copy(), r.n_items, attrs, dev)
+    else:
+        R = device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs, dev)
     eng = device.Engine(R)
     if rank == 0:
         log("setup: users=%d items=%d nnz=%d in %.1f s (synthetic data generation + H2D upload of the CSR)" % (r.n_users, r.n_items, r.nnz, time.time() - t0))
 
     def step():
+        if by_users:
+            return sharded.run_step_users(eng, u_lo, args.method, CAP, k, True, dist)
         return sharded.run_step(eng, args.method, CAP, k, True, dist, rank, world)
 
     for _ in range(args.warmup):
@@ -420,7 +432,7 @@ def main():
             "config": {"workload": wl["name"], "method": args.method, "top_k": k, "private": True,
                        "users": r.n_users, "items": I, "nnz": nnz, "P_contributions": P,
                        "D_pairs_evaluated": D, "D_pairs_kept": Dk, "paths": res["n_paths"],
-                       "parallelism": "items sharded over %d GPU(s)" % world},
+                       "parallelism": ("users sharded over %d GPU(s), partial similarities exchanged" if by_users else "items sharded over %d GPU(s)") % world},
             "alterego_profiles_per_s": res["n_profiles"] / (t_b + t_c) if (t_b + t_c) > 0 else 0.0,
             "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
             "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},

@@ -164,6 +164,31 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
                       const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_ls /*or NULL*/,
                       const int64_t *row_ptr, int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist,
                       int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *ls /*or NULL*/);
+/* User-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard partial similarities"): a rank
+ * holds the complete profiles of a share of the USERS.  Per item its share of get_universal_item_info's sums
+ * (core/baselinerSim.py:56-82) is xmap_item_partials -> [I][5] = (sum r, sum r^2, sum (r - avg_u)^2 as an exact (value, error)
+ * pair, raters); the shares of all ranks, gathered as [n_parts][I][5], are added up and finished by xmap_item_merge
+ * (rank order; exact for the adjusted norm and for integer-valued ratings).  xmap_sim2_pairs with phases bit 32 ("raw": no
+ * heavy set, coo_ls != NULL) then emits, for every pair two of the rank's users co-rated, the partial sums of
+ * calculate_cosine_sim / calculate_adjusted_cosine_sim (:115-174) and retrieve_path_info (:97-113) unfinished and unfiltered:
+ * coo_sim / coo_ls = the dot product as an exact (value, error) pair, coo_nij, coo_mutu.  xmap_sim2_pack_partials turns
+ * them into 32-byte records (key = lower index << 32 | higher index, value, error, n_ij | mutu << 32; *h_count of them),
+ * xmap_sim2_sort_partials orders records by key (stable), and -- after the records have been exchanged so that every
+ * rank holds ALL records of the pairs it owns, ordered by key with equal keys in rank order -- xmap_sim2_merge_partials adds
+ * the shares of a pair up (the dot product exactly), applies cosine, significance weighting and the zero filter
+ * (:84-95,:198,:207) with the merged item norms and appends the kept pairs (i < j) to a half COO + row counts, which
+ * xmap_sim2_scatter mirrors as usual.  h_counts = {kept, evaluated} unordered pairs. */
+int xmap_item_partials(void *stream, const xmap_ratings *R, const double *u_avg, double *partial /*[I][5]*/);
+int xmap_item_merge(void *stream, int32_t n_items, int32_t n_parts, const double *parts /*[n_parts][I][5]*/, double *info /*[I][4]*/,
+                    double *norms /*[2][I]*/);
+int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_hi,
+                            const double *coo_lo, const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][4]*/,
+                            int64_t *h_count);
+int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec /*[n][4]*/, int64_t *rec_sorted /*[n][4]*/);
+int xmap_sim2_merge_partials(void *stream, int method, int cap, int32_t n_items, int64_t n, const int64_t *rec_sorted,
+                             const double *norms /*[2][I]*/, int32_t *coo_i, int32_t *coo_j, double *coo_sim, int32_t *coo_mutu,
+                             int32_t *coo_nij, int32_t *rowcnt /*[I]*/, int64_t *h_counts /*[2]*/);
+
 /* RecommenderSim.calculate_sim (core/recommenderSim.py:65-133,188-195; both method names take the cosine branch, :190)
  * is the same pair machinery over the AlterEgo rows: call xmap_item_stats with u_avg = 0 (adjnorm is then the exact
  * norm), xmap_sim2_layout with dups = 1 and ch_min > n_users (no heavy set), xmap_sim2_plan with dups = 1, and

@@ -102,3 +102,44 @@ def test_rank_groups_and_error_agreement_world4_gloo():
     assert [t for *_, t, _, _ in got] == [3, 3, 7, 7]
     assert got[0][5] == [0, 10, 11] and got[2][5] == [20, 30, 31]
     assert [o for *_, o in got] == ["ok", "ok", "peer", "own"]
+
+
+def _worker_a2a(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmap.engine.sharded import Comm
+    comm = Comm(dist)
+    # rank s holds rows (key, s) with keys 0 .. 5+s, sorted; keys [2 r, 2 r + 2) belong to rank r, the rest to the last
+    n = 6 + rank
+    rows = torch.stack([torch.arange(n, dtype=torch.int64), torch.full((n,), rank, dtype=torch.int64)], dim=1)
+    cuts = [0] + [min(2 * r, n) for r in range(1, world)] + [n]
+    got = comm.all_to_all_rows(rows, cuts)
+    fixed = comm.all_gather_fixed(torch.tensor([[rank, 10 * rank]], dtype=torch.float64))
+    q.put((rank, got.tolist(), fixed.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_to_all_rows_world3_gloo():
+    """the exchange of the user-sharded step's partial-similarity records (Comm.all_to_all_rows; gloo has no all-to-all: the
+    all-gather form) and the fixed-size all-gather of the item sums: every rank receives exactly its key ranges, sender
+    after sender"""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_a2a, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, rows, fixed in got:
+        lo = 2 * rank
+        want = []
+        for s in range(world):
+            hi = 2 * rank + 2 if rank < world - 1 else 6 + s
+            want += [[key, s] for key in range(lo, hi)]
+        assert rows == want, (rank, rows, want)
+        assert fixed == [[[float(s), 10.0 * s]] for s in range(world)]

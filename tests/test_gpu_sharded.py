@@ -131,3 +131,74 @@ def test_multidomain_rank_groups_equal_one_rank(world):
     for rank, out in got:
         for key, v in ref.items():
             assert np.array_equal(out[key], v), (rank, key)
+
+
+def _user_share(rank, world):
+    """the complete profiles of a contiguous share of the users (items indexed globally)"""
+    from xmap.engine import synth, device
+    r = synth.make_two_domain(21, 4000, 700, 700)
+    lo, hi = r.n_users * rank // world, r.n_users * (rank + 1) // world
+    e0, e1 = int(r.user_ptr[lo]), int(r.user_ptr[hi])
+    ptr = (r.user_ptr[lo:hi + 1] - r.user_ptr[lo]).astype(np.int64)
+    R = device.DeviceRatings(ptr, r.item[e0:e1].copy(), r.rating[e0:e1].copy(), r.time[e0:e1].copy(), r.n_items, r.item_attrs())
+    return device.Engine(R), lo
+
+
+def _users_worker(rank, world, port, method, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmap.engine import sharded
+    eng, lo = _user_share(rank, world)
+    res = sharded.run_step_users(eng, lo, method, 50, 5, True, dist)
+    out = _summary(res)
+    out["info"] = res["info"].cpu().numpy()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,method", [(2, "adjust_cosine"), (3, "cosine"), (4, "adjust_cosine")])
+def test_user_sharded_equals_world1(world, method):
+    """BASELINE configs[2]'s other split: every rank holds a share of the USERS, the partial similarities of a pair are
+    sent to the rank that owns it and added up there (sharded.run_step_users).  Item statistics, similarity matrix, extension,
+    replacements and AlterEgo rows must be those of one rank over all ratings, bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    from xmap.engine import sharded
+    one = sharded.run_step(_engine(), method, 50, 5, True)
+    ref = _summary(one)
+    ref["info"] = one["S"].info.cpu().numpy()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_users_worker, args=(r, world, port, method, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ref["n_kept"] > 0 and ref["n_paths"] > 0 and ref["n_rows"] > 0
+    I = len(ref["row_ptr"]) - 1
+
+    def canon(d):       # the AlterEgo rows as a set: one rank lists them kind by kind, the shares are concatenated user range by user range
+        o = np.lexsort((d["ae_rating"], d["ae_item"], d["ae_user"]))
+        for key in ("ae_user", "ae_item", "ae_rating"):
+            d[key] = np.asarray(d[key])[o]
+    canon(ref)
+    for rank, out in got:
+        canon(out)
+        for key, v in ref.items():
+            assert np.array_equal(out[key], v), (rank, key)
+    # the ranks' partitions (pairs owned through their lower item) are disjoint and together are the whole matrix
+    rows = np.concatenate([out["part_row"] for _, out in got])
+    cols = np.concatenate([out["part_col"] for _, out in got])
+    sims = np.concatenate([out["part_sim"] for _, out in got])
+    o = np.lexsort((cols, rows))
+    full_rows = np.repeat(np.arange(I), np.diff(ref["row_ptr"]))
+    assert np.array_equal(rows[o], full_rows) and np.array_equal(cols[o], ref["col"])
+    assert np.array_equal(sims[o], ref["sim"])

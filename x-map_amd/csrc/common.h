@@ -33,6 +33,9 @@ void set_error(const char *fmt, ...);
 // Temporaries of one entry-point call: the library's own per-stream arenas (util.hip), not hipMallocAsync.
 hipError_t xm_malloc_async(void **p, size_t bytes, hipStream_t st);
 hipError_t xm_free_async(void *p, hipStream_t st);
+// plan.hip: stable LSD radix sort of (key, value) pairs by the low `bits` bits of the key; tmp buffers of n entries
+int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals, unsigned long long *keys_tmp, int *vals_tmp, long long n,
+                     int bits);
 
 constexpr int WAVE = 64;
 

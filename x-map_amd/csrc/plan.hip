@@ -62,8 +62,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const unsigned long l
 }
 
 // sorts (keys, vals) ascending by the low `bits` bits of the key, stable; result in (keys, vals); tmp buffers of n
-static int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals, unsigned long long *keys_tmp, int *vals_tmp,
-                            long long n, int bits) {
+int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals, unsigned long long *keys_tmp, int *vals_tmp,
+                     long long n, int bits) {
     if (n <= 1) return XMAP_OK;
     const int n_blocks = (int)((n + RS_TILE - 1) / RS_TILE);
     int *hist = nullptr;

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_csc_fill(long long U, const long long *
 template <int G>
 __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, const long long *iptr, const int *iuser,
                                                  const float *irating, const double *u_avg, double *info, double *norms,
-                                                 int *ia_user) {
+                                                 int *ia_user, double *partial = nullptr) {
     long long p0 = 0, p1 = 0;
     if (on) { p0 = iptr[i]; p1 = iptr[i + 1]; }
     double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
@@ -178,6 +178,13 @@ __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, 
         dd_add(a2, a2lo, oh);
         dd_add(a2, a2lo, ol);
     }
+    if (partial) {     // user-sharded input: this rank's share of the item's sums (k_item_merge adds the shares up)
+        if (on && gl == 0) {
+            double *o = partial + (size_t)i * 5;
+            o[0] = s; o[1] = q; o[2] = a2; o[3] = a2lo; o[4] = (double)(p1 - p0);
+        }
+        return;
+    }
     a2 = __shfl(a2, 0, G);
     double n = (double)(p1 - p0);
     double avg = (p1 > p0) ? 1.0 * s / n : 0.0;
@@ -202,21 +209,44 @@ __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, 
 // one per 16-lane group; the others one after the other on the whole wave
 // items [lo, hi) (a rank's share when the items are sharded: the per-item results are all-gathered afterwards)
 __global__ __launch_bounds__(256) void k_item_stats(int I, int lo, int hi, const long long *iptr, const int *iuser, const float *irating,
-                                                    const double *u_avg, double *info, double *norms, int *ia_user) {
+                                                    const double *u_avg, double *info, double *norms, int *ia_user,
+                                                    double *partial = nullptr) {
     const int i0 = lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     if (i0 >= hi) return;
     const int lane = lane_id();
     {
         const int i = i0 + (lane >> 4);
         const bool on = i < hi && iptr[i + 1] - iptr[i] <= 64;
-        item_stats_group<16>(on, i, lane & 15, I, iptr, iuser, irating, u_avg, info, norms, ia_user);
+        item_stats_group<16>(on, i, lane & 15, I, iptr, iuser, irating, u_avg, info, norms, ia_user, partial);
     }
     for (int t = 0; t < 4; t++) {
         const int i = i0 + t;
         if (i >= hi) break;
         if (iptr[i + 1] - iptr[i] <= 64) continue;
-        item_stats_group<64>(true, i, lane, I, iptr, iuser, irating, u_avg, info, norms, ia_user);
+        item_stats_group<64>(true, i, lane, I, iptr, iuser, irating, u_avg, info, norms, ia_user, partial);
     }
+}
+
+// user-sharded input: the item sums of the ranks' user shares [n_parts][I][5] = (sum r, sum r^2, adjusted
+// norm^2 as an exact (value, error) pair, raters) are added up in rank order -- the adjusted norm exactly -- and finished
+// as k_item_stats finishes them
+__global__ __launch_bounds__(256) void k_item_merge(int I, int n_parts, const double *parts, double *info, double *norms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0, n = 0.0;
+    for (int r = 0; r < n_parts; r++) {
+        const double *o = parts + ((size_t)r * I + i) * 5;
+        s += o[0]; q += o[1]; n += o[4];
+        dd_add(a2, a2lo, o[2]);
+        dd_add(a2, a2lo, o[3]);
+    }
+    const double avg = (n > 0.0) ? 1.0 * s / n : 0.0;
+    info[(size_t)i * 4 + 0] = avg;
+    info[(size_t)i * 4 + 1] = sqrt(q);
+    info[(size_t)i * 4 + 2] = sqrt(a2);
+    info[(size_t)i * 4 + 3] = 1.0 * n;
+    norms[i] = sqrt(q);
+    norms[(size_t)I + i] = sqrt(a2);
 }
 
 __global__ __launch_bounds__(256) void k_pack_user_side(long long nnz, const int *uitem, const float *urating,
@@ -539,6 +569,27 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
     if (R->nnz > 0 && ua_item) {
         k_pack_user_side<<<dim3((unsigned)((R->nnz + 255) / 256)), dim3(256), 0, st>>>(
             R->nnz, R->user_item, R->user_rating, info, ua_item);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
+
+int xmap_item_partials(void *stream, const xmap_ratings *R, const double *u_avg, double *partial /*[I][5]*/) {
+    XM_ARG(R && u_avg && partial && R->nnz < 0x7fffffffLL);
+    hipStream_t st = (hipStream_t)stream;
+    if (R->n_items > 0) {
+        k_item_stats<<<dim3((unsigned)((R->n_items + 15) / 16)), dim3(256), 0, st>>>(
+            R->n_items, 0, R->n_items, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, nullptr, nullptr, nullptr,
+            partial);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
+
+int xmap_item_merge(void *stream, int32_t n_items, int32_t n_parts, const double *parts, double *info, double *norms) {
+    XM_ARG(parts && info && norms && n_items >= 0 && n_parts >= 1);
+    if (n_items > 0) {
+        k_item_merge<<<dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(n_items, n_parts, parts, info, norms);
         XM_LAUNCH_CHECK();
     }
     return XMAP_OK;

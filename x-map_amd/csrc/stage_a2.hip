@@ -319,6 +319,8 @@ struct TriArgs {
     int *rowcnt;
     int *rowcnt_h;                  // [HEAVY_SHARDS][HMAX] replicas for the heavy items
     unsigned long long *counters;   // [2] table overflow, [3] COO overflow
+    int raw;                        // user-sharded input: emit every pair's partial sums (dot as (value, error) in coo_sim /
+                                    // coo_aux, n_ij, mutuality) unfinished and unfiltered -- xmap_sim2_merge finishes them
 };
 
 // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207) for one accumulated pair
@@ -650,6 +652,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             if (!o) return false;
             unsigned long long c = cm[s];
             j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32);
+            if (A.raw) { sv = dot[s]; return true; }
             return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
         },
         [&](int s, bool o, bool keep, double sv) {      // park: weighted sim in dot[], dropped slots emptied
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32); sv = dot[s];
             return true;
         },
-        [&](int s) { return 0.0; });
+        [&](int s) { return (ADJ && A.raw) ? dlo[s] : 0.0; });
 }
 
 // rows of H: chunk c of the raters, dense table over H (partners of a heavy row are heavier, hence in H)
@@ -865,6 +868,90 @@ __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, 
     }
 }
 
+// ---- user-sharded input ("each GPU produces partial (dot, n, mutu) for all pairs touched by its users") ------
+// A partial record is 32 bytes: key = lower item index << 32 | higher index, the dot product as an exact (value, error)
+// pair, n_ij | mutuality << 32.  A rank has at most one record per pair (every unordered pair belongs to one work unit).
+__global__ __launch_bounds__(256) void k_pack_partials(long long n_coo, const int *coo_i, const int *coo_j, const double *coo_hi,
+                                                       const double *coo_lo, const int *coo_mutu, const int *coo_nij,
+                                                       unsigned long long *cursor, long long *rec) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool v = e < n_coo && coo_i[e] >= 0;
+    const unsigned long long m = __ballot(v);
+    if (!m) return;
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)rl32((int)(base >> 32), 0) << 32) | (unsigned)rl32((int)(base & 0xffffffffull), 0);
+    if (!v) return;
+    const long long p = (long long)base + __popcll(m & lanemask_lt());
+    const int i = coo_i[e], j = coo_j[e];
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    rec[p * 4 + 0] = ((long long)a << 32) | (long long)(unsigned)b;
+    rec[p * 4 + 1] = __double_as_longlong(coo_hi[e]);
+    rec[p * 4 + 2] = __double_as_longlong(coo_lo[e]);
+    rec[p * 4 + 3] = (long long)(unsigned)coo_nij[e] | ((long long)coo_mutu[e] << 32);
+}
+
+__global__ __launch_bounds__(256) void k_partial_keys(long long n, const long long *rec, unsigned long long *keys, int *vals) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    keys[t] = (unsigned long long)rec[t * 4];
+    vals[t] = (int)t;
+}
+
+__global__ __launch_bounds__(256) void k_partial_gather(long long n, const long long *rec, const int *vals, long long *out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const long long s = vals[t];
+    const longlong2 a = *(const longlong2 *)(rec + s * 4), b = *(const longlong2 *)(rec + s * 4 + 2);
+    *(longlong2 *)(out + t * 4) = a;
+    *(longlong2 *)(out + t * 4 + 2) = b;
+}
+
+// records sorted by key, equal keys in rank order: the thread at the head of a run adds the run up (the dot product
+// exactly: the shares are exact (value, error) pairs), finishes the pair like finish_pair and appends it to the half COO
+template <int METHOD>
+__global__ __launch_bounds__(256) void k_merge_partials(long long n, const long long *rec, const double *nrm, int cap,
+                                                        unsigned long long *counters /*[0] kept, [1] evaluated*/, int *coo_i,
+                                                        int *coo_j, double *coo_sim, int *coo_mutu, int *coo_nij, int *rowcnt) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool head = false, keep = false;
+    int i = 0, j = 0, nn = 0, mm = 0;
+    double simv = 0.0;
+    if (t < n) {
+        const long long key = rec[t * 4];
+        head = t == 0 || rec[(t - 1) * 4] != key;
+        if (head) {
+            double hi = 0.0, lo = 0.0;
+            for (long long u = t; u < n && rec[u * 4] == key; u++) {
+                const double ph = __longlong_as_double(rec[u * 4 + 1]), pl = __longlong_as_double(rec[u * 4 + 2]);
+                if (METHOD == XMAP_COSINE) hi += ph;          // integer-exact
+                else { dd_add(hi, lo, ph); dd_add(hi, lo, pl); }
+                const unsigned long long c = (unsigned long long)rec[u * 4 + 3];
+                nn += (int)(c & 0xffffffffull); mm += (int)(c >> 32);
+            }
+            i = (int)(key >> 32); j = (int)(key & 0xffffffffll);
+            const double np = nrm[i] * nrm[j];                 // finish_pair
+            const double cs = (np != 0.0) ? 1.0 * hi / np : 0.0;
+            const int mn = nn < cap ? nn : cap;
+            simv = 1.0 * cs * (double)mn / (double)cap;
+            keep = (simv != 0.0) && (mm != 0);
+        }
+    }
+    const unsigned long long hm = __ballot(head), km = __ballot(keep);
+    if (!hm) return;
+    unsigned long long base = 0;
+    if (lane_id() == 0) {
+        atomicAdd(&counters[1], (unsigned long long)__popcll(hm));
+        if (km) base = atomicAdd(&counters[0], (unsigned long long)__popcll(km));
+    }
+    base = ((unsigned long long)(unsigned)rl32((int)(base >> 32), 0) << 32) | (unsigned)rl32((int)(base & 0xffffffffull), 0);
+    if (!keep) return;
+    const long long p = (long long)base + __popcll(km & lanemask_lt());
+    coo_i[p] = i; coo_j[p] = j; coo_sim[p] = simv; coo_mutu[p] = mm; coo_nij[p] = nn;
+    atomicAdd(&rowcnt[i], 1);
+    atomicAdd(&rowcnt[j], 1);
+}
+
 }  // namespace xmap
 
 using namespace xmap;
@@ -1010,7 +1097,9 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     XM_ARG(n_heavy_units == 0 || !(phases & 5) || (hp_hi && hp_lo && hp_cnt && hp_mut));
     // coo_ls selects the RecommenderSim variant: exact (double-double) sums, no filter, local sensitivity; its layout
     // has no heavy rows
-    XM_ARG(!coo_ls || (method == XMAP_ADJUST_COSINE && n_heavy_units == 0));
+    const bool raw = (phases & 32) != 0;      // partial sums of a user share: coo_ls is then the error column of the dot
+    XM_ARG(!coo_ls || ((raw || method == XMAP_ADJUST_COSINE) && n_heavy_units == 0));
+    XM_ARG(!raw || (coo_ls && n_heavy_units == 0 && n_heavy == 0));
     hipStream_t st = (hipStream_t)stream;
     if (phases & 8) {   // reset the COO cursor / counters / row counts
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
@@ -1030,6 +1119,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.shard_cap = coo_cap / COO_SHARDS; A.shard_cur = (unsigned long long *)d_shards;
     A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.coo_aux = coo_ls;
+    A.raw = raw ? 1 : 0;
     A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     // phases 1 | 2 | 4 in one call: the heavy rows (chunk partials, then their merge) run on a side stream of their own,
     // next to the class launches of the light rows -- they share nothing but the atomic COO cursors and counters
@@ -1071,7 +1161,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
             const dim3 grid((unsigned)(hi - lo));
             hipStream_t cs = side->s[c];
             XM_HIP(hipStreamWaitEvent(cs, side->fork, 0));
-            if (coo_ls) {
+            if (coo_ls && !raw) {
                 if (c == 0) k_pair_tri<XMAP_ADJUST_COSINE, 10, 16, true><<<grid, dim3(1024), 0, cs>>>(A);
                 else if (c == 1) k_pair_tri<XMAP_ADJUST_COSINE, 10, 4, true><<<grid, dim3(256), 0, cs>>>(A);
                 else if (c == 2) k_pair_tri<XMAP_ADJUST_COSINE, 9, 2, true><<<grid, dim3(128), 0, cs>>>(A);
@@ -1105,6 +1195,72 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         k_fold_heavy<<<dim3((unsigned)((n_heavy + 255) / 256)), dim3(256), 0, st>>>(n_heavy, hlist, rowcnt_h, rowcnt);
         XM_LAUNCH_CHECK();
     }
+    return XMAP_OK;
+}
+
+int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_hi,
+                            const double *coo_lo, const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][4]*/,
+                            int64_t *h_count) {
+    XM_ARG(coo_i && coo_j && coo_hi && coo_lo && coo_mutu && coo_nij && rec && h_count && n_coo >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *cur = nullptr;
+    XM_HIP(xm_malloc_async((void **)&cur, sizeof(unsigned long long), st));
+    XM_HIP(hipMemsetAsync(cur, 0, sizeof(unsigned long long), st));
+    if (n_coo > 0) {
+        k_pack_partials<<<dim3((unsigned)((n_coo + 255) / 256)), dim3(256), 0, st>>>(n_coo, coo_i, coo_j, coo_hi, coo_lo, coo_mutu,
+                                                                                     coo_nij, cur, (long long *)rec);
+        XM_LAUNCH_CHECK();
+    }
+    XM_HIP(hipMemcpyAsync(h_count, cur, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    XM_HIP(xm_free_async(cur, st));
+    return XMAP_OK;
+}
+
+int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t *rec_sorted) {
+    XM_ARG(rec && rec_sorted && n >= 0 && n < 0x7fffffffLL);
+    if (n == 0) return XMAP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *keys = nullptr;
+    int *vals = nullptr;
+    XM_HIP(xm_malloc_async((void **)&keys, sizeof(unsigned long long) * 2 * (size_t)n, st));
+    XM_HIP(xm_malloc_async((void **)&vals, sizeof(int) * 2 * (size_t)n, st));
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    k_partial_keys<<<grid, block, 0, st>>>(n, (const long long *)rec, keys, vals);
+    XM_LAUNCH_CHECK();
+    int rc = radix_sort_pairs(st, keys, vals, keys + n, vals + n, n, 64);
+    if (rc) return rc;
+    k_partial_gather<<<grid, block, 0, st>>>(n, (const long long *)rec, vals, (long long *)rec_sorted);
+    XM_LAUNCH_CHECK();
+    XM_HIP(xm_free_async(vals, st));
+    XM_HIP(xm_free_async(keys, st));
+    return XMAP_OK;
+}
+
+int xmap_sim2_merge_partials(void *stream, int method, int cap, int32_t n_items, int64_t n, const int64_t *rec_sorted,
+                             const double *norms, int32_t *coo_i, int32_t *coo_j, double *coo_sim, int32_t *coo_mutu,
+                             int32_t *coo_nij, int32_t *rowcnt, int64_t *h_counts /*[2]: kept, evaluated (unordered pairs)*/) {
+    XM_ARG(rec_sorted && norms && coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && h_counts && n >= 0 && cap > 0);
+    XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *cnt = nullptr;
+    XM_HIP(xm_malloc_async((void **)&cnt, 2 * sizeof(unsigned long long), st));
+    XM_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st));
+    XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(n_items > 0 ? n_items : 1), st));
+    if (n > 0) {
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        const double *nrm = norms + (method == XMAP_COSINE ? 0 : (size_t)n_items);
+        if (method == XMAP_COSINE)
+            k_merge_partials<XMAP_COSINE><<<grid, block, 0, st>>>(n, (const long long *)rec_sorted, nrm, cap, cnt, coo_i, coo_j, coo_sim,
+                                                                  coo_mutu, coo_nij, rowcnt);
+        else
+            k_merge_partials<XMAP_ADJUST_COSINE><<<grid, block, 0, st>>>(n, (const long long *)rec_sorted, nrm, cap, cnt, coo_i, coo_j,
+                                                                         coo_sim, coo_mutu, coo_nij, rowcnt);
+        XM_LAUNCH_CHECK();
+    }
+    XM_HIP(hipMemcpyAsync(h_counts, cnt, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    XM_HIP(xm_free_async(cnt, st));
     return XMAP_OK;
 }
 

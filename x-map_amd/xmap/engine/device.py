@@ -166,6 +166,65 @@ class Engine(object):
         check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user), i32(lo), i32(hi)))
         return u_avg, u_norm, info, ua_item, ia_user
 
+    def stats_partial(self):
+        """user-sharded input: CSC of this rank's users, their user info, and the rank's share of the item sums
+        [I][5] = (sum r, sum r^2, adjusted norm^2 as (value, error), raters) -- xmap.engine.sharded.run_step_users"""
+        R = self.R
+        st = _stream(self.dev)
+        self.build_csc()
+        u_avg = self._empty(max(R.n_users, 1), torch.float64)
+        u_norm = self._empty(max(R.n_users, 1), torch.float64)
+        check(lib.xmap_user_stats(st, C.byref(R.c), vp(u_avg), vp(u_norm)))
+        partial = self._out((max(R.n_items, 1), 5), torch.float64, R.n_items > 0)
+        check(lib.xmap_item_partials(st, C.byref(R.c), vp(u_avg), vp(partial)))
+        return u_avg, u_norm, partial
+
+    def stats_merge(self, parts):
+        """parts [n_parts][I][5] (the ranks' shares in rank order) -> info [I][4]; sets self.norms"""
+        I = self.R.n_items
+        parts = parts.contiguous()
+        info = self._out((max(I, 1), 4), torch.float64, I > 0)
+        self.norms = self._out(2 * max(I, 1), torch.float64, I > 0)
+        check(lib.xmap_item_merge(_stream(self.dev), i32(I), i32(int(parts.shape[0])), vp(parts), vp(info), vp(self.norms)))
+        return info
+
+    def partial_records(self, coo, n):
+        """raw half COO (tri_pairs(raw=True)) -> [n][4] int64 records sorted by key"""
+        st = _stream(self.dev)
+        coo_i, coo_j, coo_hi, coo_mutu, coo_nij, coo_lo = coo
+        rec = self._empty((max(n, 1), 4), torch.int64)
+        cnt = C.c_int64(0)
+        check(lib.xmap_sim2_pack_partials(st, i64(int(coo_i.numel())), vp(coo_i), vp(coo_j), vp(coo_hi), vp(coo_lo), vp(coo_mutu),
+                                          vp(coo_nij), vp(rec), C.byref(cnt)))
+        assert int(cnt.value) == n, (int(cnt.value), n)
+        return self.sort_records(rec[:n])
+
+    def sort_records(self, rec):
+        n = int(rec.shape[0])
+        out = self._empty((max(n, 1), 4), torch.int64)
+        if n:
+            check(lib.xmap_sim2_sort_partials(_stream(self.dev), i64(n), vp(rec.contiguous()), vp(out)))
+        return out[:n]
+
+    def merge_records(self, rec_sorted, method, cap):
+        """all records of the pairs this rank owns (sorted by key, equal keys in rank order) -> (coo, rowcnt, kept, evaluated)"""
+        st = _stream(self.dev)
+        I = self.R.n_items
+        m = abi.METHODS[method] if isinstance(method, str) else int(method)
+        n = int(rec_sorted.shape[0])
+        coo_i = torch.full((max(n, 1),), -1, dtype=torch.int32, device=self.dev)
+        coo_j = self._empty(max(n, 1), torch.int32)
+        coo_sim = self._empty(max(n, 1), torch.float64)
+        coo_mutu = self._empty(max(n, 1), torch.int32)
+        coo_nij = self._empty(max(n, 1), torch.int32)
+        rowcnt = self._empty(max(I, 1), torch.int32)
+        h = (C.c_int64 * 2)()
+        check(lib.xmap_sim2_merge_partials(st, m, int(cap), i32(I), i64(n), vp(rec_sorted.contiguous()), vp(self.norms), vp(coo_i),
+                                           vp(coo_j), vp(coo_sim), vp(coo_mutu), vp(coo_nij), vp(rowcnt), h))
+        kept, evaluated = int(h[0]), int(h[1])
+        k1 = max(kept, 1)
+        return (coo_i[:k1], coo_j[:k1], coo_sim[:k1], coo_mutu[:k1], coo_nij[:k1]), rowcnt, kept, evaluated
+
     def plan(self, slot_target=640):
         """work decomposition of the pair kernel: units = (item, hash partition of its partner space)"""
         R = self.R
@@ -310,7 +369,7 @@ class Engine(object):
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
-    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False):
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
         rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity)."""
         R = self.R
@@ -328,7 +387,7 @@ class Engine(object):
             coo_sim = self._empty(cap_coo, torch.float64)
             coo_mutu = self._empty(cap_coo, torch.int32)
             coo_nij = self._empty(cap_coo, torch.int32)
-            coo_ls = self._empty(cap_coo, torch.float64) if rec else None
+            coo_ls = self._empty(cap_coo, torch.float64) if (rec or raw) else None    # raw: the error column of the dot
             rowcnt = self._empty(max(I, 1), torch.int32)
             nh = L.n_heavy_units if do_heavy else 0
             hp_hi = self._empty(max(nh, 1) * 1024, torch.float64)
@@ -351,12 +410,12 @@ class Engine(object):
                 with self.timed("pair_heavy"):
                     run(8 | (1 if do_heavy else 0))
                 with self.timed("pair_tri"):
-                    run(2)
+                    run(2 | (32 if raw else 0))
                 with self.timed("heavy_merge"):
                     run((4 if do_heavy else 0) | 16)
             else:       # the heavy rows (chunk partials + merge) on a side stream next to the class launches of the light rows
                 with self.timed("pair_tri"):
-                    run(8 | 2 | 16 | (5 if do_heavy else 0))
+                    run(8 | 2 | 16 | (5 if do_heavy else 0) | (32 if raw else 0))
             h = d_cnt.tolist()
             if h[2]:
                 if L.slot_target <= 32:
@@ -373,7 +432,7 @@ class Engine(object):
             break
         sh = d_shards.view(2, 4096).sum(dim=1).tolist()
         n, n_unordered = int(sh[0]), int(sh[1])
-        coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if rec else ())
+        coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if (rec or raw) else ())
         out = (coo, rowcnt, n, n_unordered)
         return out if retry else out + (0,)
 

@@ -14,6 +14,9 @@ everywhere), the reverse and middle lists are still derived on every rank, the p
 fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
 passes over nnz and is replicated.
 
+run_step_users is the other split (inputs sharded by USER, the partial similarities of a pair exchanged and added up at
+the pair's owner): see its docstring.
+
 Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on the MI355X node; "gloo"
 (host staging) is used by the CPU-side tests and for rehearsals with several ranks on one GPU.
 """
@@ -101,6 +104,38 @@ class Comm(object):
         return out.to(dev)
 
 
+    def all_gather_fixed(self, t):
+        """[world, *t.shape]: the same-shaped tensor of every rank, in rank order"""
+        src = t.contiguous().cpu() if self.host else t.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(parts, src, group=self.group)
+        return torch.stack(parts).to(t.device)
+
+    def all_to_all_rows(self, rows, cuts):
+        """rows [n, w] int64 cut into `world` consecutive row ranges by cuts (world + 1 indices): range r goes to rank r.
+        Returns the ranges received, concatenated in rank order.  RCCL: one all_to_all_single with the split sizes; gloo
+        (no all-to-all): every rank all-gathers everything and keeps its ranges."""
+        w = int(rows.shape[1])
+        send = [int(cuts[r + 1] - cuts[r]) for r in range(self.world)]
+        table = torch.tensor(send, dtype=torch.int64)
+        if not self.host:
+            table = table.to(rows.device)
+        tabs = [torch.zeros_like(table) for _ in range(self.world)]
+        self.dist.all_gather(tabs, table, group=self.group)
+        tabs = torch.stack(tabs).cpu()                     # tabs[s][r]: rows rank s sends to rank r
+        if self.host:
+            allrows = self.all_gather_var(rows.reshape(-1)).view(-1, w)
+            start = torch.cumsum(tabs.sum(dim=1), 0) - tabs.sum(dim=1)      # first row of rank s in allrows
+            inner = torch.cumsum(tabs, 1) - tabs                            # offset of the range for r inside s's rows
+            parts = [allrows[int(start[s] + inner[s][self.rank]):int(start[s] + inner[s][self.rank] + tabs[s][self.rank])]
+                     for s in range(self.world)]
+            return torch.cat(parts) if parts else allrows[:0]
+        recv = [int(tabs[s][self.rank]) for s in range(self.world)]
+        out = torch.empty((sum(recv), w), dtype=rows.dtype, device=rows.device)
+        self.dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv, input_split_sizes=send, group=self.group)
+        return out
+
+
 # ----------------------------------------------------------------------------- the step
 def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=False, group=None):
     """stage A -> B -> C once.  Returns the counters the bench reports.  group: the process group that shares this
@@ -168,6 +203,101 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         comm.all_reduce(tot)
         it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
         light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
+    S, E, pt = _stage_b(eng, comm, coo, rowcnt, stats[2], L, k, rank, world)
+    # ---- stage C: replicated (a few ms)
+    with eng.timed("stage_c"):
+        n_top, choice, mp = eng.select(E, private)
+        G = eng.alterego(mp)
+        n_prof = eng.n_profiles(G)
+    return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * L.half_contrib,
+                n_contrib_light=light_local, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
+                n_rows=G.n_rows, n_profiles=n_prof, knn_entries=int(E.kcnt.sum().item()),
+                S=S, S_part=S_part, E=E, G=G, choice=choice, map=mp)
+
+
+class _Rows(object):
+    """AlterEgo rows gathered from the ranks (same attributes as the engine's GenResult)"""
+    pass
+
+
+def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot_target=640):
+    """stage A -> B -> C once over USER-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard
+    partial similarities"): eng.R holds the complete profiles of this rank's users -- users [user_lo, user_lo + n_users) of
+    the whole data set, items indexed globally -- instead of a replica of all ratings.
+
+    Stage A: every rank sums its users' contributions.  Item statistics: the shares [I][5] are all-gathered (the all-gather
+    of per-item norms) and added up in rank order, the adjusted norm exactly.  Pairs: the pair kernel runs over the rank's
+    users in "raw" mode and emits, per pair two of its users co-rated, the partial dot product (an exact (value, error)
+    pair), n_ij and the mutuality; the 32-byte records are sorted by pair key and sent to the rank that owns the pair's
+    lower item (all-to-all of sparse partials = the reduce-scatter: every rank receives only the shares of its own pairs,
+    added up on arrival -- the dot product exactly, so the result does not depend on the number of ranks); the owner
+    finishes the pair (cosine, significance weighting, zero filter).  From there the step is the item-sharded one: the kept
+    pairs are exchanged for stage B, the path enumeration is sharded by start item.  Stage C runs over the rank's own users
+    and the AlterEgo rows are concatenated in rank (= user) order."""
+    comm = Comm(dist, group)
+    rank, world = comm.rank, comm.world
+    I = eng.R.n_items
+    dev = eng.dev
+    with eng.timed("stage_a"):
+        u_avg, u_norm, partial = eng.stats_partial()
+        with eng.timed("stats_gather"):
+            parts = comm.all_gather_fixed(partial)
+        info = eng.stats_merge(parts)
+        # the layout of the rank's pair kernel orders items by their LOCAL rater counts (its partner bounds are local);
+        # the item averages behind the mutuality flags are the global ones
+        info_loc = info.clone()
+        if I:
+            info_loc[:I, 3] = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1]).double()
+        stats_loc = (u_avg, u_norm, info_loc, None, None)
+        err, out = None, None
+        try:
+            L = eng.tri_layout(stats_loc, slot_target, ch_min=max(64, eng.R.n_users + 2))       # no heavy set
+            out = eng.tri_pairs(method, cap, stats_loc, L, do_heavy=False, raw=True)
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage A (pair kernels)")
+        coo_raw, _, n_raw, _ = out
+        rec = eng.partial_records(coo_raw, n_raw)                # sorted by key = lower item << 32 | higher item
+        del coo_raw, out
+        with eng.timed("exchange_partials"):
+            thr = torch.tensor([(I * r // world) << 32 for r in range(1, world)], dtype=torch.int64, device=dev)
+            inner = torch.searchsorted(rec[:, 0].contiguous(), thr).tolist() if n_raw else [0] * (world - 1)
+            cuts = [0] + [int(x) for x in inner] + [n_raw]
+            got = comm.all_to_all_rows(rec, cuts)
+        err = None
+        try:
+            got = eng.sort_records(got)                          # stable: the shares of a pair stay in rank order
+            coo, rowcnt, n, n_unordered = eng.merge_records(got, method, cap)
+            S_part = eng.tri_scatter(coo, rowcnt, info, n, L)
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage A (merge of the partial similarities)")
+        tot = torch.tensor([n_unordered, n, L.half_contrib], dtype=torch.int64, device=dev)
+        comm.all_reduce(tot)
+    S, E, pt = _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world)
+    S.u_avg = None                         # user info stays with the rank that holds the users
+    with eng.timed("stage_c"):
+        n_top, choice, mp = eng.select(E, private)
+        Gl = eng.alterego(mp)
+        G = _Rows()
+        G.user = comm.all_gather_var(Gl.user.long() + int(user_lo))
+        G.item = comm.all_gather_var(Gl.item)
+        G.rating = comm.all_gather_var(Gl.rating)
+        G.time = comm.all_gather_var(Gl.time)
+        G.n_rows = int(G.user.numel())
+        prof = torch.tensor([eng.n_profiles(Gl)], dtype=torch.int64, device=dev)
+        comm.all_reduce(prof)
+    return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * int(tot[2].item()),
+                n_contrib_light=2 * L.half_contrib, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
+                n_rows=G.n_rows, n_profiles=int(prof.item()), knn_entries=int(E.kcnt.sum().item()),
+                S=S, S_part=S_part, E=E, G=G, G_local=Gl, choice=choice, map=mp, info=info)
+
+
+def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world):
+    """stage B of a sharded step: coo / rowcnt = the kept pairs this rank holds (any orientation, every unordered pair on
+    exactly one rank).  Returns (S: the full similarity matrix, E: the extension with the candidate arrays of ALL starts,
+    [paths, candidates] over all ranks)."""
+    dev = eng.dev
     # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
     # ranges balanced by the exact per-start path counts
     with eng.timed("stage_b"):
@@ -187,7 +317,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
                    (rec[:, 2] >> 32).to(torch.int32)]
         err = None
         try:
-            S = eng.tri_scatter(coo, rowcnt, stats[2], None, L)
+            S = eng.tri_scatter(coo, rowcnt, info, None, L)
             E = eng.extend(S, k, full=False, start_split=(rank, world), comm=comm)
         except Exception as e:
             err = e
@@ -197,12 +327,5 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         comm.all_reduce(E.top_val)                    # 0.0 outside the local range
         pt = torch.tensor([E.n_paths, E.n_out], dtype=torch.int64, device=dev)
         comm.all_reduce(pt)
-    # ---- stage C: replicated (a few ms)
-    with eng.timed("stage_c"):
-        n_top, choice, mp = eng.select(E, private)
-        G = eng.alterego(mp)
-        n_prof = eng.n_profiles(G)
-    return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * L.half_contrib,
-                n_contrib_light=light_local, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
-                n_rows=G.n_rows, n_profiles=n_prof, knn_entries=int(E.kcnt.sum().item()),
-                S=S, S_part=S_part, E=E, G=G, choice=choice, map=mp)
+    return S, E, pt
+
