@@ -350,7 +350,7 @@ def main():
     t0 = time.time()
     r = wl["gen"]()
     attrs = r.item_attrs()
-    by_users = args.layout == "users" and dist is not None and world > 1
+    by_users = args.layout == "users" and dist is not None      # (with XMAP_FORCE_DIST=1: one share, the exchange through RCCL)
     u_lo = 0
     if by_users:       # this rank's share of the users (complete profiles), items indexed globally
         u_lo, u_hi = r.n_users * rank // world, r.n_users * (rank + 1) // world

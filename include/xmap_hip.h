@@ -173,8 +173,9 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
  * calculate_cosine_sim / calculate_adjusted_cosine_sim (:115-174) and retrieve_path_info (:97-113) unfinished and unfiltered:
  * coo_sim / coo_ls = the dot product as an exact (value, error) pair, coo_nij, coo_mutu.  xmap_sim2_pack_partials turns
  * them into 32-byte records (key = lower index << 32 | higher index, value, error, n_ij | mutu << 32; *h_count of them),
- * xmap_sim2_sort_partials orders records by key (stable), and -- after the records have been exchanged so that every
- * rank holds ALL records of the pairs it owns, ordered by key with equal keys in rank order -- xmap_sim2_merge_partials adds
+ * xmap_sim2_sort_partials groups them by the rank that owns the lower item (stable radix sort), and -- after the exchange,
+ * sorted once more by pair key (stable: the shares of a pair stay in rank order), so that every rank holds ALL records of the
+ * pairs it owns -- xmap_sim2_merge_partials adds
  * the shares of a pair up (the dot product exactly), applies cosine, significance weighting and the zero filter
  * (:84-95,:198,:207) with the merged item norms and appends the kept pairs (i < j) to a half COO + row counts, which
  * xmap_sim2_scatter mirrors as usual.  h_counts = {kept, evaluated} unordered pairs. */
@@ -184,7 +185,8 @@ int xmap_item_merge(void *stream, int32_t n_items, int32_t n_parts, const double
 int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_hi,
                             const double *coo_lo, const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][4]*/,
                             int64_t *h_count);
-int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec /*[n][4]*/, int64_t *rec_sorted /*[n][4]*/);
+int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec /*[n][4]*/, int64_t *rec_sorted /*[n][4]*/, int32_t n_items,
+                            int32_t n_owners /*> 0: group by the rank owning the lower item (before the exchange); 0: by pair key*/);
 int xmap_sim2_merge_partials(void *stream, int method, int cap, int32_t n_items, int64_t n, const int64_t *rec_sorted,
                              const double *norms /*[2][I]*/, int32_t *coo_i, int32_t *coo_j, double *coo_sim, int32_t *coo_mutu,
                              int32_t *coo_nij, int32_t *rowcnt /*[I]*/, int64_t *h_counts /*[2]*/);

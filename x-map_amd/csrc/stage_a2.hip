@@ -891,10 +891,22 @@ __global__ __launch_bounds__(256) void k_pack_partials(long long n_coo, const in
     rec[p * 4 + 3] = (long long)(unsigned)coo_nij[e] | ((long long)coo_mutu[e] << 32);
 }
 
-__global__ __launch_bounds__(256) void k_partial_keys(long long n, const long long *rec, unsigned long long *keys, int *vals) {
+// sort key of a record: the pair key squeezed to 2 * bits_b bits (same order), or -- n_owners > 0, before the exchange --
+// the rank that owns the lower item (items [I r / n_owners, I (r + 1) / n_owners) belong to rank r)
+__global__ __launch_bounds__(256) void k_partial_keys(long long n, const long long *rec, int bits_b, int n_items, int n_owners,
+                                                      unsigned long long *keys, int *vals) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    keys[t] = (unsigned long long)rec[t * 4];
+    const unsigned long long k = (unsigned long long)rec[t * 4];
+    const long long a = (long long)(k >> 32), b = (long long)(k & 0xffffffffull);
+    if (n_owners > 0) {
+        long long r = a * n_owners / n_items;
+        while (r + 1 < n_owners && (long long)n_items * (r + 1) / n_owners <= a) r++;
+        while (r > 0 && (long long)n_items * r / n_owners > a) r--;
+        keys[t] = (unsigned long long)r;
+    } else {
+        keys[t] = ((unsigned long long)a << bits_b) | (unsigned long long)b;
+    }
     vals[t] = (int)t;
 }
 
@@ -1217,18 +1229,22 @@ int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, c
     return XMAP_OK;
 }
 
-int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t *rec_sorted) {
-    XM_ARG(rec && rec_sorted && n >= 0 && n < 0x7fffffffLL);
+int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t *rec_sorted, int32_t n_items, int32_t n_owners) {
+    XM_ARG(rec && rec_sorted && n >= 0 && n < 0x7fffffffLL && n_items > 0 && n_owners >= 0 && n_owners <= 65536);
     if (n == 0) return XMAP_OK;
+    int bits_b = 1;
+    while ((1ll << bits_b) < (long long)n_items) bits_b++;
+    int bits = 2 * bits_b;
+    if (n_owners > 0) { bits = 1; while ((1 << bits) < n_owners) bits++; }
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *keys = nullptr;
     int *vals = nullptr;
     XM_HIP(xm_malloc_async((void **)&keys, sizeof(unsigned long long) * 2 * (size_t)n, st));
     XM_HIP(xm_malloc_async((void **)&vals, sizeof(int) * 2 * (size_t)n, st));
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    k_partial_keys<<<grid, block, 0, st>>>(n, (const long long *)rec, keys, vals);
+    k_partial_keys<<<grid, block, 0, st>>>(n, (const long long *)rec, bits_b, n_items, n_owners, keys, vals);
     XM_LAUNCH_CHECK();
-    int rc = radix_sort_pairs(st, keys, vals, keys + n, vals + n, n, 64);
+    int rc = radix_sort_pairs(st, keys, vals, keys + n, vals + n, n, bits);
     if (rc) return rc;
     k_partial_gather<<<grid, block, 0, st>>>(n, (const long long *)rec, vals, (long long *)rec_sorted);
     XM_LAUNCH_CHECK();

@@ -188,8 +188,8 @@ class Engine(object):
         check(lib.xmap_item_merge(_stream(self.dev), i32(I), i32(int(parts.shape[0])), vp(parts), vp(info), vp(self.norms)))
         return info
 
-    def partial_records(self, coo, n):
-        """raw half COO (tri_pairs(raw=True)) -> [n][4] int64 records sorted by key"""
+    def partial_records(self, coo, n, n_owners):
+        """raw half COO (tri_pairs(raw=True)) -> [n][4] int64 records grouped by the rank that owns the pair's lower item"""
         st = _stream(self.dev)
         coo_i, coo_j, coo_hi, coo_mutu, coo_nij, coo_lo = coo
         rec = self._empty((max(n, 1), 4), torch.int64)
@@ -197,13 +197,15 @@ class Engine(object):
         check(lib.xmap_sim2_pack_partials(st, i64(int(coo_i.numel())), vp(coo_i), vp(coo_j), vp(coo_hi), vp(coo_lo), vp(coo_mutu),
                                           vp(coo_nij), vp(rec), C.byref(cnt)))
         assert int(cnt.value) == n, (int(cnt.value), n)
-        return self.sort_records(rec[:n])
+        return self.sort_records(rec[:n], n_owners)
 
-    def sort_records(self, rec):
+    def sort_records(self, rec, n_owners=0):
+        """stable sort of partial records: by owner of the lower item (n_owners > 0) or by pair key"""
         n = int(rec.shape[0])
         out = self._empty((max(n, 1), 4), torch.int64)
         if n:
-            check(lib.xmap_sim2_sort_partials(_stream(self.dev), i64(n), vp(rec.contiguous()), vp(out)))
+            check(lib.xmap_sim2_sort_partials(_stream(self.dev), i64(n), vp(rec.contiguous()), vp(out), i32(self.R.n_items),
+                                              i32(n_owners)))
         return out[:n]
 
     def merge_records(self, rec_sorted, method, cap):

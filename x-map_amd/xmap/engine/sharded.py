@@ -56,6 +56,7 @@ def unit_cuts(c, w_heavy, world):
 
 class Comm(object):
     """Thin wrapper over torch.distributed that stages through the host for gloo."""
+    A2A_PIECE_BYTES = 1 << 28
 
     def __init__(self, dist, group=None):
         """group: a torch.distributed process group (None = all ranks); rank / world are relative to it"""
@@ -132,7 +133,22 @@ class Comm(object):
             return torch.cat(parts) if parts else allrows[:0]
         recv = [int(tabs[s][self.rank]) for s in range(self.world)]
         out = torch.empty((sum(recv), w), dtype=rows.dtype, device=rows.device)
-        self.dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv, input_split_sizes=send, group=self.group)
+        # In pieces of at most 256 MiB per peer: RCCL 2.26's all_to_all_single returned wrong data for pieces above 1 GiB
+        # (measured with one rank: 1.28 GB of int64 rows came back wrong from byte 640 M on; all_gather / all_reduce of
+        # 2 GiB were fine).  Piece c of sender s lands behind its pieces 0 .. c-1, so the result is sender-major as above.
+        piece = max(1, self.A2A_PIECE_BYTES // (rows.element_size() * w))
+        rounds = (int(tabs.max()) + piece - 1) // piece
+        first = [sum(recv[:s_]) for s_ in range(self.world)]
+        for c in range(rounds):
+            send_c = [min(max(n_ - c * piece, 0), piece) for n_ in send]
+            recv_c = [min(max(n_ - c * piece, 0), piece) for n_ in recv]
+            buf = torch.cat([rows[int(cuts[r]) + c * piece:int(cuts[r]) + c * piece + send_c[r]] for r in range(self.world)])
+            tmp = torch.empty((sum(recv_c), w), dtype=rows.dtype, device=rows.device)
+            self.dist.all_to_all_single(tmp, buf.contiguous(), output_split_sizes=recv_c, input_split_sizes=send_c, group=self.group)
+            at = 0
+            for s_ in range(self.world):
+                out[first[s_] + c * piece:first[s_] + c * piece + recv_c[s_]] = tmp[at:at + recv_c[s_]]
+                at += recv_c[s_]
         return out
 
 
@@ -257,10 +273,11 @@ def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot
             err = e
         comm.agree(err, "stage A (pair kernels)")
         coo_raw, _, n_raw, _ = out
-        rec = eng.partial_records(coo_raw, n_raw)                # sorted by key = lower item << 32 | higher item
+        rec = eng.partial_records(coo_raw, n_raw, world)         # grouped by owner of the lower item (key = lower << 32 | higher)
         del coo_raw, out
         with eng.timed("exchange_partials"):
             thr = torch.tensor([(I * r // world) << 32 for r in range(1, world)], dtype=torch.int64, device=dev)
+            # (the keys are ordered group-wise only: "key < first key of rank r" is still monotone along the array)
             inner = torch.searchsorted(rec[:, 0].contiguous(), thr).tolist() if n_raw else [0] * (world - 1)
             cuts = [0] + [int(x) for x in inner] + [n_raw]
             got = comm.all_to_all_rows(rec, cuts)
