@@ -202,3 +202,49 @@ def test_user_sharded_equals_world1(world, method):
     full_rows = np.repeat(np.arange(I), np.diff(ref["row_ptr"]))
     assert np.array_equal(rows[o], full_rows) and np.array_equal(cols[o], ref["col"])
     assert np.array_equal(sims[o], ref["sim"])
+
+
+def _rccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from xmap.engine import sharded
+    sharded.Comm.A2A_PIECE_BYTES = 1 << 12        # 128 records per piece: the all-to-all takes hundreds of rounds
+    eng, lo = _user_share(0, 1)
+    res = sharded.run_step_users(eng, lo, "adjust_cosine", 50, 5, True, dist)
+    out = _summary(res)
+    out["info"] = res["info"].cpu().numpy()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_user_sharded_collectives_through_rccl():
+    """the user-sharded step with ONE share and RCCL as the backend: every collective of the path (fixed and variable
+    all-gathers, the all-to-all of the partial records in many small pieces, all-reduces) runs on device buffers; the
+    result is the plain step's"""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    from xmap.engine import sharded
+    one = sharded.run_step(_engine(), "adjust_cosine", 50, 5, True)
+    ref = _summary(one)
+    ref["info"] = one["S"].info.cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    for d in (ref, out):
+        o = np.lexsort((d["ae_rating"], d["ae_item"], d["ae_user"]))
+        for key in ("ae_user", "ae_item", "ae_rating"):
+            d[key] = np.asarray(d[key])[o]
+    for key, v in ref.items():
+        if not key.startswith("part_"):
+            assert np.array_equal(out[key], v), key
