@@ -38,6 +38,7 @@ while time.time() < t_end:
     if rng.random() < 0.3: os.environ["XMAP_REV_LONG"] = "64"
     else: os.environ.pop("XMAP_REV_LONG", None)
     rr = synth.make_two_domain(seed, U, Is, It, overlap=ov, mu=mu, sigma=sg)
+    print("shape", n, dict(seed=seed, U=U, Is=Is, It=It, k=k, method=method), flush=True)     # (a silent run is taken to be hung)
     try:
         T._check_all_stages(device, rr, method, k, private=bool(rng.integers(0, 2)))
     except Exception:
