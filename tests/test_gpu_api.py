@@ -140,3 +140,36 @@ def test_multidomain_driver(tmp_path):
     mae = mod.main(["--users", "1200", "--items", "250", "--workdir", str(tmp_path)])
     a, b = [float(x) for x in mae.split(";")]
     assert 0.0 < a < 2.5 and 0.0 < b < 2.5
+
+
+def test_handles_release_their_buffers_when_dropped():
+    """a dropped pipeline handle gives its HBM buffers back at once (no reference cycle inside the handle: at BASELINE
+    configs[1] an extension holds 13 GB, which must not wait for the cyclic garbage collector)"""
+    import gc
+    import torch
+    from pyspark import SparkContext, SparkConf
+    from pyspark.sql import SQLContext
+    from xmap.core.baselinerSim import BaselinerSim
+    from xmap.core.extender import ExtendSim
+    from xmap.core.generator import Generator
+    from xmap.utils.assist import baseliner_calculate_sim_pipeline, extender_pipeline, generator_pipeline
+    gold = Golden("small")
+    sc = SparkContext(conf=SparkConf().setAppName("release"))
+    trainRDD = sc.parallelize(records(gold), 4).cache()
+    tool = BaselinerSim("cosine", CAP)
+    gc.collect()
+    gc.disable()
+    try:
+        sim = baseliner_calculate_sim_pipeline(sc, tool, trainRDD)
+        ext = extender_pipeline(sc, SQLContext(sc), tool, ExtendSim(5), sim)      # (allocates the engine's persistent scratch)
+        ae = generator_pipeline(Generator(1, 0.6, "cosine", 0.1), trainRDD, ext, True)
+        del ext, ae
+        base = torch.cuda.memory_allocated()
+        for _ in range(2):
+            ext = extender_pipeline(sc, SQLContext(sc), tool, ExtendSim(5), sim)
+            ae = generator_pipeline(Generator(1, 0.6, "cosine", 0.1), trainRDD, ext, True)
+            assert torch.cuda.memory_allocated() > base
+            del ext, ae
+            assert torch.cuda.memory_allocated() <= base
+    finally:
+        gc.enable()

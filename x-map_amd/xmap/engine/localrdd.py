@@ -17,8 +17,14 @@ class LocalRDD(object):
     @property
     def _data(self):
         if self._items is None:
-            self._items = list(self._thunk())
+            # handles (subclasses owning HBM buffers) define _rows(); it is looked up here rather than stored as a bound
+            # method: self -> bound method -> self would be a reference cycle, and the buffers of a dropped handle (13 GB
+            # for an extension at BASELINE configs[1]) would stay allocated until the cyclic collector happens to run
+            self._items = list((self._thunk or self._rows)())
         return self._items
+
+    def _rows(self):
+        raise ValueError("LocalRDD without data")
 
     def _new(self, data):
         return LocalRDD(data, self.ctx)

@@ -91,7 +91,7 @@ class SimPairsRDD(LocalRDD):
     """item2item_simRDD: ((iid1, iid2), (sim, mutu, frac_mutu, label)) -- rows live in HBM."""
 
     def __init__(self, state, S, ctx=None):
-        LocalRDD.__init__(self, None, ctx, self._rows)
+        LocalRDD.__init__(self, None, ctx)
         self.state, self.S = state, S
 
     def _rows(self):
@@ -117,7 +117,7 @@ class RecSimRDD(LocalRDD):
     HBM (Engine.rec_sim); both directions of every pair, an item paired with itself once."""
 
     def __init__(self, S, iids, ctx=None, engine=None):
-        LocalRDD.__init__(self, None, ctx, self._rows)
+        LocalRDD.__init__(self, None, ctx)
         self.S, self.iids, self.engine = S, iids, engine
 
     def select_neighbors(self, keep):
@@ -166,7 +166,7 @@ class ExtendedSimRDD(LocalRDD):
     enumeration then runs once more with list buffers sized exactly from the candidate counts."""
 
     def __init__(self, state, E, ctx=None):
-        LocalRDD.__init__(self, None, ctx, self._rows)
+        LocalRDD.__init__(self, None, ctx)
         self.state, self.E = state, E
 
     @property
@@ -193,7 +193,7 @@ class AlterEgoRDD(LocalRDD):
     """alterEgo_profile: (uid, iid, rating, time) rows -- generator.py:140-157."""
 
     def __init__(self, state, G, ctx=None):
-        LocalRDD.__init__(self, None, ctx, self._rows)
+        LocalRDD.__init__(self, None, ctx)
         self.state, self.G = state, G
 
     def _rows(self):
