@@ -1290,14 +1290,28 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     MidDir cur;
     cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
     if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+#ifdef Q_NO_DPP_MERGE
+    const int nloc = 64;
+#else
+    const int nloc = (nH - h0) < 64 ? (int)(nH - h0) : 64;      // heads of this batch (lanes 0 .. nloc-1)
+#endif
     for (;;) {
         // smallest column among the heads: xor butterfly inside each half of the wave (ds_swizzle: no address registers),
         // then the two halves
         int xmin = cur.x;
+#define XM_DPP_MIN(CTRL) { const int o = __builtin_amdgcn_update_dpp(INF, xmin, CTRL, 0xf, 0xf, false); xmin = o < xmin ? o : xmin; }
 #define XM_SWZ_MIN(PAT) { const int o = __builtin_amdgcn_ds_swizzle(xmin, PAT); xmin = o < xmin ? o : xmin; }
-        XM_SWZ_MIN(0x041F) XM_SWZ_MIN(0x081F) XM_SWZ_MIN(0x101F) XM_SWZ_MIN(0x201F) XM_SWZ_MIN(0x401F)
+        if (nloc <= 16) {      // the common batch of a few heads: DPP inside the first row of lanes, no LDS round trips
+            XM_DPP_MIN(0xB1) XM_DPP_MIN(0x4E)                               // quad_perm [1,0,3,2], [2,3,0,1]
+            if (nloc > 4) { XM_DPP_MIN(0x141) XM_DPP_MIN(0x140) }           // row_half_mirror, row_mirror
+            xmin = rl32(xmin, 0);
+        } else {
+            XM_SWZ_MIN(0x041F) XM_SWZ_MIN(0x081F) XM_SWZ_MIN(0x101F) XM_SWZ_MIN(0x201F) XM_SWZ_MIN(0x401F)
+            const int x0 = rl32(xmin, 0), x1 = rl32(xmin, 32);
+            xmin = x0 < x1 ? x0 : x1;
+        }
 #undef XM_SWZ_MIN
-        { const int x0 = rl32(xmin, 0), x1 = rl32(xmin, 32); xmin = x0 < x1 ? x0 : x1; }
+#undef XM_DPP_MIN
         if (xmin == INF) break;
         const bool mine = cur.x == xmin;
         const unsigned long long part = __ballot(mine);
