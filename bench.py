@@ -496,6 +496,13 @@ def main():
                 "traffic_fetch_x1": pmc_traffic("k_paths4_fetch_x1"),     # FETCH_SIZE as is: exact for lone 32-byte reads (profiles/README.md)
                 "algorithmic_bytes_per_launch": bytes_paths, "launch_ms": paths_ms,
                 "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                # the kernel's other limit: 26 fp64 operations per path-end pair (3 to join record and end, 8 division, 1
+                # product, 14 for the two exact sums; no FMA pairs by construction: -ffp-contract=off) against the vector
+                # fp64 issue rate (78.6 TFLOP/s counts an FMA as two: 39.3e12 instructions x lanes per second); the SQ
+                # counters of profiles/*_sq_k_paths4.json give the busy fraction of the vector ALUs directly (55 %)
+                "valu": {"bound": "valu_fp64", "achieved": 26.0 * res["n_paths"] / (paths_ms * 1e-3) / 1e12 if paths_ms > 0 else 0.0,
+                         "peak": 39.3, "unit": "Tinstr/s (fp64 lane operations)",
+                         "frac": 26.0 * res["n_paths"] / (paths_ms * 1e-3) / 39.3e12 if paths_ms > 0 else 0.0},
                 "note": "per column (start, x): one set of lanes (W ends x S record slices) and one read-modify-write of the "
                         "start's row (32-byte (value, error) pairs, rows indexed by end rank in column order); ablations "
                         "(profiles/README.md): 464 ms without the row updates, 615 ms without the path arithmetic"}
