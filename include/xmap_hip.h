@@ -179,6 +179,13 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
  * the shares of a pair up (the dot product exactly), applies cosine, significance weighting and the zero filter
  * (:84-95,:198,:207) with the merged item norms and appends the kept pairs (i < j) to a half COO + row counts, which
  * xmap_sim2_scatter mirrors as usual.  h_counts = {kept, evaluated} unordered pairs. */
+/* The exchange of a sharded step's kept pairs before stage B (the reference broadcasts its knn tables, utils/assist.py:88-101):
+ * valid entries of a half COO (coo_i >= 0) -> 24-byte records (i | j << 32, sim bits, mutu | n_ij << 32), *h_count of them,
+ * in any order; and back into COO columns after the all-gather. */
+int xmap_sim2_pack_pairs(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
+                         const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][3]*/, int64_t *h_count);
+int xmap_sim2_unpack_pairs(void *stream, int64_t n, const int64_t *rec /*[n][3]*/, int32_t *coo_i, int32_t *coo_j, double *coo_sim,
+                           int32_t *coo_mutu, int32_t *coo_nij);
 int xmap_item_partials(void *stream, const xmap_ratings *R, const double *u_avg, double *partial /*[I][5]*/);
 int xmap_item_merge(void *stream, int32_t n_items, int32_t n_parts, const double *parts /*[n_parts][I][5]*/, double *info /*[I][4]*/,
                     double *norms /*[2][I]*/);

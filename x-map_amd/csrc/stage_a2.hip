@@ -893,6 +893,35 @@ __global__ __launch_bounds__(256) void k_pack_partials(long long n_coo, const in
 
 // sort key of a record: the pair key squeezed to 2 * bits_b bits (same order), or -- n_owners > 0, before the exchange --
 // the rank that owns the lower item (items [I r / n_owners, I (r + 1) / n_owners) belong to rank r)
+// the kept pairs of a rank for the stage-B exchange: valid COO entries -> 24-byte records (i | j << 32, sim bits,
+// mutu | n_ij << 32), and back
+__global__ __launch_bounds__(256) void k_pack_pairs(long long n_coo, const int *coo_i, const int *coo_j, const double *coo_sim,
+                                                    const int *coo_mutu, const int *coo_nij, unsigned long long *cursor,
+                                                    long long *rec) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool v = e < n_coo && coo_i[e] >= 0;
+    const unsigned long long m = __ballot(v);
+    if (!m) return;
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)rl32((int)(base >> 32), 0) << 32) | (unsigned)rl32((int)(base & 0xffffffffull), 0);
+    if (!v) return;
+    const long long p = (long long)base + __popcll(m & lanemask_lt());
+    rec[p * 3 + 0] = (long long)(unsigned)coo_i[e] | ((long long)coo_j[e] << 32);
+    rec[p * 3 + 1] = __double_as_longlong(coo_sim[e]);
+    rec[p * 3 + 2] = (long long)(unsigned)coo_mutu[e] | ((long long)coo_nij[e] << 32);
+}
+
+__global__ __launch_bounds__(256) void k_unpack_pairs(long long n, const long long *rec, int *coo_i, int *coo_j, double *coo_sim,
+                                                      int *coo_mutu, int *coo_nij) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const long long a = rec[t * 3], c = rec[t * 3 + 2];
+    coo_i[t] = (int)(a & 0xffffffffll); coo_j[t] = (int)(a >> 32);
+    coo_sim[t] = __longlong_as_double(rec[t * 3 + 1]);
+    coo_mutu[t] = (int)(c & 0xffffffffll); coo_nij[t] = (int)(c >> 32);
+}
+
 __global__ __launch_bounds__(256) void k_partial_keys(long long n, const long long *rec, int bits_b, int n_items, int n_owners,
                                                       unsigned long long *keys, int *vals) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1226,6 +1255,35 @@ int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, c
     XM_HIP(hipMemcpyAsync(h_count, cur, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     XM_HIP(hipStreamSynchronize(st));
     XM_HIP(xm_free_async(cur, st));
+    return XMAP_OK;
+}
+
+int xmap_sim2_pack_pairs(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
+                         const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][3]*/, int64_t *h_count) {
+    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rec && h_count && n_coo >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *cur = nullptr;
+    XM_HIP(xm_malloc_async((void **)&cur, sizeof(unsigned long long), st));
+    XM_HIP(hipMemsetAsync(cur, 0, sizeof(unsigned long long), st));
+    if (n_coo > 0) {
+        k_pack_pairs<<<dim3((unsigned)((n_coo + 255) / 256)), dim3(256), 0, st>>>(n_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, cur,
+                                                                                  (long long *)rec);
+        XM_LAUNCH_CHECK();
+    }
+    XM_HIP(hipMemcpyAsync(h_count, cur, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    XM_HIP(xm_free_async(cur, st));
+    return XMAP_OK;
+}
+
+int xmap_sim2_unpack_pairs(void *stream, int64_t n, const int64_t *rec /*[n][3]*/, int32_t *coo_i, int32_t *coo_j, double *coo_sim,
+                           int32_t *coo_mutu, int32_t *coo_nij) {
+    XM_ARG(rec && coo_i && coo_j && coo_sim && coo_mutu && coo_nij && n >= 0);
+    if (n > 0) {
+        k_unpack_pairs<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(n, (const long long *)rec, coo_i, coo_j,
+                                                                                                 coo_sim, coo_mutu, coo_nij);
+        XM_LAUNCH_CHECK();
+    }
     return XMAP_OK;
 }
 

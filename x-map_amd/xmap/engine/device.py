@@ -188,6 +188,24 @@ class Engine(object):
         check(lib.xmap_item_merge(_stream(self.dev), i32(I), i32(int(parts.shape[0])), vp(parts), vp(info), vp(self.norms)))
         return info
 
+    def pack_pairs(self, coo, n):
+        """valid entries of a half COO -> [n][3] int64 records for the exchange of a sharded step"""
+        rec = self._empty((max(n, 1), 3), torch.int64)
+        cnt = C.c_int64(0)
+        check(lib.xmap_sim2_pack_pairs(_stream(self.dev), i64(int(coo[0].numel())), vp(coo[0]), vp(coo[1]), vp(coo[2]), vp(coo[3]),
+                                       vp(coo[4]), vp(rec), C.byref(cnt)))
+        assert int(cnt.value) == n, (int(cnt.value), n)
+        return rec[:n]
+
+    def unpack_pairs(self, rec):
+        n = int(rec.shape[0])
+        coo = (self._empty(max(n, 1), torch.int32), self._empty(max(n, 1), torch.int32), self._empty(max(n, 1), torch.float64),
+               self._empty(max(n, 1), torch.int32), self._empty(max(n, 1), torch.int32))
+        if n == 0:
+            coo[0].fill_(-1)
+        check(lib.xmap_sim2_unpack_pairs(_stream(self.dev), i64(n), vp(rec.contiguous()), *[vp(x) for x in coo]))
+        return [x[:max(n, 1)] for x in coo]
+
     def partial_records(self, coo, n, n_owners):
         """raw half COO (tri_pairs(raw=True)) -> [n][4] int64 records grouped by the rank that owns the pair's lower item"""
         st = _stream(self.dev)

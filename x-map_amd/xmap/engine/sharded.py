@@ -219,7 +219,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         comm.all_reduce(tot)
         it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
         light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
-    S, E, pt = _stage_b(eng, comm, coo, rowcnt, stats[2], L, k, rank, world)
+    S, E, pt = _stage_b(eng, comm, coo, rowcnt, stats[2], L, k, rank, world, n)
     # ---- stage C: replicated (a few ms)
     with eng.timed("stage_c"):
         n_top, choice, mp = eng.select(E, private)
@@ -291,7 +291,7 @@ def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot
         comm.agree(err, "stage A (merge of the partial similarities)")
         tot = torch.tensor([n_unordered, n, L.half_contrib], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
-    S, E, pt = _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world)
+    S, E, pt = _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n)
     S.u_avg = None                         # user info stays with the rank that holds the users
     with eng.timed("stage_c"):
         n_top, choice, mp = eng.select(E, private)
@@ -310,9 +310,9 @@ def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot
                 S=S, S_part=S_part, E=E, G=G, G_local=Gl, choice=choice, map=mp, info=info)
 
 
-def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world):
-    """stage B of a sharded step: coo / rowcnt = the kept pairs this rank holds (any orientation, every unordered pair on
-    exactly one rank).  Returns (S: the full similarity matrix, E: the extension with the candidate arrays of ALL starts,
+def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
+    """stage B of a sharded step: coo / rowcnt = the n_local kept pairs this rank holds (any orientation, every unordered pair
+    on exactly one rank).  Returns (S: the full similarity matrix, E: the extension with the candidate arrays of ALL starts,
     [paths, candidates] over all ranks)."""
     dev = eng.dev
     # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
@@ -324,14 +324,9 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world):
         # records (i | j << 32, sim bits, mutu | n_ij << 32) -- and every rank mirrors the full COO into the CSR.
         with eng.timed("exchange"):
             comm.all_reduce(rowcnt)
-            idx = torch.nonzero(coo[0] >= 0).flatten()
-            ci, cj, cs, cm, cn = [x[idx] for x in coo]
-            rec = torch.stack([ci.long() | (cj.long() << 32), cs.view(torch.int64), cm.long() | (cn.long() << 32)], dim=1)
+            rec = eng.pack_pairs(coo, n_local)                                  # library kernels, no torch arithmetic
             rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
-            m32 = 0xffffffff
-            coo = [(rec[:, 0] & m32).to(torch.int32), (rec[:, 0] >> 32).to(torch.int32),
-                   rec[:, 1].contiguous().view(torch.float64), (rec[:, 2] & m32).to(torch.int32),
-                   (rec[:, 2] >> 32).to(torch.int32)]
+            coo = eng.unpack_pairs(rec)
         err = None
         try:
             S = eng.tri_scatter(coo, rowcnt, info, None, L)
