@@ -419,6 +419,20 @@ int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const f
 int xmap_rec_select(void *stream, int32_t n_items, const int64_t *row_ptr, const int32_t *col, const double *sim,
                     const double *ls, int32_t keep, int32_t *out_cnt, int32_t *out_col, double *out_sim, double *out_ls);
 
+/* ---- RecommenderPrediction.item_based_prediction (core/recommenderPrediction.py:26-105): one test pair
+ * (user, item) per thread.  test_item = -1: the item has no neighbour list (the reference emits ()), status 1.  Neighbour
+ * lists nb_* in the order of the similarity broadcast; the ratings of an item rt_* sorted by user index, stable, so that a
+ * user's ratings of an item keep their list order (test_user = -1: a user without ratings); times as numbers whose order
+ * and ties are those of the reference's time objects.  wtab[d] = exp(-alpha d) for d = 0 .. n_w - 1, made by the host with
+ * the reference's np.exp.  out_plain / out_decay: bound_rating(prediction without / with temporal decay) (:17-23, :86-97);
+ * status 2: more than 64 evidence entries (or more ranks than wtab holds) -- the caller decides that pair on the host.
+ * The reference tests `uid in rater_id` (substring); the host maps that to user indices (equality when all ids have one
+ * length). */
+int xmap_predict(void *stream, int64_t n_test, const int32_t *test_user, const int32_t *test_item, const int64_t *nb_ptr,
+                 const int32_t *nb_item, const double *nb_sim, const int64_t *rt_ptr, const int32_t *rt_user, const double *rt_rating,
+                 const double *rt_time, const double *item_avg, const double *wtab, int32_t n_w, double *out_plain,
+                 double *out_decay, int32_t *status);
+
 /* ---- stage C: generator_pipeline (utils/assist.py:136-150) ---------------------------------- */
 
 /* Generator.cross_private_mapping / cross_nonprivate_mapping (core/generator.py:27-111) + map_to_dict

@@ -192,3 +192,65 @@ def test_rec_select_vs_oracle_and_reference():
         checked += 1
     assert checked > 0.8 * len(iids)
     xo.rec_free(O)
+
+
+class _B(object):
+    def __init__(self, value):
+        self.value = value
+
+
+def _prediction_case(seed, n_users=80, n_items=60, uid_fmt="U%05d", dup_user=None):
+    import datetime
+    rng = np.random.default_rng(seed)
+    uids = [uid_fmt % u for u in range(n_users)]
+    iids = ["B%04dT:" % i for i in range(n_items)]
+    t0 = datetime.datetime(2012, 6, 1)
+    ratings = {}
+    for i in iids:
+        raters = rng.choice(n_users, size=int(rng.integers(5, 60)), replace=False)
+        lst = [(uids[u], float(rng.integers(1, 6)) + float(rng.integers(0, 3)) / 3.0,
+                t0 + datetime.timedelta(days=int(rng.integers(0, 6)))) for u in raters]      # few distinct days: ties
+        if rng.random() < 0.3:                       # an item held twice by a user (AlterEgo rows can)
+            u = uids[int(raters[0])]
+            lst.append((u, 2.5, t0 + datetime.timedelta(days=int(rng.integers(0, 6)))))
+        if dup_user is not None and i == iids[1]:
+            lst += [(uids[dup_user], float(1 + q % 5), t0 + datetime.timedelta(hours=q)) for q in range(70)]
+        order = rng.permutation(len(lst))
+        ratings[i] = [lst[q] for q in order]
+    info = {i: (float(np.mean([r[1] for r in ratings[i]])), 1.0, len(ratings[i])) for i in iids}
+    sims = {}
+    for i in iids[:n_items - 7]:                     # the last items have no neighbour list
+        nb = rng.choice(n_items, size=int(rng.integers(1, 11)), replace=False)
+        sims[i] = [(iids[n], float(rng.normal()) * (1.0 if rng.random() < 0.9 else 1e-3)) for n in nb if iids[n] != i]
+    test = []
+    for u in list(rng.choice(n_users, size=60, replace=False)) + [n_users + 5]:          # + a user without any rating
+        uid = uid_fmt % u
+        pairs = [(iids[int(q)], float(rng.integers(1, 6))) for q in rng.choice(n_items, size=int(rng.integers(1, 6)), replace=False)]
+        test.append((uid, pairs))
+    return ratings, sims, info, test
+
+
+@pytest.mark.parametrize("seed,alpha", [(1, 0.2), (2, 0.05), (3, 1.5)])
+def test_prediction_on_the_device_equals_the_python_statement(seed, alpha):
+    """RecommenderPrediction.item_based_recommendation: the pairs predicted by xmap_predict are the tuples of the Python
+    statement of reference core/recommenderPrediction.py:26-105 (itself pinned to the reference in test_cpu_downstream.py),
+    exactly: evidence order, sums, time ranks with ties, decay weights, round-half-up and clamping"""
+    from xmap.core.recommenderPrediction import RecommenderPrediction
+    from xmap.engine.localrdd import LocalRDD
+    ratings, sims, info, test = _prediction_case(seed, dup_user=7 if seed == 3 else None)
+    tool = RecommenderPrediction(alpha, "cosine_item")
+    rb, sb, ib = _B(ratings), _B(sims), _B(info)
+    dev = tool._device_recommendation(LocalRDD(test), rb, sb, ib)
+    assert dev is not None
+    got = dev.collect()
+    exp = [tool.item_based_prediction(line, rb, sb, ib) for line in test]
+    assert got == exp
+    assert any(p == () for _, ps in exp for p in ps)
+    if alpha > 1.0:        # a strong decay changes some rounded predictions: the decayed branch is really exercised
+        assert any(p != () and p[2] != p[3] for _, ps in exp for p in ps)
+    assert tool.calculate_mae(dev) == tool.calculate_mae(LocalRDD(exp))
+    # ids of different lengths: `uid in rater_id` is a real substring test, the Python statement decides
+    r2, s2, i2, t2 = _prediction_case(seed, uid_fmt="U%d")
+    assert tool._device_recommendation(LocalRDD(t2), _B(r2), _B(s2), _B(i2)) is None
+    assert tool.item_based_recommendation(LocalRDD(t2), _B(r2), _B(s2), _B(i2)).collect() == \
+        [tool.item_based_prediction(line, _B(r2), _B(s2), _B(i2)) for line in t2]
