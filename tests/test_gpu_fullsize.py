@@ -197,3 +197,46 @@ def test_dense_full_size():
     oi, ov = xo.dense_topk(xo.dense_normalize(Ft[rows].cpu().numpy()), xo.dense_normalize(Fs.cpu().numpy()), k, nthreads=8)
     assert np.array_equal(idx[rows].cpu().numpy(), oi)
     assert np.array_equal(val[rows].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+
+
+def test_c4_shape_full_size():
+    """BASELINE configs[3]: 4 source domains -> one target, 1.25 M users per two-domain problem, k = 100, private mapping,
+    through the multi-domain driver (one rank: domain after domain).  Size-independent properties of every domain's part of
+    the union, and one domain recomputed on its own must give exactly its rows."""
+    import torch
+    from xmap.engine import synth, device, multidomain
+    doms = synth.config_c4()
+    n_dom = len(doms)
+    cache = {}
+
+    def make_engine(d):
+        cache.clear()                       # one domain resident at a time
+        torch.cuda.empty_cache()
+        r = doms[d]
+        cache[d] = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs()))
+        return cache[d], r.n_src_items
+
+    out = multidomain.run_multidomain(make_engine, n_dom, "adjust_cosine", CAP, 100, True)
+    assert len(out["user"]) == int(out["n_rows"].sum()) and (out["n_paths"] > 0).all() and (out["n_rows"] > 0).all()
+    assert np.array_equal(np.unique(out["domain"]), np.arange(n_dom))
+    n_tgt = doms[0].n_items - doms[0].n_src_items
+    assert (out["item"] >= 0).all() and (out["item"] < n_tgt).all()           # the common target numbering
+    assert (out["rating"] >= 1).all() and (out["rating"] <= 5).all()
+    for d in range(n_dom):
+        sel = out["domain"] == d
+        assert int(sel.sum()) == int(out["n_rows"][d])
+        # at least the users' own target ratings are there: one row per target rating of the domain's users
+        flags = doms[d].item_attrs()[3]
+        assert int(sel.sum()) >= int((flags[doms[d].item] & 2).astype(bool).sum())
+    # domain 2 on its own
+    d = 2
+    eng, n_src = make_engine(d)
+    S = eng.item_sim("adjust_cosine", CAP)
+    E = eng.extend(S, 100)
+    assert E.n_paths == E.units.total == int(out["n_paths"][d])
+    _candidate_properties(doms[d], E, doms[d].n_items)
+    _, _, mp = eng.select(E, True)
+    G = eng.alterego(mp)
+    sel = out["domain"] == d
+    assert np.array_equal(G.user.cpu().numpy(), out["user"][sel]) and np.array_equal(G.item.cpu().numpy() - n_src, out["item"][sel])
+    assert np.array_equal(G.rating.cpu().numpy(), out["rating"][sel])
