@@ -471,6 +471,11 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         stage = dict(zip(("stage_a", "stage_b", "stage_c"), [float(x) for x in v.tolist()]))
     t_a, t_b, t_c = stage["stage_a"] / 1e3, stage["stage_b"] / 1e3, stage["stage_c"] / 1e3
+    n_upd = int(getattr(res["E"], "n_updates", 0))      # row updates of this rank's starts
+    if dist:
+        nu = torch.tensor([n_upd], dtype=torch.int64, device=dev)
+        dist.all_reduce(nu)
+        n_upd = int(nu.item())
 
     if rank == 0:
         D, Dk, P, nnz, I = res["n_eval"], res["n_kept"], res["n_contrib"], r.nnz, r.n_items
@@ -490,12 +495,19 @@ def main():
         paths_ms = float(np.mean(tm.get("paths", [0.0])))
         bytes_paths = 12.0 * res["knn_entries"] + 12.0 * res["n_out"]
         tr_a, tr_b = pmc_traffic("k_pair_tri"), pmc_traffic("k_paths4")
+
         ach_b = bytes_paths / (paths_ms * 1e-3) / 1e9 if paths_ms > 0 else 0.0
         rf_b = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
                 "traffic": tr_b, "traffic_ratio": (tr_b / bytes_paths) if (tr_b and bytes_paths) else None,
                 "traffic_fetch_x1": pmc_traffic("k_paths4_fetch_x1"),     # FETCH_SIZE as is: exact for lone 32-byte reads (profiles/README.md)
                 "algorithmic_bytes_per_launch": bytes_paths, "launch_ms": paths_ms,
                 "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                # what the kernel is bound by since round 2 (without the path arithmetic it takes as long, without
+                # the row accesses 60 %): random 32-byte read-modify-writes of row entries, counted by the kernel, against the
+                # rate of uniformly random ones over a region of this size (profiles/rand_rmw_grp.hip; the rows' column order
+                # is what puts the kernel above it)
+                "row_updates": {"count": n_upd, "per_s": n_upd / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                                "reference_per_s": 1.9e10, "reference": "profiles/rand_rmw_grp.hip, 24 GiB region"},
                 # the kernel's other limit: 26 fp64 operations per path-end pair (3 to join record and end, 8 division, 1
                 # product, 14 for the two exact sums; no FMA pairs by construction: -ffp-contract=off) against the vector
                 # fp64 issue rate (78.6 TFLOP/s counts an FMA as two: 39.3e12 instructions x lanes per second); the SQ

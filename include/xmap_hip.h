@@ -374,7 +374,8 @@ int xmap_edge_ranges(void *stream, const xmap_sim *S, int32_t *h_fast_ok);
 int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I] scratch*/, int64_t *rank /*[I+1] scratch*/,
                       int32_t *urank /*[I]*/, int32_t *uitem /*[I]*/, int64_t *h_n_ends);
 int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *U, const xmap_path_rows *R,
-                      const xmap_path_out *O, int fast_div, int64_t *d_counters, int64_t *h_counters);
+                      const xmap_path_out *O, int fast_div, int64_t *d_counters /*[8] device*/,
+                      int64_t *h_counters /*[8]: candidates, paths, -, -, row updates (read-modify-writes of row entries)*/);
 
 /* ---- planning steps of stage B (round 1 did these with torch ops on the device) ----------------------------------
  * xmap_nb_index : nb_list = the non-bridge records (cls == 2) in item order, nb_id[item] = position in it or -1.

@@ -140,8 +140,8 @@ static int run_enumeration(xmap_ctx *c, int64_t xs_cap, int64_t *xs_off, int32_t
     XM_HIP(hipMemsetAsync(c->top_end, 0xff, sizeof(int32_t) * (size_t)I * XMAP_TOPC, c->st));
     XM_HIP(hipMemsetAsync(c->top_val, 0, sizeof(double) * (size_t)I * XMAP_TOPC, c->st));
     int64_t *d_cnt;
-    XM_ALLOCZ(c->p_ext, d_cnt, 4);
-    int64_t h_cnt[4] = {0, 0, 0, 0};
+    XM_ALLOCZ(c->p_ext, d_cnt, 8);
+    int64_t h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rc;
     if (c->T.n_nb > 0) {
         rc = xmap_extend_cols(c->st, &c->T, &c->Un, &Rw, &O, c->fast_div, d_cnt, h_cnt);

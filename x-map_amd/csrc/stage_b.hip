@@ -1232,6 +1232,7 @@ struct QAcc {
     const int *urank;
     int nt;
     unsigned long long paths;
+    unsigned long long updates;            // read-modify-writes of row entries (the kernel's bound: DESIGN.md 4)
     __device__ __forceinline__ void add(bool active, int end, Carry p) {
         bool first = false;
         int u = 0;
@@ -1248,7 +1249,9 @@ struct QAcc {
         const unsigned long long m = __ballot(first);
         if (first) touched[nt + __popcll(m & lanemask_lt())] = u;
         nt += __popcll(m);
-        paths += __popcll(__ballot(active));
+        const int na = __popcll(__ballot(active));
+        paths += na;
+        updates += na;
     }
 };
 
@@ -1440,6 +1443,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 if (first) W.touched[W.nt + __popcll(fm & lanemask_lt())] = eu;
                 W.nt += __popcll(fm);
                 W.paths += (unsigned long long)fill * (unsigned long long)nact;
+                W.updates += (unsigned long long)nact;
                 if (!pm) break;
                 assign();
                 m0 = B.midX[my_rec];
@@ -1461,7 +1465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
     if (slot >= A.n_slots) return;
     const int lane = lane_id();
     QAcc W;
-    W.paths = 0; W.urank = A.urank;
+    W.paths = 0; W.updates = 0; W.urank = A.urank;
     unsigned long long cand_total = 0;
     for (;;) {
         int u_ = 0;
@@ -1520,6 +1524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
     if (lane == 0) {
         atomicAdd(&A.counters[0], cand_total);
         atomicAdd(&A.counters[1], W.paths);
+        atomicAdd(&A.counters[4], W.updates);
     }
 }
 
@@ -2109,7 +2114,7 @@ int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_uni
     XM_ARG(Un->n_heavy == 0 || (Un->heavy_unit0 && R->hacc && R->htouched));
     XM_ARG(O->xs_cap == 0 || (O->xs_off && O->xs_end && O->xs_val));
     hipStream_t st = (hipStream_t)stream;
-    XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
+    XM_HIP(hipMemsetAsync(d_counters, 0, 8 * sizeof(int64_t), st));
     if (Un->n_units > 0) {
         Path2Args B;
         memset(&B, 0, sizeof(B));
@@ -2151,7 +2156,7 @@ int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_uni
         }
     }
     if (h_counters) {
-        XM_HIP(hipMemcpyAsync(h_counters, d_counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        XM_HIP(hipMemcpyAsync(h_counters, d_counters, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         XM_HIP(hipStreamSynchronize(st));
         if (O->xs_cap > 0 && h_counters[0] > O->xs_cap) {
             set_error("candidate buffer too small: need %lld entries, have %lld", (long long)h_counters[0], (long long)O->xs_cap);

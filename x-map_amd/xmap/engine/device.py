@@ -751,8 +751,8 @@ class Engine(object):
         E.n_cand = self._zeros(max(I, 1), torch.int32)
         E.top_end = torch.full((max(I, 1), abi.TOPC), -1, dtype=torch.int32, device=self.dev)
         E.top_val = self._zeros((max(I, 1), abi.TOPC), torch.float64)
-        d_cnt = self._zeros(4, torch.int64)
-        h_cnt = (C.c_int64 * 4)()
+        d_cnt = self._zeros(8, torch.int64)
+        h_cnt = (C.c_int64 * 8)()
         T = self._ext_tables(E, M)
         Un = abi.PathUnits(U.n_units, U.unit_start.data_ptr(), U.unit_c.data_ptr(), U.unit_G.data_ptr(), U.unit_row.data_ptr(),
                            U.unit_nt.data_ptr(), U.n_heavy, U.heavy_unit0.data_ptr())
@@ -779,7 +779,7 @@ class Engine(object):
                 self._drop_scratch("qacc", "qhacc")    # a failed pass may leave partial sums behind
                 raise
             break
-        E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])
+        E.n_out, E.n_paths, E.n_updates = int(h_cnt[0]), int(h_cnt[1]), int(h_cnt[4])
         E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val
         E.start_range = (0, I) if start_range is None else tuple(start_range)
         return E
