@@ -59,6 +59,14 @@ typedef struct xmap_ratings {
 const char *xmap_last_error(void);
 int xmap_version(void);
 
+/* The library keeps its own temporaries (per thread, device and stream; recycled when a call ends, trimmed to 256 MiB when
+ * idle).  xmap_trim hands everything the calling thread's idle arenas still hold back to the driver (synchronises the
+ * device).  xmap_debug_arena / xmap_debug_arena_call are test hooks: the arena's live temporaries and reserved bytes, and a
+ * call that takes two temporaries and leaves through an error path when fail != 0. */
+int xmap_trim(void);
+int xmap_debug_arena(void *stream, int64_t *live, int64_t *reserved);
+int xmap_debug_arena_call(void *stream, int64_t bytes, int fail);
+
 /* exclusive prefix sum of n int64 values; out[n] receives the total; *h_total (may be NULL) too (syncs). */
 int xmap_exclusive_scan_i64(void *stream, const int64_t *in, int64_t *out, int64_t n, int64_t *h_total);
 int xmap_exclusive_scan_i32_to_i64(void *stream, const int32_t *in, int64_t *out, int64_t n, int64_t *h_total);
@@ -446,7 +454,8 @@ int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32
 /* Generator.build_alterEgo (core/generator.py:113-157).  count pass: cnt_t[u] pass-through rows
  * ("T:" in iid), cnt_m[u] AlterEgo rows (distinct mapped targets, first-seen order).  fill pass writes
  * rows [off_t[u]..) and [n_t_total + off_m[u]..): (user, item, rating = mean fp32, time of first row). */
-int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m);
+int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m,
+                        int64_t *d_profiles /* [1] device, zeroed by the caller: += users with at least one output row; or NULL */);
 int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, const int64_t *off_t,
                        const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item,
                        double *out_rating, int64_t *out_time);

@@ -521,7 +521,7 @@ int xmap_ctx_generate(xmap_ctx *c, int private_flag, const int32_t *picks, int32
     int32_t *cnt_t, *cnt_m;
     int64_t *off_t, *off_m, nt = 0, nm = 0;
     XM_ALLOCZ(c->p_gen, cnt_t, U); XM_ALLOCZ(c->p_gen, cnt_m, U); XM_ALLOCZ(c->p_gen, off_t, U + 1); XM_ALLOCZ(c->p_gen, off_m, U + 1);
-    XM_TRY(xmap_alterego_count(c->st, &c->R, d_map, cnt_t, cnt_m));
+    XM_TRY(xmap_alterego_count(c->st, &c->R, d_map, cnt_t, cnt_m, nullptr));
     XM_TRY(xmap_exclusive_scan_i32_to_i64(c->st, cnt_t, off_t, U, &nt));
     XM_TRY(xmap_exclusive_scan_i32_to_i64(c->st, cnt_m, off_m, U, &nm));
     const int64_t n = nt + nm;

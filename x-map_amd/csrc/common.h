@@ -33,6 +33,17 @@ void set_error(const char *fmt, ...);
 // Temporaries of one entry-point call: the library's own per-stream arenas (util.hip), not hipMallocAsync.
 hipError_t xm_malloc_async(void **p, size_t bytes, hipStream_t st);
 hipError_t xm_free_async(void *p, hipStream_t st);
+// Every entry point that takes temporaries opens a scope first: whatever path the call leaves by (XM_HIP / XM_ARG /
+// `if (rc) return rc`), the arena's count of live temporaries is back to what it was at entry, so an early return cannot
+// leave the arena growing for the rest of the process.
+struct XmScope {
+    int dev; hipStream_t st; size_t live0; bool ok;
+    explicit XmScope(hipStream_t st);
+    ~XmScope();
+    XmScope(const XmScope &) = delete;
+    XmScope &operator=(const XmScope &) = delete;
+};
+#define XM_SCOPE(stream) xmap::XmScope xm_scope_((hipStream_t)(stream))
 // plan.hip: stable LSD radix sort of (key, value) pairs by the low `bits` bits of the key; tmp buffers of n entries
 int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals, unsigned long long *keys_tmp, int *vals_tmp, long long n,
                      int bits);

@@ -597,6 +597,7 @@ int xmap_item_merge(void *stream, int32_t n_items, int32_t n_parts, const double
 
 int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *W, int64_t *unit_ptr,
                   int64_t *h_n_units, int64_t *h_contrib) {
+    XM_SCOPE(stream);
     XM_ARG(R && Q && W && unit_ptr && slot_target > 0 && slot_target <= SLOTS);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d_contrib = nullptr;
@@ -665,6 +666,7 @@ int xmap_sim_fill(void *stream, const xmap_ratings *R, int method, int cap, cons
                   const int32_t *ua_item, const int32_t *ia_user, const int32_t *Q, const int32_t *unit_item,
                   const int32_t *unit_q, int64_t unit_lo, int64_t unit_hi, const int64_t *unit_off, int32_t *col,
                   double *sim, int32_t *mutu, int32_t *nij) {
+    XM_SCOPE(stream);
     XM_ARG(R && u_avg && info && ua_item && ia_user && Q && unit_item && unit_q && unit_off);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
     XM_ARG(cap > 0 && R->nnz < 0x7fffffffLL);

@@ -1242,6 +1242,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
 int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_hi,
                             const double *coo_lo, const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][4]*/,
                             int64_t *h_count) {
+    XM_SCOPE(stream);
     XM_ARG(coo_i && coo_j && coo_hi && coo_lo && coo_mutu && coo_nij && rec && h_count && n_coo >= 0);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *cur = nullptr;
@@ -1260,6 +1261,7 @@ int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, c
 
 int xmap_sim2_pack_pairs(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
                          const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][3]*/, int64_t *h_count) {
+    XM_SCOPE(stream);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rec && h_count && n_coo >= 0);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *cur = nullptr;
@@ -1288,6 +1290,7 @@ int xmap_sim2_unpack_pairs(void *stream, int64_t n, const int64_t *rec /*[n][3]*
 }
 
 int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t *rec_sorted, int32_t n_items, int32_t n_owners) {
+    XM_SCOPE(stream);
     XM_ARG(rec && rec_sorted && n >= 0 && n < 0x7fffffffLL && n_items > 0 && n_owners >= 0 && n_owners <= 65536);
     if (n == 0) return XMAP_OK;
     int bits_b = 1;
@@ -1314,6 +1317,7 @@ int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t
 int xmap_sim2_merge_partials(void *stream, int method, int cap, int32_t n_items, int64_t n, const int64_t *rec_sorted,
                              const double *norms, int32_t *coo_i, int32_t *coo_j, double *coo_sim, int32_t *coo_mutu,
                              int32_t *coo_nij, int32_t *rowcnt, int64_t *h_counts /*[2]: kept, evaluated (unordered pairs)*/) {
+    XM_SCOPE(stream);
     XM_ARG(rec_sorted && norms && coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && h_counts && n >= 0 && cap > 0);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
     hipStream_t st = (hipStream_t)stream;

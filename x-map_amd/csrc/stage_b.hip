@@ -2055,6 +2055,7 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
 }
 
 int xmap_edge_ranges(void *stream, const xmap_sim *S, int32_t *h_fast_ok) {
+    XM_SCOPE(stream);
     XM_ARG(S && h_fast_ok);
     *h_fast_ok = 1;
     if (S->n_items == 0) return XMAP_OK;
@@ -2104,6 +2105,7 @@ int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I
 
 int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *Un, const xmap_path_rows *R,
                       const xmap_path_out *O, int fast_div, int64_t *d_counters, int64_t *h_counters) {
+    XM_SCOPE(stream);
     XM_ARG(T && Un && R && O && d_counters);
     XM_ARG(T->cls && T->kcnt && T->kcol && T->kval && T->flags && T->att_ptr && T->src_ptr && T->rnn_ptr);
     XM_ARG(T->n_ends >= 0 && (T->n_items == 0 || (T->urank && T->uitem)));

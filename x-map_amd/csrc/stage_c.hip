@@ -32,10 +32,13 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
                                                   const long long *time, const uint8_t *flags, const int *map,
                                                   int *cnt_t, int *cnt_m, const long long *off_t,
                                                   const long long *off_m, long long n_t_total, int *out_user,
-                                                  int *out_item, double *out_rating, long long *out_time) {
+                                                  int *out_item, double *out_rating, long long *out_time,
+                                                  unsigned long long *n_prof) {
     long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= U) return;
-    long long a = ptr[u], b = ptr[u + 1];
+    const bool in = u < U;
+    if (FILL && !in) return;      // (the count pass keeps the whole wave: it ends in a ballot)
+    long long a = 0, b = 0;
+    if (in) { a = ptr[u]; b = ptr[u + 1]; }
     long long ot = FILL ? off_t[u] : 0, om = FILL ? n_t_total + off_m[u] : 0;
     int ct = 0, cm = 0;
     for (long long e = a; e < b; e++) {
@@ -64,7 +67,12 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
         }
         cm++;
     }
-    if (!FILL) { cnt_t[u] = ct; cnt_m[u] = cm; }
+    if (!FILL) {
+        if (in) { cnt_t[u] = ct; cnt_m[u] = cm; }
+        // users with at least one row: the profiles of the output (one atomic per wave)
+        const unsigned long long any = __ballot(ct + cm > 0);
+        if (n_prof && any && lane_id() == 0) atomicAdd(n_prof, (unsigned long long)__popcll(any));
+    }
 }
 
 }  // namespace xmap
@@ -85,12 +93,14 @@ int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32
     return XMAP_OK;
 }
 
-int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m) {
+int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m,
+                        int64_t *d_profiles /* zeroed by the caller, or NULL */) {
     XM_ARG(R && map_src2tgt && cnt_t && cnt_m);
     if (R->n_users == 0) return XMAP_OK;
     k_alterego<false><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
-        R->flags, map_src2tgt, cnt_t, cnt_m, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+        R->flags, map_src2tgt, cnt_t, cnt_m, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+        (unsigned long long *)d_profiles);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -103,7 +113,7 @@ int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_s
     k_alterego<true><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
         R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
         R->flags, map_src2tgt, nullptr, nullptr, (const long long *)off_t, (const long long *)off_m, n_t_total, out_user,
-        out_item, out_rating, (long long *)out_time);
+        out_item, out_rating, (long long *)out_time, nullptr);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

@@ -134,7 +134,15 @@ __global__ __launch_bounds__(128) void k_predict(long long n_test, const int *tu
             a += e0[ord[k]] * w; b += e1[ord[k]] * w;
         }
         decayed = base + a / b;
+        // Python raises where this arithmetic would go on: ZeroDivisionError for a zero weight sum (every contributing
+        // neighbour with a zero similarity: RecommenderSim filters nothing), int() of an infinity or a NaN in
+        // bound_rating -- those pairs are the host's (status 2: the Python statement reproduces the reference's raise)
+        if (s1 == 0.0 || b == 0.0 || !isfinite(plain) || !isfinite(decayed)) {
+            status[t] = 2; out_plain[t] = 0.0; out_decay[t] = 0.0;
+            return;
+        }
     }
+    if (!isfinite(base)) { status[t] = 2; out_plain[t] = 0.0; out_decay[t] = 0.0; return; }
     status[t] = 0;
     out_plain[t] = bound_rating(plain);
     out_decay[t] = bound_rating(decayed);

@@ -26,14 +26,55 @@ namespace {
 struct Chunk { char *base; size_t size, used; };
 struct Arena { int dev; hipStream_t st; std::vector<Chunk> chunks; size_t live; };
 thread_local std::vector<Arena> g_arenas;
+// What an idle arena may keep: chunks beyond this are handed back to the driver when the arena resets (high-water
+// temporaries -- the 24 B/record buffers of the partial-record sort, the column end table -- would otherwise stay pinned
+// outside the caller's allocator for the life of the process).
+constexpr size_t ARENA_KEEP = (size_t)256 << 20;
+Arena *arena_find(int dev, hipStream_t st) {
+    for (Arena &a : g_arenas) if (a.dev == dev && a.st == st) return &a;
+    return nullptr;
+}
 Arena *arena_of(hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (Arena &a : g_arenas) if (a.dev == dev && a.st == st) return &a;
+    if (Arena *a = arena_find(dev, st)) return a;
     g_arenas.push_back(Arena{dev, st, {}, 0});
     return &g_arenas.back();
 }
+// all temporaries released: recycle the chunks; beyond ARENA_KEEP they go back to the driver (after the stream has
+// drained: a kernel of this call may still be reading them)
+void arena_reset(Arena *a) {
+    size_t total = 0;
+    for (Chunk &c : a->chunks) { c.used = 0; total += c.size; }
+    if (total <= ARENA_KEEP) return;
+    if (hipStreamSynchronize(a->st) != hipSuccess) return;
+    // keep the smallest chunks up to the cap, free the rest (largest first)
+    std::vector<Chunk> keep;
+    size_t kept = 0;
+    std::vector<Chunk> all = a->chunks;
+    for (size_t i = 0; i < all.size(); i++)
+        for (size_t j = i + 1; j < all.size(); j++)
+            if (all[j].size < all[i].size) { Chunk t = all[i]; all[i] = all[j]; all[j] = t; }
+    for (Chunk &c : all) {
+        if (kept + c.size <= ARENA_KEEP) { keep.push_back(c); kept += c.size; }
+        else (void)hipFree(c.base);
+    }
+    a->chunks.swap(keep);
+}
 }  // namespace
+
+XmScope::XmScope(hipStream_t s) : dev(0), st(s), live0(0), ok(false) {
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    ok = true;
+    if (Arena *a = arena_find(dev, st)) live0 = a->live;
+}
+XmScope::~XmScope() {
+    if (!ok) return;
+    Arena *a = arena_find(dev, st);       // (looked up again: a nested call on another stream may have grown the vector)
+    if (!a || a->live <= live0) return;
+    a->live = live0;                      // a path that returned between a malloc and its free
+    if (a->live == 0) arena_reset(a);
+}
 
 hipError_t xm_malloc_async(void **p, size_t bytes, hipStream_t st) {
     Arena *a = arena_of(st);
@@ -56,7 +97,7 @@ hipError_t xm_free_async(void *p, hipStream_t st) {
     (void)p;
     Arena *a = arena_of(st);
     if (!a || a->live == 0) return hipErrorInvalidValue;
-    if (--a->live == 0) for (Chunk &c : a->chunks) c.used = 0;
+    if (--a->live == 0) arena_reset(a);
     return hipSuccess;
 }
 
@@ -138,6 +179,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_tile_scan(const TIn *in, long 
 template <typename TIn>
 static int exclusive_scan(hipStream_t st, const TIn *in, int64_t *out, int64_t n, int64_t *h_total) {
     XM_ARG(n >= 0);
+    XM_SCOPE(st);
     // out[n] doubles as the grand total; tile offsets live in a small temporary
     int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     long long *tile = nullptr;
@@ -164,6 +206,46 @@ static int exclusive_scan(hipStream_t st, const TIn *in, int64_t *out, int64_t n
 extern "C" {
 const char *xmap_last_error(void) { return xmap::g_err; }
 int xmap_version(void) { return 100; }
+
+/* The library's temporaries: give every idle arena's memory of the calling thread back to the driver (arenas with live
+ * temporaries are left alone).  Synchronises the device. */
+int xmap_trim(void) {
+    XM_HIP(hipDeviceSynchronize());
+    int dev = 0;
+    XM_HIP(hipGetDevice(&dev));
+    for (xmap::Arena &a : xmap::g_arenas) {
+        if (a.dev != dev || a.live != 0) continue;
+        for (xmap::Chunk &c : a.chunks) (void)hipFree(c.base);
+        a.chunks.clear();
+    }
+    return XMAP_OK;
+}
+
+/* test hooks: state of the calling thread's arena of `stream` (live temporaries, bytes reserved), and a call that takes two
+ * temporaries and then leaves through an error path (fail != 0) the way an entry point would */
+int xmap_debug_arena(void *stream, int64_t *live, int64_t *reserved) {
+    XM_ARG(live && reserved);
+    int dev = 0;
+    XM_HIP(hipGetDevice(&dev));
+    *live = 0; *reserved = 0;
+    if (xmap::Arena *a = xmap::arena_find(dev, (hipStream_t)stream)) {
+        *live = (int64_t)a->live;
+        for (xmap::Chunk &c : a->chunks) *reserved += (int64_t)c.size;
+    }
+    return XMAP_OK;
+}
+int xmap_debug_arena_call(void *stream, int64_t bytes, int fail) {
+    using namespace xmap;
+    XM_SCOPE(stream);
+    hipStream_t st = (hipStream_t)stream;
+    void *a = nullptr, *b = nullptr;
+    XM_HIP(xm_malloc_async(&a, (size_t)bytes, st));
+    XM_HIP(xm_malloc_async(&b, 1024, st));
+    XM_ARG(!fail);                      // the early return under test
+    XM_HIP(xm_free_async(b, st));
+    XM_HIP(xm_free_async(a, st));
+    return XMAP_OK;
+}
 
 int xmap_exclusive_scan_i64(void *stream, const int64_t *in, int64_t *out, int64_t n, int64_t *h_total) {
     return xmap::exclusive_scan<long long>((hipStream_t)stream, (const long long *)in, out, n, h_total);

@@ -787,7 +787,15 @@ class Engine(object):
     def ext_tables(self, S, top_k, comm=None):
         """B1-B5b: bridge flags, classified top-k lists and the three reverse adjacencies (attach / src / rnn).
         comm (xmap.engine.sharded.Comm of several ranks): every rank classifies a share of the rows -- contiguous ranges of
-        equal entry counts -- and the tables are all-gathered (the reference broadcasts them, utils/assist.py:93-95)."""
+        equal entry counts -- and the tables are all-gathered (the reference broadcasts them, utils/assist.py:93-95).
+        Three phases (a sharded caller puts its collective error check between them: ext_knn and ext_reverse may raise,
+        ext_gather holds every collective and nothing else)."""
+        E = self.ext_knn(S, top_k, comm)
+        self.ext_gather(E, comm)
+        return self.ext_reverse(S, E)
+
+    def ext_knn(self, S, top_k, comm=None):
+        """local part: the classified top-k lists of this rank's share of the rows (all rows without comm)"""
         I = self.R.n_items
         rows = None
         if comm is not None and comm.world > 1 and I > 0:
@@ -797,17 +805,31 @@ class Engine(object):
             cuts = np.maximum.accumulate(np.asarray(cuts))
             rows = (int(cuts[comm.rank]), int(cuts[comm.rank + 1]))
         E = self.knn(S, top_k, rows=rows)
+        E.rows = rows
         ok = C.c_int32(1)
         check(lib.xmap_edge_ranges(_stream(self.dev), C.byref(S.c), C.byref(ok)))
         E.fast_div = int(ok.value)       # the bare division sequence of k_paths4 is the division for these edge values
-        if rows is not None:
-            lo, hi = rows
-            with self.timed("knn_gather"):
-                k = E.k
-                E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
-                E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
-                E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)
-                E.kval[:I] = comm.all_gather_var(E.kval[lo:hi].reshape(-1)).view(I, 2, k, 3)
+        return E
+
+    def ext_gather(self, E, comm):
+        """collectives only: the ranks' shares of the knn tables, all-gathered"""
+        rows = getattr(E, "rows", None)
+        if rows is None:
+            return E
+        I = self.R.n_items
+        lo, hi = rows
+        with self.timed("knn_gather"):
+            k = E.k
+            E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
+            E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
+            E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)
+            E.kval[:I] = comm.all_gather_var(E.kval[lo:hi].reshape(-1)).view(I, 2, k, 3)
+        E.rows = None
+        return E
+
+    def ext_reverse(self, S, E):
+        """local part: list thresholds and the three reverse adjacencies from the complete knn tables"""
+        I = self.R.n_items
         st = _stream(self.dev)
         with self.timed("reverse"):
             E.thr = self._empty(max(I, 1) * 4, torch.float64)      # last entry of every list, 16 B each
@@ -1015,43 +1037,65 @@ class Engine(object):
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
-        n_top = self._zeros(max(I, 1), torch.int32)
-        choice = self._zeros(max(I, 1), torch.int32)
-        mp = self._zeros(max(I, 1), torch.int32)
+        n_top = self._out(max(I, 1), torch.int32, I > 0)      # written for every start / filled by the library
+        choice = self._out(max(I, 1), torch.int32, I > 0)
+        mp = self._out(max(I, 1), torch.int32, I > 0)
         pk = None
         if picks is not None:
             pk = torch.from_numpy(np.ascontiguousarray(picks, np.int32)).to(self.dev)
-        check(lib.xmap_select_map(st, i32(I), 1 if private else 0, vp(E.n_cand), vp(E.top_end), vp(pk),
-                                  vp(n_top), vp(choice), vp(mp)))
+        with self.timed("c_select"):
+            check(lib.xmap_select_map(st, i32(I), 1 if private else 0, vp(E.n_cand), vp(E.top_end), vp(pk),
+                                      vp(n_top), vp(choice), vp(mp)))
         return n_top, choice, mp
 
     def alterego(self, mp):
         R = self.R
         st = _stream(self.dev)
         U = R.n_users
-        cnt_t = self._zeros(max(U, 1), torch.int32)
-        cnt_m = self._zeros(max(U, 1), torch.int32)
-        check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m)))
-        off_t = self._zeros(U + 1, torch.int64)
-        off_m = self._zeros(U + 1, torch.int64)
-        nt, nm = C.c_int64(0), C.c_int64(0)
-        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_t), vp(off_t), i64(U), C.byref(nt)))
-        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_m), vp(off_m), i64(U), C.byref(nm)))
-        n = int(nt.value) + int(nm.value)
+        cnt_t = self._empty(max(U, 1), torch.int32)
+        cnt_m = self._empty(max(U, 1), torch.int32)
+        if U == 0:
+            cnt_t.zero_(); cnt_m.zero_()
+        d_prof = self._zeros(1, torch.int64)
+        with self.timed("c_count"):
+            check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m), vp(d_prof)))
+            off_t = self._empty(U + 1, torch.int64)
+            off_m = self._empty(U + 1, torch.int64)
+            check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_t), vp(off_t), i64(U), None))
+            check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_m), vp(off_m), i64(U), None))
+            # the three totals in ONE synchronisation (the scans leave theirs in out[U])
+            h = self._pinned3()
+            h[0:1].copy_(off_t[U:U + 1], non_blocking=True)
+            h[1:2].copy_(off_m[U:U + 1], non_blocking=True)
+            h[2:3].copy_(d_prof, non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()
+            nt, nm, n_prof = int(h[0]), int(h[1]), int(h[2])
+        n = nt + nm
         G = GenResult()
         G.user = self._empty(max(n, 1), torch.int32)
         G.item = self._empty(max(n, 1), torch.int32)
         G.rating = self._empty(max(n, 1), torch.float64)      # pass-through ratings and np.mean of the merged ones (fp64)
         G.time = self._empty(max(n, 1), torch.int64)
-        check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt.value),
-                                     vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))
-        G.n_rows, G.n_target_rows = n, int(nt.value)
+        with self.timed("c_fill"):
+            check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt),
+                                         vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))
+        G.n_rows, G.n_target_rows = n, nt
         G.cnt_t, G.cnt_m = cnt_t, cnt_m
+        G.n_profiles = n_prof
         G.user, G.item, G.rating, G.time = G.user[:n], G.item[:n], G.rating[:n], G.time[:n]
         return G
 
+    def _pinned3(self):
+        h = getattr(self, "_h3", None)
+        if h is None:
+            h = self._h3 = torch.empty(3, dtype=torch.int64, pin_memory=True)
+        return h
+
     def n_profiles(self, G):
         """distinct users present in the AlterEgo output (profiles/s numerator)."""
+        n = getattr(G, "n_profiles", None)      # counted by the count pass of alterego()
+        if n is not None:
+            return int(n)
         U = self.R.n_users
         return int(((G.cnt_t[:U] + G.cnt_m[:U]) > 0).sum().item())
 

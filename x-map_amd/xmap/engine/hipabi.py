@@ -64,7 +64,7 @@ class PathOut(C.Structure):
 
 
 EXPORTS = [
-    "xmap_last_error", "xmap_version", "xmap_exclusive_scan_i64", "xmap_exclusive_scan_i32_to_i64",
+    "xmap_last_error", "xmap_version", "xmap_trim", "xmap_debug_arena", "xmap_debug_arena_call", "xmap_exclusive_scan_i64", "xmap_exclusive_scan_i32_to_i64",
     "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", "xmap_sim_plan", "xmap_sim_units", "xmap_sim_count",
     "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
     "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_item_partials", "xmap_item_merge", "xmap_sim2_pack_partials",

@@ -327,10 +327,20 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
             rec = eng.pack_pairs(coo, n_local)                                  # library kernels, no torch arithmetic
             rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
             coo = eng.unpack_pairs(rec)
-        err = None
+        # No collective sits between a possible raise and the agree() that follows it: the local phases run in try blocks,
+        # the all-gathers of the knn tables (ext_gather) run outside any of them.
+        err, S, E = None, None, None
         try:
             S = eng.tri_scatter(coo, rowcnt, info, None, L)
-            E = eng.extend(S, k, full=False, start_split=(rank, world), comm=comm)
+            E = eng.ext_knn(S, k, comm)
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage B (mirror + knn tables)")
+        eng.ext_gather(E, comm)
+        err = None
+        try:
+            eng.ext_reverse(S, E)
+            E = eng.extend_tables(E, False, None, start_split=(rank, world))
         except Exception as e:
             err = e
         comm.agree(err, "stage B (extension)")
