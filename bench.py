@@ -243,8 +243,8 @@ def bench_recsim(args, rank, world, local, dist, sink=None):
     np.cumsum(np.bincount(uinv, minlength=len(uu)), out=ptr[1:])
     all_ids = r.item_ids()
     iids = [all_ids[x] for x in ii]
-    item, rating = iinv.astype(np.int32), ra[o].astype(np.float32)
-    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), ids.item_attrs(iids), dev)
+    item, rating = iinv.astype(np.int32), ra[o].astype(np.float64)      # np.float64 means, as RecommenderSim receives them
+    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), ids.item_attrs(iids), dev, rating64=True)
     eng = device.Engine(R)
     log("recsim: AlterEgo rows %d, users %d, items %d" % (len(item), len(uu), len(iids)))
     for _ in range(args.warmup):

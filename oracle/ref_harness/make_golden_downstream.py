@@ -113,8 +113,8 @@ def main():
     # ---- RecommenderSim on non-integer ratings (AlterEgo ratings are means): pins the float behaviour of the
     # similarity and of the leave-one-out local sensitivity (items with a single rater included)
     frac = (0.0, 1.0 / 3.0, 0.5, 0.25, 2.0 / 3.0)
-    rows_f = [(u, i, float(np.float32(float(r) - frac[k % 5])) if float(r) > 1 else float(r), t)   # fp32 values: the
-              for k, (u, i, r, t) in enumerate(rows)]                                                  # engine's rating type
+    rows_f = [(u, i, (float(r) - frac[k % 5]) if float(r) > 1 else float(r), t)     # fp64 values that no float32 holds
+              for k, (u, i, r, t) in enumerate(rows)]                                   # (4 - 1/3, 5 - 2/3, ...), like np.mean's
     sim_tool = RecommenderSim("cosine_item", 50)
     res = assist.recommender_calculate_sim_pipeline(sc, sim_tool, MiniRDD(rows_f, sc))
     out["cosine_item_float"] = dict(

@@ -160,7 +160,7 @@ XoSim *xo_item_sim(int method, int cap, int64_t U, int32_t I, const int64_t *ptr
     for (int64_t e = 0; e < nnz; e++) iptr[item[e] + 1]++;
     for (int32_t i = 0; i < I; i++) iptr[i + 1] += iptr[i];
     int32_t *iuser = (int32_t *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
-    float *irat = (float *)malloc((size_t)(nnz ? nnz : 1) * sizeof(float));
+    double *irat = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));   /* np.float64: AlterEgo ratings are means (generator.py:134) */
     {
         int64_t *cur = (int64_t *)malloc((size_t)I * sizeof(int64_t));
         memcpy(cur, iptr, (size_t)I * sizeof(int64_t));
@@ -719,14 +719,14 @@ static double rec_weight(double cs, int32_t n, int cap) {
     return 1.0 * cs * (double)mn / (double)cap;
 }
 
-XoRec *xo_rec_sim(int cap, int64_t U, int32_t I, const int64_t *ptr, const int32_t *item, const float *rating) {
+XoRec *xo_rec_sim(int cap, int64_t U, int32_t I, const int64_t *ptr, const int32_t *item, const double *rating) {
     int64_t nnz = ptr[U];
     XoRec *S = (XoRec *)calloc(1, sizeof(XoRec));
     S->I = I;
     S->norm = (double *)calloc((size_t)(I ? I : 1), sizeof(double));
     {   /* exact sum of the squares per item */
         double *hi = (double *)calloc((size_t)(I ? I : 1), sizeof(double)), *lo = (double *)calloc((size_t)(I ? I : 1), sizeof(double));
-        for (int64_t e = 0; e < nnz; e++) { double r = (double)rating[e]; dd_add(&hi[item[e]], &lo[item[e]], r * r); }
+        for (int64_t e = 0; e < nnz; e++) { double r = rating[e]; dd_add(&hi[item[e]], &lo[item[e]], r * r); }
         for (int32_t i = 0; i < I; i++) S->norm[i] = sqrt(hi[i]);
         free(hi); free(lo);
     }
@@ -735,7 +735,7 @@ XoRec *xo_rec_sim(int cap, int64_t U, int32_t I, const int64_t *ptr, const int32
     for (int32_t i = 0; i < I; i++) iptr[i + 1] += iptr[i];
     int32_t *iuser = (int32_t *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
     int64_t *ient = (int64_t *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int64_t));   /* the rating's own profile entry */
-    float *irat = (float *)malloc((size_t)(nnz ? nnz : 1) * sizeof(float));
+    double *irat = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));   /* np.float64: AlterEgo ratings are means (generator.py:134) */
     {
         int64_t *cur = (int64_t *)malloc((size_t)(I ? I : 1) * sizeof(int64_t));
         memcpy(cur, iptr, (size_t)I * sizeof(int64_t));
@@ -770,7 +770,7 @@ XoRec *xo_rec_sim(int cap, int64_t U, int32_t I, const int64_t *ptr, const int32
                     b0 = (double *)realloc(b0, bufcap * sizeof(double)); b1 = (double *)realloc(b1, bufcap * sizeof(double));
                     g0 = (double *)realloc(g0, bufcap * sizeof(double)); g1 = (double *)realloc(g1, bufcap * sizeof(double));
                 }
-                bj[w] = j; b0[w] = (double)irat[p]; b1[w] = (double)rating[e]; w++;
+                bj[w] = j; b0[w] = irat[p]; b1[w] = rating[e]; w++;
                 if (cnt[j]++ == 0) touched[nt++] = j;
             }
         }

@@ -247,9 +247,9 @@ def rec_sim(user_ptr, item, rating, n_items, cap):
     L.xo_rec_sim.restype = C.POINTER(_XoRec)
     user_ptr = np.ascontiguousarray(user_ptr, np.int64)
     item = np.ascontiguousarray(item, np.int32)
-    rating = np.ascontiguousarray(rating, np.float32)
+    rating = np.ascontiguousarray(rating, np.float64)      # np.float64 like the reference's AlterEgo ratings (generator.py:134)
     p = L.xo_rec_sim(C.c_int(int(cap)), C.c_int64(len(user_ptr) - 1), C.c_int32(int(n_items)), _p(user_ptr, C.c_int64),
-                     _p(item, C.c_int32), _p(rating, C.c_float))
+                     _p(item, C.c_int32), _p(rating, C.c_double))
     c = p.contents
     R = Rec()
     R.row_ptr = _arr(c.row_ptr, n_items + 1, np.int64)

@@ -79,4 +79,4 @@ def rows_to_csr(rows):
         ptr[k + 1] = ptr[k] + len(prof)
         item += [p[0] for p in prof]
         rating += [p[1] for p in prof]
-    return uids, iids, ptr, np.array(item, np.int32), np.array(rating, np.float32)
+    return uids, iids, ptr, np.array(item, np.int32), np.array(rating, np.float64)     # fp64: AlterEgo ratings are np.float64 means

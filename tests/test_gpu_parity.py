@@ -274,6 +274,57 @@ def test_long_profiles_and_popular_items(dev, method):
     xo.sim_free(So)
 
 
+@pytest.mark.parametrize("method", METHODS)
+def test_keys_larger_than_a_tile(dev, method):
+    """The two transpositions of stage A (rater records by item, kept pairs by heavier item: csrc/tilesort.h) with keys
+    far larger than a tile: two items rated by every user (8000 raters; each is the partner of every lighter row, so its
+    mirrored half has thousands of entries too), next to thousands of items with a handful.  Both sequences of the stage
+    (round 3: one transposition, tile-sorted mirror; round 2: CSC + cursor-atomic mirror) against the oracle, bit for bit."""
+    from oracle import xmap_oracle as xo
+    from xmap.engine import synth
+    r = synth.make_two_domain(31, 8000, 4000, 4000, overlap=0.4)
+    # every user also rates source item 7 and target item n_src + 11 (appended to the profile if absent)
+    hubs = (7, r.n_src_items + 11)
+    rng = np.random.default_rng(5)
+    ptr, item, rating, time = [0], [], [], []
+    for u in range(r.n_users):
+        a, b = int(r.user_ptr[u]), int(r.user_ptr[u + 1])
+        it, ra, ti = list(r.item[a:b]), list(r.rating[a:b]), list(r.time[a:b])
+        for h in hubs:
+            if h not in it:
+                it.append(h); ra.append(float(rng.integers(1, 6))); ti.append(int(rng.integers(synth.T0, synth.T1)))
+        item += it; rating += ra; time += ti
+        ptr.append(len(item))
+    ptr, item = np.asarray(ptr, np.int64), np.asarray(item, np.int32)
+    rating, time = np.asarray(rating, np.float32), np.asarray(time, np.int64)
+    assert np.bincount(item, minlength=r.n_items)[list(hubs)].tolist() == [r.n_users, r.n_users]
+    attrs = r.item_attrs()
+    eng = _engine(dev, ptr, item, rating, time, r.n_items, attrs)
+    T = xo.Train(ptr, item, rating, time, r.n_items, *attrs)
+    So = xo.item_sim(T, method, CAP, nthreads=8)
+    orow, ocol = csr_to_pairs(So.row_ptr, So.col)
+    assert np.diff(So.row_ptr)[list(hubs)].min() > 3000
+    old = os.environ.get("XMAP_A_V2")
+    try:
+        for v2 in ("0", "1"):
+            os.environ["XMAP_A_V2"] = v2
+            for ch_min in (1024, 64):
+                S = eng.item_sim_tri(method, CAP, ch_min=ch_min)
+                assert S.n_eval == So.n_eval and S.n_contrib == So.n_contrib
+                rows, cols, sim, mutu, nij = _sorted_sim(S)
+                assert np.array_equal(rows, orow) and np.array_equal(cols, ocol)
+                assert np.array_equal(mutu, So.mutu) and np.array_equal(nij, So.nij)
+                assert np.array_equal(S.info.cpu().numpy(), So.info)
+                assert np.array_equal(S.u_avg.cpu().numpy()[:r.n_users], xo.user_info(T)[0])
+                assert np.array_equal(sim, So.sim)
+    finally:
+        if old is None:
+            os.environ.pop("XMAP_A_V2", None)
+        else:
+            os.environ["XMAP_A_V2"] = old
+    xo.sim_free(So)
+
+
 def test_determinism_and_partitions(dev):
     """two runs give identical bytes; the result does not depend on the table partitioning."""
     from xmap.engine import synth

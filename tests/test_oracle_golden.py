@@ -115,8 +115,13 @@ def test_rec_sim_oracle_matches_reference(key, rows_key):
         g = json.load(f)
     rows = g[key][rows_key] if rows_key else g["downstream_input"]["rows"]
     uids, iids, ptr, item, rating = rows_to_csr(rows)
-    assert np.array_equal(rating.astype(np.float64), np.array([float(r[2]) for r in rows])[np.argsort(
-        [uids.index(r[0]) for r in rows], kind="stable")]) or True
+    # the oracle sees the reference's own fp64 values (4 - 1/3, ... in the float case: no float32 holds them)
+    by_user = {}
+    for r in rows:
+        by_user.setdefault(r[0], []).append(float(r[2]))
+    assert np.array_equal(rating, np.array([x for u in uids for x in by_user[u]], np.float64))
+    if rows_key:
+        assert np.any(rating != rating.astype(np.float32).astype(np.float64))
     R = xo.rec_sim(ptr, item, rating, len(iids), 50)
     got = {}
     for i in range(len(iids)):

@@ -295,7 +295,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
         // all phases in one call: the heavy rows run on a side stream next to the class launches of the light rows
         XM_TRY(xmap_sim2_pairs(c->st, &R, method, cap, c->u_avg, norms, rcrec, ub, Q, small, uq_item, uq_q, hc + 2, 0, n_light, hid, hlist,
                                ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, 8 | 1 | 2 | 4 | 16, hp_hi, hp_lo, hp_cnt, hp_mut,
-                               cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, rowcnt, rowcnt_h, d_shards, d_cnt));
+                               cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, rowcnt, rowcnt_h, d_shards, d_cnt, nullptr));
         int64_t h_cnt[4];
         XM_TRY(d2h(h_cnt, d_cnt, 4, c->st));
         XM_HIP(hipStreamSynchronize(c->st));

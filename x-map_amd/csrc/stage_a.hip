@@ -16,6 +16,7 @@
 //   * finalisation (cosine, significance weighting, zero filter) is done from LDS; a count pass
 //     sizes the CSR output, a fill pass writes it (col, sim fp64, mutu, n_ij).
 #include "common.h"
+#include "item_stats.h"
 
 namespace xmap {
 
@@ -106,105 +107,6 @@ __global__ __launch_bounds__(256) void k_csc_fill(long long U, const long long *
         }
 }
 
-// one wave per item: lane-strided partial sums, fixed butterfly reduction (deterministic)
-// stats of item i on a group of G lanes (G = 16: four items per wave; G = 64: the whole wave); gl = lane in the group.
-// All lanes of the wave call it (the reductions are wave instructions); `on` says whether this group has an item.
-template <int G>
-__device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, const long long *iptr, const int *iuser,
-                                                 const float *irating, const double *u_avg, double *info, double *norms,
-                                                 int *ia_user, double *partial = nullptr) {
-    long long p0 = 0, p1 = 0;
-    if (on) { p0 = iptr[i]; p1 = iptr[i + 1]; }
-    double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
-    if (G < 64 || p1 - p0 <= 64 * 8) {
-        for (long long p = p0 + gl; p < p1; p += G) {
-            double r = (double)irating[p];
-            double d = r - u_avg[iuser[p]];
-            s += r;
-            q += r * r;
-            dd_add(a2, a2lo, d * d);   // exact sum of the fp64 squares (order-independent)
-        }
-    } else {
-        // popular items (up to 1e5 raters): 8 independent accumulators keep 8 gathers in flight per lane instead of
-        // a chain of 1300 dependent round trips; the partials are merged exactly below
-        constexpr int UN = 8;
-        double su[UN], qu[UN], ah[UN], al[UN];
-#pragma unroll
-        for (int t = 0; t < UN; t++) { su[t] = 0.0; qu[t] = 0.0; ah[t] = 0.0; al[t] = 0.0; }
-        // software pipeline: the ratings and users of the NEXT round are requested before this round's user averages
-        // are gathered, so a round costs one dependent round trip, not two (156 rounds for the most popular item: the
-        // kernel's tail).  Same partial sums in the same order.
-        float rr[UN], nr[UN];
-        int uu[UN], nu[UN];
-        auto fetch = [&](long long p, float *r_, int *u_) {
-#pragma unroll
-            for (int t = 0; t < UN; t++) {
-                const long long pp = p + 64 * t;
-                r_[t] = pp < p1 ? irating[pp] : 0.f;
-                u_[t] = pp < p1 ? iuser[pp] : -1;
-            }
-        };
-        fetch(p0 + gl, nr, nu);
-        for (long long p = p0 + gl; p < p1; p += 64 * UN) {
-#pragma unroll
-            for (int t = 0; t < UN; t++) { rr[t] = nr[t]; uu[t] = nu[t]; }
-            fetch(p + 64 * UN, nr, nu);      // out-of-range entries come back as (0, -1)
-            double av[UN];
-#pragma unroll
-            for (int t = 0; t < UN; t++) av[t] = uu[t] >= 0 ? u_avg[uu[t]] : 0.0;
-#pragma unroll
-            for (int t = 0; t < UN; t++) {
-                if (uu[t] < 0) continue;
-                const double r = (double)rr[t];
-                const double d = r - av[t];
-                su[t] += r;
-                qu[t] += r * r;
-                dd_add(ah[t], al[t], d * d);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            s += su[t];
-            q += qu[t];
-            dd_add(a2, a2lo, ah[t]);
-            dd_add(a2, a2lo, al[t]);
-        }
-    }
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) {
-        double oh = __shfl_down(a2, m, G), ol = __shfl_down(a2lo, m, G);
-        dd_add(a2, a2lo, oh);
-        dd_add(a2, a2lo, ol);
-    }
-    if (partial) {     // user-sharded input: this rank's share of the item's sums (k_item_merge adds the shares up)
-        if (on && gl == 0) {
-            double *o = partial + (size_t)i * 5;
-            o[0] = s; o[1] = q; o[2] = a2; o[3] = a2lo; o[4] = (double)(p1 - p0);
-        }
-        return;
-    }
-    a2 = __shfl(a2, 0, G);
-    double n = (double)(p1 - p0);
-    double avg = (p1 > p0) ? 1.0 * s / n : 0.0;
-    if (on && gl == 0) {
-        info[(size_t)i * 4 + 0] = avg;
-        info[(size_t)i * 4 + 1] = sqrt(q);
-        info[(size_t)i * 4 + 2] = sqrt(a2);
-        info[(size_t)i * 4 + 3] = 1.0 * n;
-        if (norms) {   // dense copies of the two norms: 8 B per item stays L2-resident for the per-pair gathers
-            norms[i] = sqrt(q);
-            norms[(size_t)I + i] = sqrt(a2);
-        }
-    }
-    if (!ia_user) return;   // the flag-packed copies are read by the complete-rows formulation only
-    for (long long p = p0 + gl; p < p1; p += G) {
-        unsigned ge = ((double)irating[p] >= avg) ? 0x80000000u : 0u;
-        ia_user[p] = (int)((unsigned)iuser[p] | ge);
-    }
-}
-
 // four items per wave: the ones with at most 64 raters (99 % at BASELINE configs[1]; the median item has 10) together,
 // one per 16-lane group; the others one after the other on the whole wave
 // items [lo, hi) (a rank's share when the items are sharded: the per-item results are all-gathered afterwards)
@@ -217,13 +119,13 @@ __global__ __launch_bounds__(256) void k_item_stats(int I, int lo, int hi, const
     {
         const int i = i0 + (lane >> 4);
         const bool on = i < hi && iptr[i + 1] - iptr[i] <= 64;
-        item_stats_group<16>(on, i, lane & 15, I, iptr, iuser, irating, u_avg, info, norms, ia_user, partial);
+        item_stats_group<16>(on, i, lane & 15, I, iptr, CscSrc{iuser, irating, u_avg}, info, norms, ia_user, partial);
     }
     for (int t = 0; t < 4; t++) {
         const int i = i0 + t;
         if (i >= hi) break;
         if (iptr[i + 1] - iptr[i] <= 64) continue;
-        item_stats_group<64>(true, i, lane, I, iptr, iuser, irating, u_avg, info, norms, ia_user, partial);
+        item_stats_group<64>(true, i, lane, I, iptr, CscSrc{iuser, irating, u_avg}, info, norms, ia_user, partial);
     }
 }
 

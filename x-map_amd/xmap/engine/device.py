@@ -25,10 +25,13 @@ class DeviceRatings(object):
     derived on the device at the start of every stage-A pass (Engine.build_csc); only the id dictionary and the
     H2D upload are one-off host work."""
 
-    def __init__(self, user_ptr, item, rating, time, n_items, attrs, device="cuda:0"):
+    def __init__(self, user_ptr, item, rating, time, n_items, attrs, device="cuda:0", rating64=False):
+        """rating64: also keep the ratings as fp64 (RecommenderSim runs over AlterEgo rows, whose ratings are np.float64 means,
+        reference core/generator.py:123-138 -> core/recommenderSim.py:64-133; the three stages of the path read float32)"""
         self.device = torch.device(device)
         user_ptr = np.ascontiguousarray(user_ptr, np.int64)
         item = np.ascontiguousarray(item, np.int32)
+        r64 = np.ascontiguousarray(rating, np.float64) if rating64 else None
         rating = np.ascontiguousarray(rating, np.float32)
         time = np.ascontiguousarray(time, np.int64)
         self.n_users = len(user_ptr) - 1
@@ -44,6 +47,7 @@ class DeviceRatings(object):
         self.user_ptr = t(user_ptr).to(d)
         self.user_item = t(item).to(d)
         self.user_rating = t(rating).to(d)
+        self.user_rating64 = t(r64).to(d) if r64 is not None else None
         self.user_time = t(time).to(d)
         self.item_ptr = torch.zeros(self.n_items + 1, dtype=torch.int64, device=d)
         self.item_user = torch.zeros(max(self.nnz, 1), dtype=torch.int32, device=d)
@@ -389,9 +393,11 @@ class Engine(object):
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
-    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False):
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
-        rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity)."""
+        rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity).
+        split: count a row's own pairs (rowcnt) and the pairs lighter rows computed for it (a 5th return value) apart --
+        what tri_mirror takes."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -409,6 +415,7 @@ class Engine(object):
             coo_nij = self._empty(cap_coo, torch.int32)
             coo_ls = self._empty(cap_coo, torch.float64) if (rec or raw) else None    # raw: the error column of the dot
             rowcnt = self._empty(max(I, 1), torch.int32)
+            mircnt = self._empty(max(I, 1), torch.int32) if split else None
             nh = L.n_heavy_units if do_heavy else 0
             hp_hi = self._empty(max(nh, 1) * 1024, torch.float64)
             hp_lo = self._empty(max(nh, 1) * 1024, torch.float64)
@@ -425,7 +432,7 @@ class Engine(object):
                     vp(L.uq_q), L.cls_ptr, i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
-                    vp(coo_mutu), vp(coo_nij), vp(coo_ls), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
+                    vp(coo_mutu), vp(coo_nij), vp(coo_ls), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt), vp(mircnt)))
             if os.environ.get("XMAP_SPLIT_PHASES") == "1":        # one timer per phase (analysis)
                 with self.timed("pair_heavy"):
                     run(8 | (1 if do_heavy else 0))
@@ -454,6 +461,8 @@ class Engine(object):
         n, n_unordered = int(sh[0]), int(sh[1])
         coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if (rec or raw) else ())
         out = (coo, rowcnt, n, n_unordered)
+        if split:
+            return out + (mircnt,)
         return out if retry else out + (0,)
 
     def tri_scatter(self, coo, rowcnt, info, n=None, L=None):
@@ -491,15 +500,9 @@ class Engine(object):
         sensitivity of every directed item pair with a co-rater, CSR by first item (col, sim, nij, ls).  The same
         pair machinery as stage A: exact (double-double) sums with a zero user average, no heavy set."""
         R = self.R
-        st = _stream(self.dev)
         with self.timed("rec_stats"):
-            self.build_csc()
-            zero_avg = self._zeros(max(R.n_users, 1), torch.float64)
-            info = self._zeros((max(R.n_items, 1), 4), torch.float64)
-            self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
-            check(lib.xmap_item_stats(st, C.byref(R.c), vp(zero_avg), vp(info), vp(self.norms), None, None, i32(0), i32(R.n_items)))
-        stats = (zero_avg, None, info, None, None)
-        L = self.tri_layout(stats, slot_target, ch_min=max(64, R.n_users + 2), dups=True)
+            stats, L = self.layout3(slot_target, ch_min=max(64, R.n_users + 2), wide=True)      # no heavy set
+        info = stats[2]
         coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
         S = self.tri_scatter(coo, rowcnt, info, n, L)
         S.cap, S.n_unordered, S.layout = int(cap), n_unordered, L
@@ -520,13 +523,94 @@ class Engine(object):
                                       vp(col), vp(sim), vp(ls)))
         return cnt[:I], col[:I], sim[:I], ls[:I]
 
+    def layout3(self, slot_target=640, ch_min=1024, item_range=None, wide=False):
+        """Round-3 layout of the "tri" formulation, one transposition per pass (xmap_sim3_layout): item counts, user and
+        item info, weight-sorted profiles, rater records through the tile sort, heavy set, work units.  Returns (stats, L)
+        like stats() + tri_layout().  item_range: item info of that share of the items only (sharded ranks all-gather
+        the rest).  wide: fp64 ratings (R.user_rating64) with zero user averages -- the RecommenderSim variant."""
+        R = self.R
+        st = _stream(self.dev)
+        I, U, nnz = R.n_items, R.n_users, R.nnz
+        n1, i1 = max(nnz, 1), max(I, 1)
+        rw = 3 if wide else 2                                    # 64-bit words per sort record
+        L = SimResult()
+        cnt = self._empty(i1, torch.int32)
+        rsum = self._empty(i1, torch.float64)
+        ian = self._empty((i1, 2), torch.float64)
+        u_avg = self._zeros(max(U, 1), torch.float64) if wide else self._empty(max(U, 1), torch.float64)
+        u_norm = None if wide else self._empty(max(U, 1), torch.float64)
+        L.hist = self._empty(U + 2, torch.int32)
+        L.pre = self._empty(U + 3, torch.int64)
+        L.ctl = self._empty(4, torch.int32)
+        L.hid = self._empty(i1, torch.int32)
+        L.hlist = self._zeros(1024, torch.int32)
+        L.ub_key = self._empty(n1, torch.int64)
+        L.ub = self._empty(n1 * (2 if wide else 1), torch.int64)
+        srec = self._empty(n1 * rw, torch.int64)
+        buf_a = self._empty(n1 * rw, torch.int64)
+        buf_b = self._empty(n1 * rw, torch.int64)
+        L.rc = self._empty(n1 * 2, torch.int64)
+        L.Wp = self._empty(i1, torch.int64)
+        L.dups = bool(wide)
+        L.wide = bool(wide)
+        info = self._out((i1, 4), torch.float64, I > 0)
+        self.norms = self._out(2 * i1, torch.float64, I > 0)
+        lo, hi = (0, I) if item_range is None else (int(item_range[0]), int(item_range[1]))
+        h_ctl = (C.c_int32 * 2)()
+        r64 = None
+        if wide:
+            r64 = R.user_rating64 if R.user_rating64 is not None else R.user_rating.double()
+        with self.timed("layout3"):
+            check(lib.xmap_sim3_layout(st, C.byref(R.c), vp(R.item_ptr), vp(r64), i32(ch_min), i32(lo), i32(hi), vp(cnt), vp(rsum),
+                                       vp(ian), vp(u_avg), vp(u_norm), vp(L.hist), vp(L.pre), vp(L.ctl), vp(L.hid), vp(L.hlist),
+                                       vp(L.ub_key), vp(L.ub), vp(srec), vp(buf_a), vp(buf_b), vp(L.rc), vp(L.Wp), vp(info),
+                                       vp(self.norms), h_ctl))
+        R.csc_ready = False             # item_ptr is current; item_user / item_rating are not built on this path
+        L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
+        L.slot_target = slot_target
+        self._tri_plan(L, slot_target)
+        both = torch.stack([L.Wp[:I].sum(), L.Wp[L.hlist[:L.n_heavy].long()].sum()]).tolist() if I else [0, 0]   # one sync
+        L.half_contrib, L.heavy_half = int(both[0]), int(both[1])
+        return (u_avg, u_norm, info, None, None), L
+
+    def tri_mirror(self, coo, own, mir, info, n):
+        """round-3 mirror (xmap_sim3_mirror): a complete half COO with n valid entries, own[i] = pairs row i computed,
+        mir[j] = pairs computed in lighter rows -> CSR, row = [own | mirrored]"""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo[:5]]
+        cap = int(coo_i.numel())
+        kept = 2 * int(n)
+        row_ptr = self._out(I + 1, torch.int64, I > 0)
+        mptr = self._empty(I + 1, torch.int64)
+        tot = self._empty(max(I, 1), torch.int32)
+        fill = self._empty(max(I, 1), torch.int32)
+        buf_a = self._empty(max(int(n), 1) * 3, torch.int64)
+        buf_b = self._empty(max(int(n), 1) * 3, torch.int64)
+        col = self._empty(max(kept, 1), torch.int32)
+        sim = self._empty(max(kept, 1), torch.float64)
+        mutu = self._empty(max(kept, 1), torch.int32)
+        nij = self._empty(max(kept, 1), torch.int32)
+        with self.timed("scatter"):
+            check(lib.xmap_sim3_mirror(st, i32(I), i64(cap), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu), vp(coo_nij), i64(n),
+                                       vp(own), vp(mir), vp(tot), vp(row_ptr), vp(mptr), vp(fill), vp(buf_a), vp(buf_b), vp(col),
+                                       vp(sim), vp(mutu), vp(nij)))
+        return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
+
     def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
-        """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU)."""
-        with self.timed("stats"):
-            stats = self.stats()
-        L = self.tri_layout(stats, slot_target, ch_min)
-        coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
-        S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
+        """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU).  XMAP_A_V2=1: the round-2 sequence
+        (CSC build, CSC-driven rater records, cursor-atomic mirror) -- kept as a cross-check of the round-3 one."""
+        if os.environ.get("XMAP_A_V2") == "1":
+            with self.timed("stats"):
+                stats = self.stats()
+            L = self.tri_layout(stats, slot_target, ch_min)
+            coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
+            S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
+        else:
+            stats, L = self.layout3(slot_target, ch_min)
+            coo, rowcnt, n, n_unordered, mir = self.tri_pairs(method, cap, stats, L, split=True)
+            S = self.tri_mirror(coo, rowcnt, mir, stats[2], n)
         S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
         S.cap = int(cap)
         S.u_avg, S.u_norm = stats[0], stats[1]

@@ -158,8 +158,10 @@ def rec_sim_from_profiles(user_profiles, cap, ctx=None):
         item.extend(iidx[t[0]] for t in prof)
         rating.extend(float(t[1]) for t in prof)
     dev = "cuda:%d" % torch.cuda.current_device()
-    R = device.DeviceRatings(ptr, np.asarray(item, np.int32), np.asarray(rating, np.float32),
-                             np.zeros(len(item), np.int64), len(iids), xids.item_attrs(iids), dev)
+    # fp64 all the way: AlterEgo ratings are np.float64 means (reference core/generator.py:123-138), and that is what
+    # RecommenderSim multiplies (core/recommenderSim.py:64-133)
+    R = device.DeviceRatings(ptr, np.asarray(item, np.int32), np.asarray(rating, np.float64),
+                             np.zeros(len(item), np.int64), len(iids), xids.item_attrs(iids), dev, rating64=True)
     eng = device.Engine(R)
     S = eng.rec_sim(cap)
     return RecSimRDD(S, iids, ctx, eng)
