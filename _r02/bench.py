@@ -1,0 +1,574 @@
+"""bench.py -- one "step" = one pass of the X-MAP hot path (item-item similarity -> cross-domain
+extension -> AlterEgo generation) over synthetic Amazon-format ratings already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  metric = item-item sim pairs/s: D (distinct directed item pairs with
+>= 1 co-rater evaluated by stage A) / stage-A time; AlterEgo profiles/s and the per-stage
+times ride along in the same line.  N>1 shards the items of the SAME workload over the ranks (strong
+scaling): stage-A rows and stage-B start items are split, the kept rows and the per-start candidates are
+exchanged with RCCL all-gathers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "x-map_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+CAP = 50                # parameters.yaml:18
+
+
+# The bench line is the ONLY thing on stdout: native libraries write there too (RCCL prints a version banner on
+# communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
+_REAL_STDOUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+
+
+def emit(out):
+    _REAL_STDOUT.write(json.dumps(out) + "\n")
+    _REAL_STDOUT.flush()
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def workloads():
+    from xmap.engine import synth
+    return {
+        # BASELINE.json configs[1]: ~1M users / 200k+200k items, top-k 50
+        "c2": dict(gen=lambda: synth.config_c2(), k=50, name="amazon-like two-domain 1M users / 200k+200k items, top-k=50 (BASELINE configs[1])"),
+        # BASELINE.json configs[0]: 10k users / 2x5k items (the reference's CPU-runnable case)
+        "c1": dict(gen=lambda: synth.config_c1(), k=10, name="10k users / 2x5k items, top-k=10 (BASELINE configs[0])"),
+    }
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
+def cpu_baseline(r, attrs, method, target_s=15.0, threads=4, k=0):
+    """Oracle (CPU restatement, `port`) timed on this host on a bounded row sample of the same workload."""
+    from oracle import xmap_oracle as xo
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
+    uavg, _ = xo.user_info(T)
+    info = xo.item_info(T, uavg)
+    I = r.n_items
+    # probe on a small slice to size the sample
+    probe = max(1, I // 200)
+    t0 = time.time()
+    S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, probe))
+    dt = max(time.time() - t0, 1e-3)
+    xo.sim_free(S)
+    rows = int(min(I, max(probe, probe * target_s / dt)))
+    t0 = time.time()
+    S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, rows))
+    dt = time.time() - t0
+    if dt < 0.5 * target_s and rows < I:      # the low rows are the cheap ones: take the whole stage when it is short
+        xo.sim_free(S)
+        rows = I
+        t0 = time.time()
+        S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, rows))
+        dt = time.time() - t0
+    out = dict(value=S.n_eval / dt, unit="pairs/s", cores=threads, kind="port",
+               sample="oracle stage A (item-item sim) on item rows [0,%d) of %d: %d pairs in %.1f s, OpenMP %d threads"
+                      % (rows, I, S.n_eval, dt, threads))
+    if rows == I and k:
+        # stage B beside it: the oracle's path enumeration + X-Sim accumulation (one thread, the reference's
+        # (t, s)-centric order) on the source records of a bounded item range; the knn classification before it is not
+        # part of the figure
+        X = xo.extend(T, S, k, s_range=(0, I), max_seconds=8.0)
+        out["stage_b"] = dict(value=X.n_paths / max(X.path_seconds, 1e-9), unit="paths/s", cores=1, kind="port",
+                              sample="oracle extend (k=%d), source records in item order until 8 s have passed: %d paths in %.1f s, 1 thread"
+                                     % (k, X.n_paths, X.path_seconds))
+        xo.ext_free(X)
+    xo.sim_free(S)
+    return out
+
+
+def bench_dense(args, rank, world, local, dist, sink=None):
+    """--workload dense: BASELINE.json configs[4], 200k x 200k item factors of dimension 128, top-k 50.  The target
+    rows are split over the ranks (no exchange: every rank ranks its rows against all source items)."""
+    from xmap.engine import device, synth
+    dev = "cuda:%d" % local
+    n_t = n_s = 200000
+    K, k = 128, args.k or 50
+    r = synth.make_two_domain(3, 60, 30, 30, overlap=0.5)      # an Engine needs a ratings handle; unused here
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev))
+    g = torch.Generator(device=dev).manual_seed(1)
+    Ft = torch.randn(n_t, K, device=dev, generator=g)
+    Fs = torch.randn(n_s, K, device=dev, generator=g)
+    lo, hi = rank * n_t // world, (rank + 1) * n_t // world
+    for _ in range(args.warmup):
+        eng.dense_topk(Ft[lo:hi], Fs, k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    eng.timers = {}
+    t0 = time.time()
+    for _ in range(args.steps):
+        eng.dense_topk(Ft[lo:hi], Fs, k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.time() - t0
+    tm = eng.timer_ms()
+    if dist:
+        wt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        wall = float(wt.item())
+    if rank == 0:
+        ms = float(np.mean(tm["dense_topk"]))
+        flop = 2.0 * K * (hi - lo) * n_s
+        ach = flop / (ms * 1e-3) / 1e12
+        out = {"metric": "dense_item_sim_pairs_per_s", "value": float(n_t) * n_s * args.steps / wall, "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "dense 128-d item factors 200k x 200k, top-k=%d (BASELINE configs[4])" % k,
+                          "parallelism": "target rows sharded over %d GPU(s)" % world},
+               "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+               "roofline": {"bound": "mfma", "kernel": "k_dense_topk", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("k_dense_topk"),
+                            "algorithmic_flop_per_launch": flop, "launch_ms": ms}}
+        if not args.no_cpu and world == 1:
+            from oracle import xmap_oracle as xo
+            rows, threads = 64, 4
+            a, b = xo.dense_normalize(Ft[:rows].cpu().numpy()), xo.dense_normalize(Fs.cpu().numpy())
+            t0 = time.time()
+            xo.dense_topk(a, b, k, nthreads=threads)
+            dt = time.time() - t0
+            while dt < 5.0 and rows < 4096:
+                rows *= 4
+                a = xo.dense_normalize(Ft[:rows].cpu().numpy())
+                t0 = time.time()
+                xo.dense_topk(a, b, k, nthreads=threads)
+                dt = time.time() - t0
+            out["cpu_baseline"] = dict(value=rows * float(n_s) / dt, unit="pairs/s", cores=threads, kind="port",
+                                       sample="oracle dense top-k on target rows [0,%d) x all %d sources: %.1f s, OpenMP %d threads"
+                                              % (rows, n_s, dt, threads))
+        (sink or emit)(out)
+
+
+def bench_multidomain(args, rank, world, local, dist):
+    """--workload c4: BASELINE.json configs[3] shape -- 4 source domains -> 1 target, ~5M users in total (1.25 M per
+    two-domain problem), top-k 100, private mapping.  The domains are dealt to rank groups (xmap.engine.multidomain);
+    a step = all domains once + the union of the AlterEgo rows.  Ratings are generated and uploaded inside the step's
+    make_engine (one domain resident at a time on a rank); that set-up is timed separately and excluded."""
+    from xmap.engine import device, synth, multidomain
+    dev = "cuda:%d" % local
+    k = args.k or 100
+    n_dom = 4
+    t0 = time.time()
+    doms = synth.config_c4()
+    log("setup: %d domains generated in %.1f s" % (n_dom, time.time() - t0))
+    engines = {}
+    up = [0.0]
+
+    def make_engine(d):
+        t1 = time.time()
+        if d not in engines:
+            engines.clear()                 # one domain resident at a time
+            torch.cuda.empty_cache()
+            r = doms[d]
+            engines[d] = (device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev)),
+                          r.n_src_items)
+            torch.cuda.synchronize()
+        up[0] += time.time() - t1
+        return engines[d]
+
+    walls = []
+    out = None
+    for it in range(args.warmup + args.steps):
+        up[0] = 0.0
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t1 = time.time()
+        out = multidomain.run_multidomain(make_engine, n_dom, args.method, CAP, k, True, dist)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        if it >= args.warmup:
+            walls.append(time.time() - t1 - up[0])
+    wall = float(np.sum(walls))
+    if dist:
+        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    if rank == 0:
+        users = len(np.unique(out["user"]))
+        emit({"metric": "alterego_profiles_per_s", "value": users * args.steps / wall, "unit": "profiles/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": "4 source domains -> 1 target, 1.25M users per two-domain problem, top-k=%d, private mapping "
+                                     "(BASELINE configs[3] shape)" % k,
+                         "parallelism": "domains dealt to %d rank group(s)" % min(world, n_dom), "domains": n_dom,
+                         "paths_per_domain": [int(x) for x in out["n_paths"]], "rows_per_domain": [int(x) for x in out["n_rows"]],
+                         "alterego_rows": int(len(out["user"])), "profiles": users}})
+
+
+def bench_recsim(args, rank, world, local, dist, sink=None):
+    """--workload recsim: RecommenderSim.calculate_sim over the AlterEgo rows the hot path produces at
+    BASELINE configs[1] (one GPU; the rows come out of one untimed pass of the three pipelines)."""
+    from xmap.engine import device, synth, ids
+    dev = "cuda:%d" % local
+    r = synth.config_c2()
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev))
+    S = eng.item_sim(args.method, CAP)
+    E = eng.extend(S, args.k or 50)
+    _, _, mp = eng.select(E, True)
+    G = eng.alterego(mp)
+    u, it, ra = G.user.cpu().numpy(), G.item.cpu().numpy(), G.rating.cpu().numpy()
+    del eng, S, E, G
+    torch.cuda.empty_cache()
+    o = np.argsort(u, kind="stable")
+    uu, uinv = np.unique(u[o], return_inverse=True)
+    ii, iinv = np.unique(it[o], return_inverse=True)
+    ptr = np.zeros(len(uu) + 1, np.int64)
+    np.cumsum(np.bincount(uinv, minlength=len(uu)), out=ptr[1:])
+    all_ids = r.item_ids()
+    iids = [all_ids[x] for x in ii]
+    item, rating = iinv.astype(np.int32), ra[o].astype(np.float32)
+    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), ids.item_attrs(iids), dev)
+    eng = device.Engine(R)
+    log("recsim: AlterEgo rows %d, users %d, items %d" % (len(item), len(uu), len(iids)))
+    for _ in range(args.warmup):
+        eng.rec_sim(CAP)
+    torch.cuda.synchronize()
+    eng.timers = {}
+    t0 = time.time()
+    for _ in range(args.steps):
+        S = eng.rec_sim(CAP)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    for _ in range(args.steps):      # neighbour selection (recommender_privacy_pipeline, non-private): outside the metric
+        eng.rec_select(S, 10)
+    torch.cuda.synchronize()
+    tm = eng.timer_ms()
+    D = int(S.row_ptr[-1].item())
+    tri_ms = float(np.mean(tm["pair_tri"]))
+    nnz, I, P = len(item), len(iids), 2 * S.layout.half_contrib
+    # two walks over the co-ratings (accumulate, then the leave-one-out variants): 2 x (8 B per contribution it processes +
+    # rater records and profile copy once) + norms + 32 B per unordered pair written
+    bytes_tri = 2.0 * (8.0 * S.layout.half_contrib + 16.0 * nnz) + 8.0 * I + 32.0 * S.n_unordered
+    ach = bytes_tri / (tri_ms * 1e-3) / 1e9
+    out = {"metric": "recsim_pairs_per_s", "value": D * args.steps / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "RecommenderSim over the AlterEgo rows of BASELINE configs[1] (k=%d, private mapping)" % (args.k or 50),
+                      "rows": nnz, "users": len(uu), "items": I, "P_contributions": P, "D_pairs": D},
+           "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+           "roofline": {"bound": "hbm", "kernel": "k_pair_tri<LS>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms}}
+    if not args.no_cpu:
+        from oracle import xmap_oracle as xo
+        users = min(len(uu), 500000)           # bounded sample: the first users' rows (a closed sub-problem)
+        t0 = time.time()
+        O = xo.rec_sim(ptr[:users + 1], item[:ptr[users]], rating[:ptr[users]], I, CAP)
+        dt = time.time() - t0
+        out["cpu_baseline"] = dict(value=float(O.row_ptr[-1]) / dt, unit="pairs/s", cores=1, kind="port",
+                                   sample="oracle rec_sim on the rows of the first %d users: %d pairs in %.1f s, 1 thread"
+                                          % (users, int(O.row_ptr[-1]), dt))
+        xo.rec_free(O)
+    (sink or emit)(out)
+
+
+def bench_api(args, rank, world, local, dist):
+    """--api: BASELINE configs[1] driven through the reference's pipeline API -- xmap.utils.assist.{baseliner_calculate_sim,
+    extender, generator}_pipeline with the tool classes of xmap.core, a trainRDD of (uid, [(iid, rating, time)*]) records --
+    i.e. what a caller of the drop-in package gets.  One-off work (Python records -> id dictionary -> CSR -> H2D) happens
+    inside the first pipeline call and is reported as setup; the timed steps are the three calls, device-synchronised."""
+    from pyspark import SparkContext, SparkConf
+    from pyspark.sql import SQLContext
+    from xmap.core.baselinerSim import BaselinerSim
+    from xmap.core.extender import ExtendSim
+    from xmap.core.generator import Generator
+    from xmap.utils.assist import baseliner_calculate_sim_pipeline, extender_pipeline, generator_pipeline
+    from xmap.engine import synth
+    wl = workloads()["c2"]
+    k = args.k or wl["k"]
+    t0 = time.time()
+    r = wl["gen"]()
+    recs = r.train_records()
+    t_rec = time.time() - t0
+    sc = SparkContext(conf=SparkConf().setAppName("bench"))
+    sqlContext = SQLContext(sc)
+    trainRDD = sc.parallelize(recs, 8).cache()
+    sim_tool, ext_tool, gen_tool = BaselinerSim(args.method, CAP), ExtendSim(k), Generator(1, 0.6, args.method, 0.1)
+    t0 = time.time()
+    sim = baseliner_calculate_sim_pipeline(sc, sim_tool, trainRDD)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+    log("api: %d records built in %.1f s; first baseliner call (id dictionary + CSR + upload + stage A) %.1f s" % (len(recs), t_rec, t_setup))
+    # the 1.2e7 Python objects of the record list are static from here on: keep the cyclic collector from walking them
+    # in the middle of a timed call (a full collection over them is ~0.1 s; a Spark driver would not hold the records)
+    import gc
+    gc.collect()
+    gc.freeze()
+    ta, tb, tc = [], [], []
+    ae = ext = None
+    t_all = 0.0
+    for it in range(args.warmup + args.steps):
+        ae = ext = sim = None
+        torch.cuda.synchronize()
+        t0 = time.time()
+        sim = baseliner_calculate_sim_pipeline(sc, sim_tool, trainRDD)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        ext = extender_pipeline(sc, sqlContext, sim_tool, ext_tool, sim)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        ae = generator_pipeline(gen_tool, trainRDD, ext, True)
+        torch.cuda.synchronize()
+        t3 = time.time()
+        if it >= args.warmup:
+            ta.append(t1 - t0); tb.append(t2 - t1); tc.append(t3 - t2)
+            t_all += t3 - t0
+        if it + 1 == args.warmup:
+            sim.state.engine.timers = {}            # HIP-event brackets of the engine calls behind the timed steps
+    tm = sim.state.engine.timer_ms()
+    sim.state.engine.timers = None
+    S, E, G = sim.S, ext.E, ae.G
+    n_prof = ae.state.engine.n_profiles(G)
+    t_a, t_b, t_c = float(np.mean(ta)), float(np.mean(tb)), float(np.mean(tc))
+    emit({"metric": "item_sim_pairs_per_s", "value": S.n_eval / t_a, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+          "warmup": args.warmup, "ms_per_step": t_all * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+          "config": {"workload": wl["name"], "via": "xmap.utils.assist pipelines + xmap.core tool classes (host wall clock around each "
+                                                    "call, device-synchronised; lazy extended_simRDD not materialised)",
+                     "method": args.method, "top_k": k, "private": True, "users": r.n_users, "items": r.n_items, "nnz": r.nnz,
+                     "D_pairs_evaluated": S.n_eval, "D_pairs_kept": S.n_kept, "paths": E.n_paths},
+          "alterego_profiles_per_s": n_prof / (t_b + t_c), "alterego_rows": G.n_rows, "profiles": n_prof,
+          "stage_ms": {"A_item_sim": t_a * 1e3, "B_extend": t_b * 1e3, "C_generate": t_c * 1e3},
+          "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+          "setup_s": {"python_records": t_rec, "first_call_id_dictionary_csr_upload_stage_a": t_setup}})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)    # the first pass of a fresh process allocates (and first-touches) ~120 GB of accumulator rows
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--method", default="adjust_cosine")   # parameters.yaml:17
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--layout", default="items", choices=["items", "users"])   # N > 1: replicated ratings + item-sharded work
+    #                                             (default), or user-sharded ratings + exchange of the partial similarities
+    ap.add_argument("--api", action="store_true")        # configs[1] through the pipeline API of the drop-in package (one GPU)
+    ap.add_argument("--no-extra", action="store_true")   # default c2 run at N = 1: skip the short recsim / dense lines
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("XMAP_DIST_BACKEND", "nccl") != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
+    if args.gpus > 1 and world == 1:
+        log("bench.py: --gpus %d needs torch.distributed.run; running 1 rank" % args.gpus)
+    dist = None
+    # XMAP_FORCE_DIST=1: take the sharded path with one rank (rehearses the RCCL collectives on a one-GPU box)
+    force = world == 1 and os.environ.get("XMAP_FORCE_DIST") == "1"
+    if force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        backend = os.environ.get("XMAP_DIST_BACKEND", "nccl")   # "gloo": rehearsal with several ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    dev = "cuda:%d" % local
+    torch.cuda.set_device(local)
+
+    if args.api:
+        bench_api(args, rank, world, local, dist)
+        return
+    if args.workload == "recsim":
+        bench_recsim(args, rank, world, local, dist)
+        return
+    if args.workload == "c4":
+        bench_multidomain(args, rank, world, local, dist)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.workload == "dense":
+        bench_dense(args, rank, world, local, dist)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    from xmap.engine import device, sharded
+    wl = workloads()[args.workload]
+    k = args.k or wl["k"]
+    t0 = time.time()
+    r = wl["gen"]()
+    attrs = r.item_attrs()
+    by_users = args.layout == "users" and dist is not None      # (with XMAP_FORCE_DIST=1: one share, the exchange through RCCL)
+    u_lo = 0
+    if by_users:       # this rank's share of the users (complete profiles), items indexed globally
+        u_lo, u_hi = r.n_users * rank // world, r.n_users * (rank + 1) // world
+        e0, e1 = int(r.user_ptr[u_lo]), int(r.user_ptr[u_hi])
+        R = device.DeviceRatings((r.user_ptr[u_lo:u_hi + 1] - r.user_ptr[u_lo]).astype(np.int64), r.item[e0:e1].copy(),
+                                 r.rating[e0:e1].copy(), r.time[e0:e1].copy(), r.n_items, attrs, dev)
+    else:
+        R = device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs, dev)
+    eng = device.Engine(R)
+    if rank == 0:
+        log("setup: users=%d items=%d nnz=%d in %.1f s (synthetic data generation + H2D upload of the CSR)" % (r.n_users, r.n_items, r.nnz, time.time() - t0))
+
+    def step():
+        if by_users:
+            return sharded.run_step_users(eng, u_lo, args.method, CAP, k, True, dist)
+        return sharded.run_step(eng, args.method, CAP, k, True, dist, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    eng.timers = {}
+    t_start = time.time()
+    res = None
+    for _ in range(args.steps):
+        res = None          # drop the previous pass's buffers first: the caching allocator then hands the same blocks out
+        res = step()        # again instead of growing (13 GB of middle lists per pass)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.time() - t_start
+    tm = eng.timer_ms()
+    eng.timers = None
+    if dist:
+        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    ms_step = wall * 1e3 / args.steps
+    stage = {n: float(np.mean(tm.get(n, [0.0]))) for n in ("stage_a", "stage_b", "stage_c")}
+    if dist:  # max over ranks of the per-stage means
+        v = torch.tensor([stage["stage_a"], stage["stage_b"], stage["stage_c"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        stage = dict(zip(("stage_a", "stage_b", "stage_c"), [float(x) for x in v.tolist()]))
+    t_a, t_b, t_c = stage["stage_a"] / 1e3, stage["stage_b"] / 1e3, stage["stage_c"] / 1e3
+    n_upd = int(getattr(res["E"], "n_updates", 0))      # row updates of this rank's starts
+    if dist:
+        nu = torch.tensor([n_upd], dtype=torch.int64, device=dev)
+        dist.all_reduce(nu)
+        n_upd = int(nu.item())
+
+    if rank == 0:
+        D, Dk, P, nnz, I = res["n_eval"], res["n_kept"], res["n_contrib"], r.nnz, r.n_items
+        # Stage-A dominant kernel: k_pair_tri (one logical pass per step: one launch per LDS table class).  Algorithmic bytes per launch (SURVEY.md 8d,
+        # DESIGN.md 4): 8 B per directed co-rating contribution it processes + CSR and rater records read once
+        # (16 B per rating) + item stats (32 B per item) + the kept pairs it emits (24 B per unordered pair).
+        tri_ms = float(np.mean(tm.get("pair_tri", [0.0])))
+        # (the bracket covers the rows of the heavy set too unless XMAP_SPLIT_PHASES=1: they run on a side stream next to the
+        # class launches, and their contributions are then part of the bytes)
+        split = "pair_heavy" in tm
+        bytes_tri = 8.0 * (res["n_contrib_light"] if split or world > 1 else P) + 16.0 * nnz + 32.0 * I + 12.0 * res["n_kept_local"]
+        ach = bytes_tri / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
+        # SURVEY.md 8d states the whole-stage figure too: B_A = 8 P + 16 nnz + 32 I + 20 D' over t_A
+        bytes_a = 8.0 * P + 16.0 * nnz + 32.0 * I + 20.0 * Dk
+        # Stage-B dominant kernel: k_paths2.  Compulsory HBM bytes are the knn tables + the outputs (SURVEY.md 8d:
+        # 12 E + 12 N_out); it is latency / random-access bound, paths/s is the figure of merit.
+        paths_ms = float(np.mean(tm.get("paths", [0.0])))
+        bytes_paths = 12.0 * res["knn_entries"] + 12.0 * res["n_out"]
+        tr_a, tr_b = pmc_traffic("k_pair_tri"), pmc_traffic("k_paths4")
+
+        ach_b = bytes_paths / (paths_ms * 1e-3) / 1e9 if paths_ms > 0 else 0.0
+        rf_b = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
+                "traffic": tr_b, "traffic_ratio": (tr_b / bytes_paths) if (tr_b and bytes_paths) else None,
+                "traffic_fetch_x1": pmc_traffic("k_paths4_fetch_x1"),     # FETCH_SIZE as is: exact for lone 32-byte reads (profiles/README.md)
+                "algorithmic_bytes_per_launch": bytes_paths, "launch_ms": paths_ms,
+                "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                # what the kernel is bound by since round 2 (without the path arithmetic it takes as long, without
+                # the row accesses 60 %): random 32-byte read-modify-writes of row entries, counted by the kernel, against the
+                # rate of uniformly random ones over a region of this size (profiles/rand_rmw_grp.hip; the rows' column order
+                # is what puts the kernel above it)
+                "row_updates": {"count": n_upd, "per_s": n_upd / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
+                                "reference_per_s": 1.9e10, "reference": "profiles/rand_rmw_grp.hip, 24 GiB region"},
+                # the kernel's other limit: 26 fp64 operations per path-end pair (3 to join record and end, 8 division, 1
+                # product, 14 for the two exact sums; no FMA pairs by construction: -ffp-contract=off) against the vector
+                # fp64 issue rate (78.6 TFLOP/s counts an FMA as two: 39.3e12 instructions x lanes per second); the SQ
+                # counters of profiles/*_sq_k_paths4.json give the busy fraction of the vector ALUs directly (55 %)
+                "valu": {"bound": "valu_fp64", "achieved": 26.0 * res["n_paths"] / (paths_ms * 1e-3) / 1e12 if paths_ms > 0 else 0.0,
+                         "peak": 39.3, "unit": "Tinstr/s (fp64 lane operations)",
+                         "frac": 26.0 * res["n_paths"] / (paths_ms * 1e-3) / 39.3e12 if paths_ms > 0 else 0.0},
+                "note": "per column (start, x): one set of lanes (W ends x S record slices) and one read-modify-write of the "
+                        "start's row (32-byte (value, error) pairs, rows indexed by end rank in column order); ablations "
+                        "(profiles/README.md): 464 ms without the row updates, 615 ms without the path arithmetic"}
+        out = {
+            "metric": "item_sim_pairs_per_s", "value": D / t_a if t_a > 0 else 0.0, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "method": args.method, "top_k": k, "private": True,
+                       "users": r.n_users, "items": I, "nnz": nnz, "P_contributions": P,
+                       "D_pairs_evaluated": D, "D_pairs_kept": Dk, "paths": res["n_paths"],
+                       "parallelism": ("users sharded over %d GPU(s), partial similarities exchanged" if by_users else "items sharded over %d GPU(s)") % world},
+            "alterego_profiles_per_s": res["n_profiles"] / (t_b + t_c) if (t_b + t_c) > 0 else 0.0,
+            "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
+            "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},
+            "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
+            # the dominant kernel of the step (90 % of it): the path enumeration of stage B.  Its compulsory HBM bytes
+            # (12 E + 12 N_out -- knn tables in, (start, end, xsim) out) are a small part of what it moves:
+            # it accumulates 32-byte (value, error) pairs per (start, end) in HBM rows; paths/s is the figure of merit
+            "roofline": dict(rf_b, kernel="k_paths4"),
+            "roofline_stage_a": {"bound": "hbm", "kernel": "k_pair_tri" if split else "k_pair_tri + k_pair_heavy / k_heavy_merge (side stream)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr_a,
+                                 "traffic_ratio": (tr_a / bytes_tri) if (tr_a and bytes_tri) else None,
+                                 "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms,
+                                 "stage_a_whole": {"algorithmic_bytes": bytes_a, "ms": stage["stage_a"],
+                                                   "achieved": bytes_a / t_a / 1e9 if t_a > 0 else 0.0,
+                                                   "frac": bytes_a / t_a / 1e9 / HBM_PEAK_GBS if t_a > 0 else 0.0}},
+        }
+        if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(r, attrs, args.method, k=k)
+        if world == 1 and args.workload == "c2" and not args.no_extra:
+            # the two other full-size workloads (`--workload recsim`, `--workload dense`), three steps each, so that every
+            # run of the default command records them; their full lines (with cpu_baseline) come from their own flags
+            res = None
+            eng._scratch.clear()            # 26 GB of accumulator rows
+            torch.cuda.empty_cache()
+            a2 = argparse.Namespace(**dict(vars(args), steps=3, warmup=1, no_cpu=True, k=0))
+            other = {}
+            for name, fn in (("recsim", bench_recsim), ("dense", bench_dense)):
+                try:
+                    fn(a2, rank, world, local, None, sink=lambda o, name=name: other.__setitem__(name, o))
+                    o = other[name]
+                    other[name] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                                   "steps": o["steps"], "warmup": o["warmup"], "dtype": o["dtype"], "workload": o["config"]["workload"],
+                                   "roofline": {x: o["roofline"][x] for x in ("bound", "kernel", "achieved", "peak", "unit", "frac")}}
+                except Exception as e:      # the headline line must not depend on the side workloads
+                    other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
+            out["other_workloads"] = other
+        emit(out)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

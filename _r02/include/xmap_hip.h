@@ -59,14 +59,6 @@ typedef struct xmap_ratings {
 const char *xmap_last_error(void);
 int xmap_version(void);
 
-/* The library keeps its own temporaries (per thread, device and stream; recycled when a call ends, trimmed to 256 MiB when
- * idle).  xmap_trim hands everything the calling thread's idle arenas still hold back to the driver (synchronises the
- * device).  xmap_debug_arena / xmap_debug_arena_call are test hooks: the arena's live temporaries and reserved bytes, and a
- * call that takes two temporaries and leaves through an error path when fail != 0. */
-int xmap_trim(void);
-int xmap_debug_arena(void *stream, int64_t *live, int64_t *reserved);
-int xmap_debug_arena_call(void *stream, int64_t bytes, int fail);
-
 /* exclusive prefix sum of n int64 values; out[n] receives the total; *h_total (may be NULL) too (syncs). */
 int xmap_exclusive_scan_i64(void *stream, const int64_t *in, int64_t *out, int64_t n, int64_t *h_total);
 int xmap_exclusive_scan_i32_to_i64(void *stream, const int32_t *in, int64_t *out, int64_t n, int64_t *h_total);
@@ -167,50 +159,11 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij,
                     double *coo_ls /*NULL, or the RecommenderSim variant (below)*/, int32_t *rowcnt,
                     int32_t *rowcnt_h /*[64][1024] scratch*/, int64_t *d_shards /*[2][4096]*/,
-                    int64_t *d_counters /*[4]*/,
-                    int32_t *mircnt /*[I] or NULL.  NULL: rowcnt[i]++ / rowcnt[j]++ as described above.  Else rowcnt counts
-                                      the pairs a row computed itself and mircnt those computed in lighter rows (the row layout
-                                      of xmap_sim3_mirror)*/);
+                    int64_t *d_counters /*[4]*/);
 int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
                       const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_ls /*or NULL*/,
                       const int64_t *row_ptr, int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist,
                       int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *ls /*or NULL*/);
-/* ---- round 3: one transposition per pass -----------------------------------------------------------------------------
- * xmap_sim3_layout replaces xmap_build_csc + xmap_user_stats + xmap_item_stats + xmap_sim2_layout for the "tri" formulation:
- *   k_count3          raters per item in one pass over the CSR (LDS-cached atomics) -> item_ptr (exclusive scan)
- *   k_user_stats      u_avg / u_norm (get_universal_user_info, core/baselinerSim.py:17-38)        [float ratings only]
- *   k_hist .. k_mark_heavy   as xmap_sim2_layout
- *   k_sort_profiles3  profiles sorted heaviest first: ub (8 B per entry; 16 B with rating64) and one sort record per entry
- *                     {item, position, rating, user} (16 B; 24 B with rating64)
- *   tile sort         (csrc/tilesort.h) sort records -> rater records rc in item order (any order inside an item), W+ summed
- *   k_item_stats3 ..  get_universal_item_info (:40-82) from the rater records -> info, norms; items with more than 4096
- *                     raters in chunks of 2048 on a wave each, merged in chunk order
- *   flags             `rating >= item average` (retrieve_path_info, :97-113) into the rater records and the profile copy
- * The CSC arrays (R->item_user / item_rating) are neither read nor written; R->item_ptr (= item_ptr) is written.
- * rating64 != NULL: the ratings are fp64 (RecommenderSim over AlterEgo means, core/recommenderSim.py:64-133; R->user_rating is
- * ignored), the user averages are zero by construction (u_avg must be zero-filled, u_norm may be NULL), there is no
- * mutuality, and ub / rc use the 16-byte wide forms xmap_sim2_pairs reads when coo_ls != NULL without phases bit 32.
- * h_ctl (host, [2]) = {CH, |H|}; synchronises. */
-int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr /*[I+1] = R->item_ptr*/,
-                     const double *rating64 /*[nnz] or NULL*/, int32_t ch_min, int32_t *cnt /*[I] scratch*/,
-                     double *u_avg /*[U]*/, double *u_norm /*[U] or NULL with rating64*/, int32_t *hist /*[U+2]*/,
-                     int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]*/, int32_t *hid /*[I]*/, int32_t *hlist /*[1024]*/,
-                     uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] x 8 B (16 B)*/, void *srec /*[nnz] x 16 B (24 B) scratch*/,
-                     void *bufA /*as srec, scratch*/, void *bufB /*as srec, scratch*/, void *rc /*[nnz] x 16 B*/,
-                     uint64_t *Wp /*[I]*/, double *info /*[I][4]*/, double *norms /*[2][I]*/, int32_t *h_ctl /*[2], host*/);
-/* The mirror of round 3.  xmap_sim2_pairs was given mircnt: own[i] = pairs row i computed (rowcnt), mir[j] = pairs computed
- * in lighter rows.  Row i of the CSR = [own | mirrored]: row_ptr = exclusive scan of own + mir; the own halves are written
- * in runs straight from the COO, the mirrored halves go through the tile sort keyed by the heavier item (positions mptr =
- * exclusive scan of mir).  n_pairs = valid COO entries (no entry may pair a row with itself). */
-int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
-                     const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij,
-                     const int64_t *d_shards /*[4096] fill of the COO's shards as left by xmap_sim2_pairs (coo_cap / 4096
-                                               slots each), or NULL: the COO is one range of n_pairs records*/,
-                     int64_t n_pairs, const int32_t *own /*[I]*/, const int32_t *mir /*[I]*/, int32_t *tot /*[I] scratch*/,
-                     int64_t *row_ptr /*[I+1] out*/, int64_t *mptr /*[I+1] scratch*/, int32_t *fill /*[I] scratch*/,
-                     void *bufA /*[n_pairs] x 24 B scratch*/, void *bufB /*[n_pairs] x 24 B scratch*/, int32_t *col,
-                     double *sim, int32_t *mutu, int32_t *nij);
-
 /* User-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard partial similarities"): a rank
  * holds the complete profiles of a share of the USERS.  Per item its share of get_universal_item_info's sums
  * (core/baselinerSim.py:56-82) is xmap_item_partials -> [I][5] = (sum r, sum r^2, sum (r - avg_u)^2 as an exact (value, error)
@@ -493,8 +446,7 @@ int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32
 /* Generator.build_alterEgo (core/generator.py:113-157).  count pass: cnt_t[u] pass-through rows
  * ("T:" in iid), cnt_m[u] AlterEgo rows (distinct mapped targets, first-seen order).  fill pass writes
  * rows [off_t[u]..) and [n_t_total + off_m[u]..): (user, item, rating = mean fp32, time of first row). */
-int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m,
-                        int64_t *d_profiles /* [1] device, zeroed by the caller: += users with at least one output row; or NULL */);
+int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m);
 int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, const int64_t *off_t,
                        const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item,
                        double *out_rating, int64_t *out_time);

@@ -1,0 +1,105 @@
+"""Stages around the hot path (clean, split, recommender sim / privacy / prediction): the
+build's host-side implementations against vectors captured from the reference
+(tests/golden/small_downstream.json.gz <- oracle/ref_harness/make_golden_downstream.py).  No GPU needed."""
+import datetime
+import gzip
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+os.environ["TZ"] = "UTC"
+time.tzset()
+
+from pyspark import SparkContext, SparkConf  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_downstream.json.gz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with gzip.open(GOLD, "rt") as f:
+        return json.load(f)
+
+
+def dt(ts):
+    return datetime.datetime.utcfromtimestamp(int(ts))
+
+
+def test_clean_matches_reference(gold, tmp_path):
+    from xmap.core.baselinerClean import BaselinerClean
+    from xmap.utils.assist import baseliner_clean_data_pipeline
+    g = gold["clean"]
+    p = tmp_path / "raw.txt"
+    p.write_text("\n".join(g["lines"]) + "\n")
+    sc = SparkContext(conf=SparkConf())
+    tool = BaselinerClean(*g["params"])
+    cleaned = baseliner_clean_data_pipeline(sc, tool, "file:" + str(p), False, 30).collect()
+    want = [(u, [(i, r, dt(t)) for (i, r, t) in prof]) for u, prof in g["cleaned"]]
+    assert cleaned == want
+    debug = baseliner_clean_data_pipeline(sc, tool, str(p), True, 30).collect()
+    assert [u for u, _ in debug] == g["partial"] and len(debug) <= g["params"][1]
+
+
+def test_split_protocol():
+    from xmap.core.baselinerSplit import BaselinerSplit
+    from xmap.utils.assist import baseliner_split_data_pipeline
+    sc = SparkContext(conf=SparkConf())
+    src = sc.parallelize([("u%d" % u, [("s%d_%dS:" % (u, k), 4.0, k) for k in range(3)]) for u in range(0, 60)])
+    tgt = sc.parallelize([("u%d" % u, [("t%d_%dT:" % (u, k), 3.0, k) for k in range(4)]) for u in range(30, 90)])
+    tool = BaselinerSplit(1, 0.2, 0.8, 666666)
+    train, test = baseliner_split_data_pipeline(sc, tool, src, tgt)
+    train, test = train.collect(), dict(test.collect())
+    overlap = {"u%d" % u for u in range(30, 60)}
+    assert set(test) <= overlap and 0 < len(test) < len(overlap)
+    by_user = {}
+    for u, prof in train:
+        by_user.setdefault(u, []).extend(prof)
+    for u in overlap:
+        items = {i for i, _, _ in by_user[u]}
+        if u in test:       # num_left target ratings stay, the rest are hidden and form the test profile
+            hidden = {i for i, _, _ in test[u]}
+            assert len(hidden) == 3 and not (hidden & items)
+            assert sum("T:" in i for i in items) == 1 and sum("S:" in i for i in items) == 3
+        else:
+            assert len(items) == 7
+    assert all(len(by_user["u%d" % u]) == 3 for u in range(0, 30)) and all(len(by_user["u%d" % u]) == 4 for u in range(60, 90))
+
+
+@pytest.mark.parametrize("method", ["cosine_item", "adjust_cosine_item"])
+def test_recommender_stages_match_reference(gold, method):
+    from xmap.core.recommenderSim import RecommenderSim
+    from xmap.core.recommenderPrivacy import RecommenderPrivacy
+    from xmap.core.recommenderPrediction import RecommenderPrediction
+    from xmap.utils.assist import (recommender_calculate_sim_pipeline, recommender_privacy_pipeline,
+                                   recommender_prediction_pipeline)
+    sc = SparkContext(conf=SparkConf())
+    rows = [(u, i, r, dt(t)) for (u, i, r, t) in gold["downstream_input"]["rows"]]
+    test = [(u, [(i, r, dt(t)) for (i, r, t) in prof]) for u, prof in gold["downstream_input"]["test"]]
+    g = gold[method]
+    sim_tool = RecommenderSim(method, 50)
+    sim_tool.calculate_sim = sim_tool.calculate_sim_host     # the per-pair Python statement (the product runs it on the GPU)
+    res = recommender_calculate_sim_pipeline(sc, sim_tool, sc.parallelize(rows))
+    user_based, item_based, ubd, ibd, uinfo, iinfo, sim = res
+    assert sorted((k, [float(x) for x in v]) for k, v in iinfo.value.items()) == [(k, v) for k, v in g["item_info"]]
+    assert sorted((k, [float(x) for x in v]) for k, v in uinfo.value.items()) == [(k, v) for k, v in g["user_info"]]
+    pairs = sim.collect()
+    got = [([a, b], [float(v[0]), float(v[1])]) for (a, b), v in pairs]
+    assert len(got) == len(g["sim"])
+    for (ka, va), (kb, vb) in zip(got, g["sim"]):
+        assert ka == kb
+        assert np.array_equal(np.array(va), np.array(vb), equal_nan=True)
+    for name, private in (("nonprivate", False), ("private", True)):
+        exp = g[name]
+        np.random.seed(exp["seed"])
+        sel = recommender_privacy_pipeline(RecommenderPrivacy(10, 0.6, 0.1), sc.parallelize(pairs), private).collect()
+        sel = [(i, [(n, float(v)) for n, v in lst]) for i, lst in sel]
+        assert [(i, [[n, v] for n, v in lst]) for i, lst in sel] == [(i, lst) for i, lst in exp["selected"]]
+        pred_tool = RecommenderPrediction(0.03, method)
+        test_rdd = sc.parallelize(test)
+        pred = pred_tool.item_based_recommendation(test_rdd, ibd, sc.broadcast(dict(sel)), iinfo).collect()
+        assert [(u, [list(p) for p in lst]) for u, lst in pred] == [(u, lst) for u, lst in exp["predicted"]]
+        mae = recommender_prediction_pipeline(pred_tool, sim_tool, test_rdd, sc.broadcast(dict(sel)), ubd, ibd, uinfo, iinfo)
+        assert mae == exp["mae"]

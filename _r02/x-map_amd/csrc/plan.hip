@@ -64,7 +64,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const unsigned long l
 // sorts (keys, vals) ascending by the low `bits` bits of the key, stable; result in (keys, vals); tmp buffers of n
 int radix_sort_pairs(hipStream_t st, unsigned long long *keys, int *vals, unsigned long long *keys_tmp, int *vals_tmp,
                      long long n, int bits) {
-    XM_SCOPE(st);
     if (n <= 1) return XMAP_OK;
     const int n_blocks = (int)((n + RS_TILE - 1) / RS_TILE);
     int *hist = nullptr;
@@ -162,14 +161,11 @@ __global__ __launch_bounds__(256) void k_end_home(int n_nb, int k, const int *nb
     else if (idx - 1 < kcnt[(size_t)x * 2 + 1]) e = kcol[((size_t)x * 2 + 1) * k + (idx - 1)];
     if (e >= 0) atomicMin(&home[e], x);
 }
-__global__ __launch_bounds__(256) void k_home_keys(int nU, const int *uitem, const int *home, int n_items, int item_bits,
-                                                   unsigned long long *keys) {
+__global__ __launch_bounds__(256) void k_home_keys(int nU, const int *uitem, const int *home, unsigned long long *keys) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nU) return;
     const int e = uitem[r];
-    int h = home[e];
-    if (h > n_items) h = n_items;            // home = item of the column; ends of no column (0x7f7f7f7f): after every column
-    keys[r] = ((unsigned long long)(unsigned)h << item_bits) | (unsigned)e;
+    keys[r] = ((unsigned long long)(unsigned)home[e] << 21) | (unsigned)e;      // home = 0x7fffffff for ends of no column: last
 }
 __global__ __launch_bounds__(256) void k_inverse(int nU, const int *uitem, int *urank) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,7 +179,6 @@ using namespace xmap;
 extern "C" {
 
 int xmap_nb_index(void *stream, int32_t n_items, const uint8_t *cls, int32_t *nb_list, int32_t *nb_id, int64_t *h_n_nb) {
-    XM_SCOPE(stream);
     XM_ARG(cls && nb_list && nb_id && h_n_nb);
     *h_n_nb = 0;
     if (n_items == 0) return XMAP_OK;
@@ -207,7 +202,6 @@ int xmap_nb_index(void *stream, int32_t n_items, const uint8_t *cls, int32_t *nb
 int xmap_path_plan(void *stream, int32_t n_items, const int64_t *paths, int32_t start_lo, int32_t start_hi, int64_t chunk,
                    int64_t chunk_div, int64_t max_rows, int64_t cap_units, int32_t *unit_start, int32_t *unit_c, int32_t *unit_G, int32_t *unit_row,
                    int32_t *heavy_unit0, int64_t *h_out /*[5]: units, heavy starts, rows, paths, chunk*/) {
-    XM_SCOPE(stream);
     XM_ARG(paths && h_out && (chunk > 0 || chunk_div > 0) && cap_units >= 0);
     for (int i = 0; i < 5; i++) h_out[i] = 0;
     h_out[4] = chunk;
@@ -279,8 +273,7 @@ int xmap_path_plan(void *stream, int32_t n_items, const int64_t *paths, int32_t 
 
 int xmap_end_order(void *stream, int32_t n_items, int top_k, int32_t n_nb, const int32_t *nb_list, const int32_t *kcnt,
                    const int32_t *kcol, int32_t n_ends, int32_t *urank, int32_t *uitem) {
-    XM_SCOPE(stream);
-    XM_ARG(urank && uitem && n_ends >= 0 && n_items >= 0);
+    XM_ARG(urank && uitem && n_ends >= 0 && n_items < (1 << 21));
     if (n_ends == 0 || n_nb == 0) return XMAP_OK;
     XM_ARG(nb_list && kcnt && kcol);
     hipStream_t st = (hipStream_t)stream;
@@ -294,14 +287,9 @@ int xmap_end_order(void *stream, int32_t n_items, int top_k, int32_t n_nb, const
     k_end_home<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n_nb, top_k, nb_list, kcnt, kcol, home);
     XM_LAUNCH_CHECK();
     const dim3 grid((unsigned)((n_ends + 255) / 256)), block(256);
-    // sort key = home column << bits(n_items) | item: as many bits as the catalogue and the column count need (a fixed
-    // 21-bit item field had refused catalogues of 2^21 items and sorted 52 bits whatever the size)
-    int item_bits = 1, home_bits = 1;
-    while ((1ll << item_bits) < (long long)n_items) item_bits++;
-    while ((1ll << home_bits) < (long long)n_items + 1) home_bits++;
-    k_home_keys<<<grid, block, 0, st>>>(n_ends, uitem, home, n_items, item_bits, keys);
+    k_home_keys<<<grid, block, 0, st>>>(n_ends, uitem, home, keys);
     XM_LAUNCH_CHECK();
-    int rc = radix_sort_pairs(st, keys, uitem, keys + n_ends, vt, n_ends, item_bits + home_bits);
+    int rc = radix_sort_pairs(st, keys, uitem, keys + n_ends, vt, n_ends, 52);
     if (rc) return rc;
     k_inverse<<<grid, block, 0, st>>>(n_ends, uitem, urank);
     XM_LAUNCH_CHECK();

@@ -26,11 +26,7 @@
 //   k_scatter       : mirror the half-COO into the CSR rows (atomic cursors)
 // Sums are exact (double-double, or integer-exact in cosine mode), so neither the order of raters nor the
 // chunking changes a bit of the result.
-#include <type_traits>
-
 #include "common.h"
-#include "item_stats.h"
-#include "tilesort.h"
 
 namespace xmap {
 
@@ -97,10 +93,6 @@ __global__ __launch_bounds__(256) void k_mark_heavy(int I, const long long *iptr
 }
 
 struct RaterRec { int e0; int pos_ge; float rating; int user; };   // 16 B: one rater of an item
-// fp64 ratings (the RecommenderSim variant, LS: AlterEgo ratings are np.float64 means, core/generator.py:123-138 ->
-// core/recommenderSim.py:64-133): 16-byte profile entries and rater records of their own
-struct UbWide { int item_ge; int pad; double rating; };      // 16 B: one entry of a sorted profile, fp64 rating
-struct RaterRecWide { int e0; int pos_ge; double rating; };  // 16 B: one rater of an item, fp64 rating (no user: its average is 0)
 
 // private copy of every profile sorted heaviest first, (index | flag, rating) interleaved.  One wave per 4 users:
 // profiles of up to 16 ratings (90 % at BASELINE configs[1]) are sorted four at a time, one per 16-lane group, by a
@@ -325,8 +317,6 @@ struct TriArgs {
     int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
     double *coo_aux;                // optional 6th column (RecommenderSim: local sensitivity)
     int *rowcnt;
-    int *mircnt;                    // NULL: the mirrored entries of a row are counted in rowcnt as well; else separately
-                                    // (round-3 mirror: row = [own | mirrored], xmap_sim3_mirror)
     int *rowcnt_h;                  // [HEAVY_SHARDS][HMAX] replicas for the heavy items
     unsigned long long *counters;   // [2] table overflow, [3] COO overflow
     int raw;                        // user-sharded input: emit every pair's partial sums (dot as (value, error) in coo_sim /
@@ -391,7 +381,7 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begi
             const int hj = A.hid[j];
             if (j == i) {}   // a row paired with itself (RecommenderSim) has no mirror entry
             else if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
-            else atomicAdd(&(A.mircnt ? A.mircnt : A.rowcnt)[j], 1);
+            else atomicAdd(&A.rowcnt[j], 1);
         }
         base += __popcll(km);
     }
@@ -451,7 +441,6 @@ template <int METHOD, int LOG_SLOTS, int NW, bool LS>
 __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     constexpr int SLOTS_ = 1 << LOG_SLOTS;
     constexpr bool ADJ = METHOD == XMAP_ADJUST_COSINE;
-    using RT = typename std::conditional<LS, double, float>::type;      // rating type of the profile copy and the rater records
     __shared__ uint32_t key[SLOTS_];
     __shared__ unsigned long long cm[SLOTS_];     // n_ij (low 32) | mutuality (high 32)
     __shared__ double dot[SLOTS_];
@@ -496,17 +485,12 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
         for (int base = p0 + 64 * w; base < p1; base += 64 * NW) {
             const int p = base + lane;
             int e0 = 0, pw = 0;
-            RT r = (RT)0;
+            float r = 0.f;
             double au = 0.0;
             if (p < p1) {
-                if (LS) {       // fp64 ratings, user average 0 by construction
-                    const RaterRecWide rr = ((const RaterRecWide *)A.rc)[p];
-                    e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
-                } else {
-                    const RaterRec rr = A.rc[p];
-                    e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
-                    if (ADJ) au = A.u_avg[rr.user];
-                }
+                const RaterRec rr = A.rc[p];
+                e0 = rr.e0; pw = rr.pos_ge; r = rr.rating;
+                if (ADJ) au = A.u_avg[rr.user];
             }
             const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
 #ifdef A_TRACE
@@ -516,25 +500,21 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             // processed (a step waits for the longest of its 8 prefixes; every load inside the loop below is one more
             // dependent round trip while the unit holds its table: 16 entries cover nearly all prefixes)
             int nb0 = 0, nb1 = 0, npw = 0, njw = 0, njw2 = 0;
-            RT nrj = (RT)0, nrj2 = (RT)0;
-            auto entry = [&](int e, int &jw_, RT &rj_) {        // one entry of a sorted profile
-                if (LS) { const UbWide v = ((const UbWide *)A.ub)[e]; jw_ = v.item_ge; rj_ = (RT)v.rating; }
-                else { const int2 v = A.ub[e]; jw_ = v.x; rj_ = (RT)__int_as_float(v.y); }
-            };
+            float nrj = 0.f, nrj2 = 0.f;
             auto prefetch = [&](int t) {
                 nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
                 nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
-                if (nb0 + sub < nb1) entry(nb0 + sub, njw, nrj);
-                if (nb0 + GRP + sub < nb1) entry(nb0 + GRP + sub, njw2, nrj2);
+                if (nb0 + sub < nb1) { const int2 v = A.ub[nb0 + sub]; njw = v.x; nrj = __int_as_float(v.y); }
+                if (nb0 + GRP + sub < nb1) { const int2 v = A.ub[nb0 + GRP + sub]; njw2 = v.x; nrj2 = __int_as_float(v.y); }
             };
             prefetch(g);
             for (int t0 = 0; t0 < nr; t0 += NGRP) {
                 const int t = t0 + g;                    // this lane group's rater
                 const int b0 = nb0, b1 = nb1, pwt = npw;
                 int jw = njw;
-                RT rj = nrj;
+                float rj = nrj;
                 const int jw2 = njw2;
-                const RT rj2 = nrj2;
+                const float rj2 = nrj2;
                 if (t0 + NGRP < nr) prefetch(t + NGRP);
                 const double ri = (double)__shfl(r, t, 64);
                 const double a = ADJ ? __shfl(au, t, 64) : 0.0;
@@ -543,7 +523,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
                 for (int e = b0 + sub; __ballot(e < b1); e += GRP, it++) {
                     bool act = e < b1;
                     if (it == 1) { jw = jw2; rj = rj2; }
-                    else if (act && it >= 2) entry(e, jw, rj);
+                    else if (act && it >= 2) { const int2 v = A.ub[e]; jw = v.x; rj = __int_as_float(v.y); }
                     const int j = jw & 0x7fffffff;
                     if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
                     body(act, j, jw, rj, ri, a, gei);
@@ -553,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     };
 
     // pass 1: accumulate n_ij, mutuality and the dot product per partner
-    walk([&](bool act, int j, int jw, RT rj, double ri, double a, unsigned gei) {
+    walk([&](bool act, int j, int jw, float rj, double ri, double a, unsigned gei) {
         uint32_t h = 0;
         if (act) {
             h = ((uint32_t)j * 0x9E3779B1u) >> (32 - LOG_SLOTS);
@@ -631,7 +611,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
         }
         if (NW > 1) __syncthreads();
         // pass 2: leave-one-out variants (recommenderSim.py:98-116)
-        walk([&](bool act, int j, int jw, RT rj, double ri, double a, unsigned gei) {
+        walk([&](bool act, int j, int jw, float rj, double ri, double a, unsigned gei) {
             if (!act) return;
             uint32_t h = ((uint32_t)j * 0x9E3779B1u) >> (32 - LOG_SLOTS);
             while (key[h] != (uint32_t)j) h = (h + 1) & (SLOTS_ - 1);
@@ -1013,525 +993,6 @@ __global__ __launch_bounds__(256) void k_merge_partials(long long n, const long 
     atomicAdd(&rowcnt[j], 1);
 }
 
-
-// =================================================================================================================
-// Round 3: ONE transposition per pass.  Round 2 built the CSC (count + scan + fill with returning cursor atomics), read
-// it for the item statistics, and transposed a second time in k_rater_records; the mirror of the kept pairs was a third
-// scatter with cursor atomics.  Now: item counts and rating sums in one pass over the CSR (k_count3) -> profiles sorted
-// by weight, each entry leaving as a 16-byte sort record keyed by its item (k_sort_profiles3) -> the records moved to
-// item order by the two-level tile sort (tilesort.h), where the rater records get their final form and W+ is summed ->
-// item statistics from the rater records (k_item_stats3).  The CSC arrays are not built at all.
-// =================================================================================================================
-constexpr int CNT_SLOTS = 4096;
-constexpr int CNT_CHUNK = 8192;
-__device__ __forceinline__ int cnt_slot(int it) { return (int)(mix32((uint32_t)it) & (CNT_SLOTS - 1)); }
-
-// raters per item.  Popular items (8e4 raters at BASELINE configs[1]) would serialise that many atomics on one word:
-// every workgroup counts its entries in a direct-mapped LDS cache of (item, count) slots first and goes to memory once
-// per occupied slot; entries whose slot is taken by another item use the global word directly.
-__global__ __launch_bounds__(256) void k_count3(long long nnz, const int *uitem, int *cnt) {
-    __shared__ int tag[CNT_SLOTS], loc[CNT_SLOTS];
-    for (int t = threadIdx.x; t < CNT_SLOTS; t += 256) { tag[t] = -1; loc[t] = 0; }
-    __syncthreads();
-    const long long e0 = (long long)blockIdx.x * CNT_CHUNK;
-    for (int q = threadIdx.x; q < CNT_CHUNK; q += 256) {
-        const long long e = e0 + q;
-        if (e >= nnz) break;
-        const int it = uitem[e];
-        const int sl = cnt_slot(it);
-        const int old = atomicCAS(&tag[sl], -1, it);
-        if (old == -1 || old == it) atomicAdd(&loc[sl], 1); else atomicAdd(&cnt[it], 1);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < CNT_SLOTS; t += 256)
-        if (loc[t]) atomicAdd(&cnt[tag[t]], loc[t]);
-}
-
-// Sort records (tilesort.h: key = low 32 bits of word 0).  Narrow (float ratings): {item, pos | flag << 31, rating bits,
-// user}.  Wide (fp64 ratings -- RecommenderSim over AlterEgo means, core/recommenderSim.py:64-133 takes np.float64): {item,
-// pos | flag, rating (8 B), user, -}.
-
-// The mutuality flag (rating >= item average) needs the item averages, which come out of the rater records this sort
-// feeds: the profile copy and the sort records leave without it, k_item_stats3 sets it in the rater records and
-// k_ub_flags in the profile copy.
-template <bool WIDE>
-__device__ __forceinline__ void sort_entry3(const int *uitem, const float *ur32, const double *ur64, const int *cnt,
-                                            long long e, unsigned long long &key, int &px, long long &py) {
-    const int it = uitem[e];
-    key = wkey(cnt[it], it);
-    px = it;
-    py = WIDE ? __double_as_longlong(ur64[e]) : (long long)(unsigned)__float_as_int(ur32[e]);
-}
-
-template <bool WIDE>
-__device__ __forceinline__ void bitonic_desc3(int width, int pos, unsigned long long &key, int &px, long long &py) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-        if (k2 <= width)
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            const unsigned long long ok = __shfl_xor(key, j, 64);
-            const int ox = __shfl_xor(px, j, 64);
-            long long oy;
-            if (WIDE) oy = __shfl_xor(py, j, 64); else oy = (long long)(unsigned)__shfl_xor((int)py, j, 64);
-            const bool desc = (pos & k2) == 0;
-            const bool lower = (pos & j) == 0;
-            const bool take_other = (lower == desc) ? (ok > key) : (ok < key);
-            if (take_other) { key = ok; px = ox; py = oy; }
-        }
-    }
-}
-
-// one sorted entry at position `rank` of user u's profile [a, a + d): the profile copy the pair kernel walks and the sort
-// record that becomes the item's rater record
-template <bool WIDE>
-__device__ __forceinline__ void emit_entry3(long long a, int d, int rank, long long u, int px, long long py, void *ub,
-                                            unsigned long long *srec) {
-    const long long e = a + rank;
-    const unsigned pos_ge = (unsigned)(d >= 2 ? rank : 0) | ((unsigned)px & 0x80000000u);   // users with >= 2 ratings only (:184-185)
-    const unsigned long long w0 = (unsigned long long)((unsigned)px & 0x7fffffffu) | ((unsigned long long)pos_ge << 32);
-    if (WIDE) {
-        UbWide v; v.item_ge = px; v.pad = 0; v.rating = __longlong_as_double(py);
-        ((UbWide *)ub)[e] = v;
-        srec[e * 3 + 0] = w0; srec[e * 3 + 1] = (unsigned long long)py; srec[e * 3 + 2] = (unsigned long long)(unsigned)u;
-    } else {
-        ((int2 *)ub)[e] = make_int2(px, (int)py);
-        ulonglong2 w; w.x = w0; w.y = (unsigned long long)(unsigned)py | ((unsigned long long)(unsigned)u << 32);
-        *(ulonglong2 *)(srec + e * 2) = w;
-    }
-}
-
-// k_sort_profiles with the item's rater count as the only gather and the sort records as second output
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_sort_profiles3(long long U, const long long *uptr, const int *uitem, const float *ur32,
-                                                        const double *ur64, const int *cnt, unsigned long long *ub_key,
-                                                        void *ub, unsigned long long *srec) {
-    __shared__ unsigned long long lkeys[4][SORT_LDS];
-    const long long u0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (u0 >= U) return;
-    const int lane = lane_id();
-    const int g = lane >> 4, gl = lane & 15;
-    {   // the short profiles, one per 16-lane group
-        const long long u = u0 + g;
-        long long a = 0;
-        int d = 0;
-        if (u < U) { a = uptr[u]; d = (int)(uptr[u + 1] - a); }
-        const bool small = d <= 16;
-        int wmax = small ? d : 0;
-#pragma unroll
-        for (int m = 32; m >= 16; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m, 64));
-        wmax = rl32(wmax, 0);
-        if (wmax > 0) {
-            unsigned long long key = 0ull;   // pads sort last
-            int px = 0;
-            long long py = 0;
-            if (small && gl < d) sort_entry3<WIDE>(uitem, ur32, ur64, cnt, a + gl, key, px, py);
-            bitonic_desc3<WIDE>(pow2_at_least(wmax), gl, key, px, py);
-            if (small && gl < d) emit_entry3<WIDE>(a, d, gl, u, px, py, ub, srec);
-        }
-    }
-    for (int q = 0; q < 4; q++) {   // the longer ones on the whole wave
-        const long long u = u0 + q;
-        if (u >= U) break;
-        const long long a = uptr[u];
-        const int d = (int)(uptr[u + 1] - a);
-        if (d <= 16) continue;
-        if (d <= 64) {
-            unsigned long long key = 0ull;
-            int px = 0;
-            long long py = 0;
-            if (lane < d) sort_entry3<WIDE>(uitem, ur32, ur64, cnt, a + lane, key, px, py);
-            bitonic_desc3<WIDE>(pow2_at_least(d), lane, key, px, py);
-            if (lane < d) emit_entry3<WIDE>(a, d, lane, u, px, py, ub, srec);
-            continue;
-        }
-        unsigned long long *keys = d <= SORT_LDS ? lkeys[threadIdx.x >> 6] : ub_key + a;
-        for (int p = lane; p < d; p += 64) {
-            unsigned long long key;
-            int px;
-            long long py;
-            sort_entry3<WIDE>(uitem, ur32, ur64, cnt, a + p, key, px, py);
-            keys[p] = key;
-        }
-        __threadfence_block();
-        for (int p = lane; p < d; p += 64) {
-            unsigned long long key;
-            int px;
-            long long py;
-            sort_entry3<WIDE>(uitem, ur32, ur64, cnt, a + p, key, px, py);
-            int rank = 0;   // equal keys (an item twice in one profile: AlterEgo rows) keep their order
-            for (int o = 0; o < d; o++) rank += (keys[o] > key) || (keys[o] == key && o < p);
-            emit_entry3<WIDE>(a, d, rank, u, px, py, ub, srec);
-        }
-    }
-}
-
-// final form of a rater record from its sort record: e0 = first entry of the user's profile
-template <bool WIDE>
-__device__ __forceinline__ ulonglong2 rater_record(const unsigned long long *w, const long long *uptr) {
-    const unsigned user = WIDE ? (unsigned)w[2] : (unsigned)(w[1] >> 32);
-    const unsigned e0 = (unsigned)uptr[user];
-    ulonglong2 o;
-    o.x = (unsigned long long)e0 | (w[0] & 0xffffffff00000000ull);     // {e0, pos | flag}
-    o.y = w[1];                                                        // narrow: {rating bits, user}; wide: the fp64 rating
-    return o;
-}
-
-// level C of the rater records: one workgroup per tile.  The small keys' records are ranked by LDS cursors, converted,
-// laid out in final order in LDS and written as whole rows; W+ of every small key (sum of its raters' prefix lengths = the
-// contributions of its row) is summed on the way.
-template <bool WIDE>
-__global__ __launch_bounds__(ts::CT) void k_rc_tiles(ts::Geo G, const unsigned long long *bufB, const long long *uptr,
-                                                     ulonglong2 *rc, unsigned long long *Wp) {
-    constexpr int RW = WIDE ? 3 : 2;
-    __shared__ unsigned cur[ts::NK_MAX], kst[ts::NK_MAX];
-    __shared__ unsigned long long wsum[ts::NK_MAX];
-    __shared__ ulonglong2 lrec[ts::CAP];
-    const ts::TileHead h = ts::tile_head(G, blockIdx.x);
-    if (h.nk <= 0) return;
-    for (int x = threadIdx.x; x < h.nk; x += ts::CT) {
-        cur[x] = 0u; wsum[x] = 0ull;
-        kst[x] = (unsigned)(G.ptr[h.k0 + x] - h.pos0);
-    }
-    __syncthreads();
-    const bool in_lds = h.n <= ts::CAP;
-    constexpr int UN = 4;
-    for (int base = 0; base < h.n; base += ts::CT * UN) {
-        unsigned long long w[UN][RW];
-        bool on[UN];
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            const int idx = base + t * ts::CT + threadIdx.x;
-            on[t] = idx < h.n;
-            const size_t o = (size_t)(h.pos0 + (on[t] ? idx : 0)) * RW;
-#pragma unroll
-            for (int x = 0; x < RW; x++) w[t][x] = bufB[o + x];
-        }
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            if (!on[t]) continue;
-            const int kk = (int)((unsigned)w[t][0]) - h.k0;
-            const unsigned q = kst[kk] + atomicAdd(&cur[kk], 1u);
-            atomicAdd(&wsum[kk], (unsigned long long)((unsigned)(w[t][0] >> 32) & 0x7fffffffu));
-            const ulonglong2 o = rater_record<WIDE>(w[t], uptr);
-            if (in_lds) lrec[q] = o; else rc[h.pos0 + q] = o;
-        }
-    }
-    __syncthreads();
-    if (in_lds)
-        for (int q = threadIdx.x; q < h.n; q += ts::CT) rc[h.pos0 + q] = lrec[q];
-    for (int x = threadIdx.x; x < h.nk; x += ts::CT) Wp[h.k0 + x] = wsum[x];
-}
-
-// the slices of the large keys: their records sit in their final range already (any order inside a key is a result)
-template <bool WIDE>
-__global__ __launch_bounds__(ts::LT) void k_rc_large(ts::Geo G, const unsigned long long *bufB, const long long *uptr,
-                                                     ulonglong2 *rc, unsigned long long *Wp) {
-    constexpr int RW = WIDE ? 3 : 2;
-    if (blockIdx.x >= G.counters[1]) return;
-    const int2 sl = G.slist[blockIdx.x];
-    const long long lo = G.ptr[sl.x] + (long long)sl.y * ts::SL;
-    const long long hi = min(G.ptr[sl.x + 1], lo + ts::SL);
-    unsigned long long sum = 0ull;
-    for (long long p = lo + threadIdx.x; p < hi; p += ts::LT) {
-        unsigned long long w[RW];
-#pragma unroll
-        for (int x = 0; x < RW; x++) w[x] = bufB[(size_t)p * RW + x];
-        sum += (unsigned long long)((unsigned)(w[0] >> 32) & 0x7fffffffu);
-        rc[p] = rater_record<WIDE>(w, uptr);
-    }
-    sum = (unsigned long long)wave_sum_ll((long long)sum);
-    if (lane_id() == 0 && sum) atomicAdd(&Wp[sl.x], sum);
-}
-
-// item statistics from the rater records (item_stats.h); the records' mutuality flags are set once the average is known
-struct RcSrc {
-    RaterRec *rc; const double *u_avg;
-    static constexpr bool has_flags = true;
-    __device__ __forceinline__ void load(long long p, double &r, int &u) const { const RaterRec x = rc[p]; r = (double)x.rating; u = x.user; }
-    __device__ __forceinline__ double uavg(int u) const { return u_avg[u]; }
-    __device__ __forceinline__ void set_flag(long long p, bool ge) const { if (ge) rc[p].pos_ge |= (int)0x80000000u; }
-};
-struct RcWideSrc {
-    const RaterRecWide *rc;
-    static constexpr bool has_flags = false;       // RecommenderSim has no mutuality
-    __device__ __forceinline__ void load(long long p, double &r, int &u) const { r = rc[p].rating; u = 0; }
-    __device__ __forceinline__ double uavg(int) const { return 0.0; }
-    __device__ __forceinline__ void set_flag(long long, bool) const {}
-};
-
-// Items with more than STAT_BIG raters (up to 1e5 at BASELINE configs[1]: one wave walking them was the kernel's tail) are
-// cut into chunks of STAT_CHK raters: k_item_stats3 lists them, k_item_chunks sums every chunk on a wave of its own,
-// k_item_big adds an item's chunk sums up in chunk order (the adjusted norm exactly) and finishes it, k_item_big_flags sets
-// the flags of its rater records.
-constexpr int STAT_BIG = 4096;
-constexpr int STAT_CHK = 2048;
-struct BigList {
-    unsigned *counters;       // [0] chunks listed, [1] big items listed
-    int2 *chunks;             // (item, chunk)
-    int4 *items;              // (item, first chunk, chunks, -)
-    double *part;             // [chunk][5]
-    long long chunk_cap, item_cap;
-};
-
-template <typename Src>
-__global__ __launch_bounds__(256) void k_item_stats3(int I, const long long *iptr, const Src src, double *info, double *norms,
-                                                     BigList B) {
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (i0 >= I) return;
-    const int lane = lane_id();
-    {
-        const int i = i0 + (lane >> 4);
-        const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
-        item_stats_group<16>(on, i, lane & 15, I, iptr, src, info, norms, nullptr, nullptr);
-    }
-    for (int t = 0; t < 4; t++) {
-        const int i = i0 + t;
-        if (i >= I) break;
-        const long long n = iptr[i + 1] - iptr[i];
-        if (n <= 64) continue;
-        if (n > STAT_BIG) {
-            if (lane == 0) {
-                const int nch = (int)((n + STAT_CHK - 1) / STAT_CHK);
-                const unsigned base = atomicAdd(&B.counters[0], (unsigned)nch);
-                const unsigned slot = atomicAdd(&B.counters[1], 1u);
-                if ((long long)slot < B.item_cap) B.items[slot] = make_int4(i, (int)base, nch, 0);
-                for (int x = 0; x < nch; x++)
-                    if ((long long)base + x < B.chunk_cap) B.chunks[base + x] = make_int2(i, x);
-            }
-            continue;
-        }
-        item_stats_group<64>(true, i, lane, I, iptr, src, info, norms, nullptr, nullptr);
-    }
-}
-
-// one wave per listed chunk: the item's partial sums over raters [c STAT_CHK, (c + 1) STAT_CHK)
-template <typename Src>
-__global__ __launch_bounds__(256) void k_item_chunks(const long long *iptr, const Src src, BigList B) {
-    const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= B.counters[0]) return;
-    const int2 d = B.chunks[c];
-    const int lane = lane_id();
-    const long long p0 = iptr[d.x] + (long long)d.y * STAT_CHK;
-    const long long p1 = min(iptr[d.x + 1], p0 + STAT_CHK);
-    constexpr int UN = 8;
-    double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
-    for (long long p = p0 + lane; p < p1; p += 64 * UN) {
-        double rr[UN], av[UN];
-        int uu[UN];
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            rr[t] = 0.0; uu[t] = -1;
-            if (p + 64 * t < p1) src.load(p + 64 * t, rr[t], uu[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < UN; t++) av[t] = uu[t] >= 0 ? src.uavg(uu[t]) : 0.0;
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            if (uu[t] < 0) continue;
-            const double dlt = rr[t] - av[t];
-            s += rr[t];
-            q += rr[t] * rr[t];
-            dd_add(a2, a2lo, dlt * dlt);
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double oh = __shfl_down(a2, m, 64), ol = __shfl_down(a2lo, m, 64);
-        dd_add(a2, a2lo, oh);
-        dd_add(a2, a2lo, ol);
-    }
-    if (lane == 0) {
-        double *o = B.part + (size_t)c * 5;
-        o[0] = s; o[1] = q; o[2] = a2; o[3] = a2lo; o[4] = (double)(p1 - p0);
-    }
-}
-
-__global__ __launch_bounds__(64) void k_item_big(int I, BigList B, double *info, double *norms) {
-    const unsigned b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B.counters[1]) return;
-    const int4 d = B.items[b];
-    double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0, n = 0.0;
-    for (int x = 0; x < d.z; x++) {
-        const double *o = B.part + (size_t)(d.y + x) * 5;
-        s += o[0]; q += o[1]; n += o[4];
-        dd_add(a2, a2lo, o[2]);
-        dd_add(a2, a2lo, o[3]);
-    }
-    const int i = d.x;
-    info[(size_t)i * 4 + 0] = (n > 0.0) ? 1.0 * s / n : 0.0;
-    info[(size_t)i * 4 + 1] = sqrt(q);
-    info[(size_t)i * 4 + 2] = sqrt(a2);
-    info[(size_t)i * 4 + 3] = 1.0 * n;
-    norms[i] = sqrt(q);
-    norms[(size_t)I + i] = sqrt(a2);
-}
-
-template <typename Src>
-__global__ __launch_bounds__(256) void k_item_big_flags(const long long *iptr, const Src src, BigList B, const double *info) {
-    const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= B.counters[0]) return;
-    const int2 d = B.chunks[c];
-    const double avg = info[(size_t)d.x * 4];
-    const long long p0 = iptr[d.x] + (long long)d.y * STAT_CHK;
-    const long long p1 = min(iptr[d.x + 1], p0 + STAT_CHK);
-    for (long long p = p0 + lane_id(); p < p1; p += 64) {
-        double r; int u;
-        src.load(p, r, u);
-        src.set_flag(p, r >= avg);
-    }
-}
-
-// the profile copy's flags: rating >= average of the entry's item
-__global__ __launch_bounds__(256) void k_ub_flags(long long nnz, int2 *ub, const double *info) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    const int2 v = ub[e];
-    if ((double)__int_as_float(v.y) >= info[(size_t)v.x * 4]) ub[e].x = (int)((unsigned)v.x | 0x80000000u);
-}
-
-// ---- the mirror (round 3): own half written in runs, mirrored half through the tile sort --------------------------------------
-// Row i of the CSR = [the pairs row i computed itself (own[i]) | the pairs computed in lighter rows (mir[i])].
-__global__ __launch_bounds__(256) void k_row_totals(int I, const int *own, const int *mir, int *tot) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < I) tot[i] = own[i] + mir[i];
-}
-
-// level-A loader of the mirror: the half COO (SoA, cut into shards that are filled from their start) as 24-byte records
-// keyed by the heavier item; its chunks are listed from the shard cursors (k_coo_chunks), so every slot of a chunk is a
-// record.  The same workgroup writes the OWN half of its chunk (extra): the records of one unit are contiguous in the
-// COO and share the lighter item i -- one cursor bump per run, coalesced writes, the chunk still in the caches.
-struct CooLoader {
-    const int *__restrict__ coo_i; const int *__restrict__ coo_j; const double *__restrict__ coo_sim;
-    const int *__restrict__ coo_mutu; const int *__restrict__ coo_nij;
-    const longlong2 *chunks; const unsigned *n_chunks;
-    const long long *row_ptr; int *fill; int *col; double *sim; int *mutu; int *nij;
-    static constexpr bool listed = true;
-    __device__ __forceinline__ bool chunk(long long, long long &i0, long long &i1) const {
-        if (blockIdx.x >= *n_chunks) return false;
-        const longlong2 c = chunks[blockIdx.x];
-        i0 = c.x; i1 = c.x + c.y;
-        return true;
-    }
-    __device__ __forceinline__ unsigned key(long long idx) const { return (unsigned)coo_j[idx]; }
-    __device__ __forceinline__ void get(long long idx, unsigned long long (&w)[3]) const {
-        w[0] = (unsigned long long)(unsigned)coo_j[idx] | ((unsigned long long)(unsigned)coo_i[idx] << 32);
-        w[1] = (unsigned long long)__double_as_longlong(coo_sim[idx]);
-        w[2] = (unsigned long long)(unsigned)coo_mutu[idx] | ((unsigned long long)(unsigned)coo_nij[idx] << 32);
-    }
-    __device__ __forceinline__ void extra(long long i0, long long i1) const {
-        const int lane = lane_id();
-        for (long long g = i0 + (long long)(threadIdx.x >> 6) * 64; g < i1; g += ts::BT) {
-            const long long r = g + lane;
-            const bool valid = r < i1;
-            int i = 0, j = 0, m = 0, nn = 0;
-            double s = 0.0;
-            if (valid) { i = coo_i[r]; j = coo_j[r]; s = coo_sim[r]; m = coo_mutu[r]; nn = coo_nij[r]; }
-            const int iu = valid ? i : -1 - lane;       // inactive lanes: unique fake rows
-            const int prev = __shfl_up(iu, 1, 64);
-            const bool leader = (lane == 0) || (prev != iu);
-            const unsigned long long lm = __ballot(leader);
-            const unsigned long long below = lm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-            const int lead = 63 - __clzll((long long)below);
-            const unsigned long long above = (lane == 63) ? 0ull : (lm >> (lane + 1));
-            const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-            int base = 0;
-            if (leader && valid) base = atomicAdd(&fill[iu], next - lane);
-            base = __shfl(base, lead, 64);
-            if (valid) {
-                const long long a = row_ptr[iu] + base + (lane - lead);
-                col[a] = j; sim[a] = s; mutu[a] = m; nij[a] = nn;
-            }
-        }
-    }
-};
-
-// chunks of CH records of the COO's shards: shard s holds its records in slots [s shard_cap, s shard_cap + fill[s])
-// (cur == NULL: one range of n_fill records)
-__global__ __launch_bounds__(256) void k_coo_chunks(int n_shards, long long shard_cap, const unsigned long long *cur, long long n_fill,
-                                                    longlong2 *chunks, unsigned *n_chunks, long long cap) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_shards) return;
-    long long f = cur ? (long long)cur[s] : n_fill;
-    if (f > shard_cap) f = shard_cap;
-    const int nch = (int)((f + ts::CH - 1) / ts::CH);
-    if (nch == 0) return;
-    const unsigned base = atomicAdd(n_chunks, (unsigned)nch);
-    for (int x = 0; x < nch; x++)
-        if ((long long)base + x < cap) {
-            longlong2 c;
-            c.x = (long long)s * shard_cap + (long long)x * ts::CH;
-            c.y = min((long long)ts::CH, f - (long long)x * ts::CH);
-            chunks[base + x] = c;
-        }
-}
-
-// level C of the mirror: the small keys of a tile, laid out as CSR columns in LDS, leave as whole row segments
-__global__ __launch_bounds__(ts::CT) void k_mir_tiles(ts::Geo G, const unsigned long long *bufB, const long long *row_ptr,
-                                                      const int *own, int *col, double *sim, int *mutu, int *nij) {
-    __shared__ unsigned cur[ts::NK_MAX], kst[ts::NK_MAX];
-    __shared__ long long gsh[ts::NK_MAX];
-    __shared__ double lsim[ts::CAP];
-    __shared__ int lcol[ts::CAP], lmutu[ts::CAP], lnij[ts::CAP];
-    __shared__ unsigned short lkk[ts::CAP];
-    const ts::TileHead h = ts::tile_head(G, blockIdx.x);
-    if (h.nk <= 0 || h.n <= 0) return;
-    for (int x = threadIdx.x; x < h.nk; x += ts::CT) {
-        const int k = h.k0 + x;
-        cur[x] = 0u;
-        kst[x] = (unsigned)(G.ptr[k] - h.pos0);
-        gsh[x] = row_ptr[k] + own[k] - G.ptr[k];        // mirrored position -> CSR position of key k
-    }
-    __syncthreads();
-    const bool in_lds = h.n <= ts::CAP;
-    constexpr int UN = 4;
-    for (int base = 0; base < h.n; base += ts::CT * UN) {
-        unsigned long long w[UN][3];
-        bool on[UN];
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            const int idx = base + t * ts::CT + threadIdx.x;
-            on[t] = idx < h.n;
-            const size_t o = (size_t)(h.pos0 + (on[t] ? idx : 0)) * 3;
-            w[t][0] = bufB[o]; w[t][1] = bufB[o + 1]; w[t][2] = bufB[o + 2];
-        }
-#pragma unroll
-        for (int t = 0; t < UN; t++) {
-            if (!on[t]) continue;
-            const int kk = (int)((unsigned)w[t][0]) - h.k0;
-            const unsigned q = kst[kk] + atomicAdd(&cur[kk], 1u);
-            const int ci = (int)(w[t][0] >> 32), cm = (int)(unsigned)w[t][2], cn = (int)(w[t][2] >> 32);
-            const double cs = __longlong_as_double((long long)w[t][1]);
-            if (in_lds) { lcol[q] = ci; lsim[q] = cs; lmutu[q] = cm; lnij[q] = cn; lkk[q] = (unsigned short)kk; }
-            else { const long long P = h.pos0 + q + gsh[kk]; col[P] = ci; sim[P] = cs; mutu[P] = cm; nij[P] = cn; }
-        }
-    }
-    if (!in_lds) return;
-    __syncthreads();
-    for (int q = threadIdx.x; q < h.n; q += ts::CT) {
-        const long long P = h.pos0 + q + gsh[lkk[q]];
-        col[P] = lcol[q]; sim[P] = lsim[q]; mutu[P] = lmutu[q]; nij[P] = lnij[q];
-    }
-}
-
-__global__ __launch_bounds__(ts::LT) void k_mir_large(ts::Geo G, const unsigned long long *bufB, const long long *row_ptr,
-                                                      const int *own, int *col, double *sim, int *mutu, int *nij) {
-    if (blockIdx.x >= G.counters[1]) return;
-    const int2 sl = G.slist[blockIdx.x];
-    const int k = sl.x;
-    const long long lo = G.ptr[k] + (long long)sl.y * ts::SL;
-    const long long hi = min(G.ptr[k + 1], lo + ts::SL);
-    const long long sh = row_ptr[k] + own[k] - G.ptr[k];
-    for (long long p = lo + threadIdx.x; p < hi; p += ts::LT) {
-        const unsigned long long w0 = bufB[(size_t)p * 3], w1 = bufB[(size_t)p * 3 + 1], w2 = bufB[(size_t)p * 3 + 2];
-        const long long P = p + sh;
-        col[P] = (int)(w0 >> 32); sim[P] = __longlong_as_double((long long)w1);
-        mutu[P] = (int)(unsigned)w2; nij[P] = (int)(w2 >> 32);
-    }
-}
-
 }  // namespace xmap
 
 using namespace xmap;
@@ -1553,58 +1014,6 @@ static SideStreams *side_streams() {
     cur[dev] = p;
     return p;
 }
-
-
-// ---- tile sort: host side ---------------------------------------------------------------------------------------------
-namespace {
-// geometry for K keys and M records (tilesort.h): tile measure 2^ts_log, key weight KW, T = NA * NB tiles
-void ts_geometry(int K, long long M, ts::Geo &G) {
-    G.K = K; G.M = M;
-    G.ts_log = 11;
-    for (;;) {
-        const long long TS = 1ll << G.ts_log;
-        long long kw = M / (4 * (long long)(K > 0 ? K : 1));
-        const long long kw_min = TS / (ts::NK_MAX - 2) + 1;          // keys of a tile <= TS / KW + 1 <= NK_MAX
-        if (kw < kw_min) kw = kw_min;
-        if (kw < 4) kw = 4;
-        const long long tiles = ((M + (long long)K * kw) >> G.ts_log) + 1;
-        if (tiles <= (long long)ts::NA_MAX * ts::NB || G.ts_log >= 30) {
-            G.KW = (int)kw;
-            G.NA = (int)((tiles + ts::NB - 1) / ts::NB);
-            if (G.NA < 1) G.NA = 1;
-            if (G.NA > ts::NA_MAX) G.NA = ts::NA_MAX;
-            G.T = G.NA * ts::NB;
-            return;
-        }
-        G.ts_log++;
-    }
-}
-
-// tables of one sort (arena temporaries of the calling entry point) + plan and chunk kernels
-int ts_prepare(hipStream_t st, ts::Geo &G, const long long *ptr) {
-    G.ptr = ptr;
-    G.clist_cap = G.M / ts::CH + G.NA + 1;
-    G.slist_cap = G.M / ts::SL + (G.M >> G.ts_log) + 2;
-    XM_HIP(xm_malloc_async((void **)&G.tk, sizeof(unsigned) * (size_t)(G.K > 0 ? G.K : 1), st));
-    XM_HIP(xm_malloc_async((void **)&G.tile_key0, sizeof(int) * ((size_t)G.T + 1), st));
-    XM_HIP(xm_malloc_async((void **)&G.tile_pos0, sizeof(long long) * ((size_t)G.T + 1), st));
-    XM_HIP(xm_malloc_async((void **)&G.tile_large, sizeof(int) * (size_t)G.T, st));
-    // cursors and counters in one zeroed block: curA [NA], curB [2 T], counters [2 x 4 B]
-    unsigned long long *z = nullptr;
-    const size_t nz = (size_t)G.NA + 2 * (size_t)G.T + 1;
-    XM_HIP(xm_malloc_async((void **)&z, sizeof(unsigned long long) * nz, st));
-    G.curA = z; G.curB = z + G.NA; G.counters = (unsigned *)(z + G.NA + 2 * (size_t)G.T);
-    XM_HIP(xm_malloc_async((void **)&G.clist, sizeof(int2) * (size_t)G.clist_cap, st));
-    XM_HIP(xm_malloc_async((void **)&G.slist, sizeof(int2) * (size_t)G.slist_cap, st));
-    XM_HIP(hipMemsetAsync(z, 0, sizeof(unsigned long long) * nz, st));
-    XM_HIP(hipMemsetAsync(G.tile_large, 0xff, sizeof(int) * (size_t)G.T, st));
-    ts::k_ts_plan<<<dim3((unsigned)((G.K + 255) / 256)), dim3(256), 0, st>>>(G);
-    XM_LAUNCH_CHECK();
-    ts::k_ts_chunks<<<dim3((unsigned)((G.NA + 255) / 256)), dim3(256), 0, st>>>(G);
-    XM_LAUNCH_CHECK();
-    return XMAP_OK;
-}
-}  // namespace
 
 extern "C" {
 #ifdef A_TRACE
@@ -1720,7 +1129,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     double *hp_hi, double *hp_lo, int32_t *hp_cnt, int32_t *hp_mut, int64_t coo_cap, int32_t *coo_i,
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, double *coo_ls /*or NULL*/,
                     int32_t *rowcnt, int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/,
-                    int64_t *d_counters /*[4]*/, int32_t *mircnt /*[I] or NULL*/) {
+                    int64_t *d_counters /*[4]*/) {
     XM_ARG(R && u_avg && norms && rc && ub);
     XM_ARG(Q && small && uq_item && uq_q && cls_ptr && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && rowcnt_h && d_shards && d_counters);
@@ -1739,7 +1148,6 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         XM_HIP(hipMemsetAsync(rowcnt_h, 0, sizeof(int32_t) * HEAVY_SHARDS * HMAX, st));
         XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry
         XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
-        if (mircnt) XM_HIP(hipMemsetAsync(mircnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
     }
     TriArgs A;
     memset(&A, 0, sizeof(A));
@@ -1753,7 +1161,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.coo_aux = coo_ls;
     A.raw = raw ? 1 : 0;
-    A.rowcnt = rowcnt; A.mircnt = mircnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
+    A.rowcnt = rowcnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     // phases 1 | 2 | 4 in one call: the heavy rows (chunk partials, then their merge) run on a side stream of their own,
     // next to the class launches of the light rows -- they share nothing but the atomic COO cursors and counters
     const bool heavy_aside = (phases & 7) == 7 && n_heavy_units > 0 && unit_hi > unit_lo;
@@ -1825,7 +1233,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         XM_LAUNCH_CHECK();
     }
     if ((phases & 16) && n_heavy > 0) {   // fold the heavy items' count replicas into rowcnt
-        k_fold_heavy<<<dim3((unsigned)((n_heavy + 255) / 256)), dim3(256), 0, st>>>(n_heavy, hlist, rowcnt_h, mircnt ? mircnt : rowcnt);
+        k_fold_heavy<<<dim3((unsigned)((n_heavy + 255) / 256)), dim3(256), 0, st>>>(n_heavy, hlist, rowcnt_h, rowcnt);
         XM_LAUNCH_CHECK();
     }
     return XMAP_OK;
@@ -1834,7 +1242,6 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
 int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_hi,
                             const double *coo_lo, const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][4]*/,
                             int64_t *h_count) {
-    XM_SCOPE(stream);
     XM_ARG(coo_i && coo_j && coo_hi && coo_lo && coo_mutu && coo_nij && rec && h_count && n_coo >= 0);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *cur = nullptr;
@@ -1853,7 +1260,6 @@ int xmap_sim2_pack_partials(void *stream, int64_t n_coo, const int32_t *coo_i, c
 
 int xmap_sim2_pack_pairs(void *stream, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
                          const int32_t *coo_mutu, const int32_t *coo_nij, int64_t *rec /*[n_coo][3]*/, int64_t *h_count) {
-    XM_SCOPE(stream);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rec && h_count && n_coo >= 0);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *cur = nullptr;
@@ -1882,7 +1288,6 @@ int xmap_sim2_unpack_pairs(void *stream, int64_t n, const int64_t *rec /*[n][3]*
 }
 
 int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t *rec_sorted, int32_t n_items, int32_t n_owners) {
-    XM_SCOPE(stream);
     XM_ARG(rec && rec_sorted && n >= 0 && n < 0x7fffffffLL && n_items > 0 && n_owners >= 0 && n_owners <= 65536);
     if (n == 0) return XMAP_OK;
     int bits_b = 1;
@@ -1909,7 +1314,6 @@ int xmap_sim2_sort_partials(void *stream, int64_t n, const int64_t *rec, int64_t
 int xmap_sim2_merge_partials(void *stream, int method, int cap, int32_t n_items, int64_t n, const int64_t *rec_sorted,
                              const double *norms, int32_t *coo_i, int32_t *coo_j, double *coo_sim, int32_t *coo_mutu,
                              int32_t *coo_nij, int32_t *rowcnt, int64_t *h_counts /*[2]: kept, evaluated (unordered pairs)*/) {
-    XM_SCOPE(stream);
     XM_ARG(rec_sorted && norms && coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && h_counts && n >= 0 && cap > 0);
     XM_ARG(method == XMAP_COSINE || method == XMAP_ADJUST_COSINE);
     hipStream_t st = (hipStream_t)stream;
@@ -1950,194 +1354,6 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
             n_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_ls, (const long long *)row_ptr, fill, col, sim, mutu, nij, ls);
         XM_LAUNCH_CHECK();
     }
-    return XMAP_OK;
-}
-
-/* Round-3 layout of stage A (one transposition per pass): see the declarations in include/xmap_hip.h. */
-int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, const double *rating64, int32_t ch_min, int32_t *cnt,
-                     double *u_avg, double *u_norm, int32_t *hist, int64_t *pre, int32_t *ctl, int32_t *hid, int32_t *hlist,
-                     uint64_t *ub_key, void *ub, void *srec, void *bufA, void *bufB, void *rc, uint64_t *Wp, double *info,
-                     double *norms, int32_t *h_ctl) {
-    XM_SCOPE(stream);
-    XM_ARG(R && item_ptr && (const int64_t *)item_ptr == R->item_ptr && cnt && u_avg && hist && pre && ctl && hid && hlist);
-    XM_ARG(ub_key && ub && srec && bufA && bufB && rc && Wp && info && norms && ch_min >= 64);
-    XM_ARG(R->nnz < 0x7fffffffLL && R->n_users < 0x7ffffff0LL && R->n_items >= 0);
-    XM_ARG(rating64 || u_norm);
-    hipStream_t st = (hipStream_t)stream;
-    const int I = R->n_items;
-    const long long nnz = R->nnz;
-    const bool wide = rating64 != nullptr;
-    const size_t In = (size_t)(I > 0 ? I : 1);
-    // raters per item -> item_ptr
-    XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * In, st));
-    if (nnz > 0) {
-        k_count3<<<dim3((unsigned)((nnz + CNT_CHUNK - 1) / CNT_CHUNK)), dim3(256), 0, st>>>(nnz, R->user_item, cnt);
-        XM_LAUNCH_CHECK();
-    }
-    int rcode = xmap_exclusive_scan_i32_to_i64(stream, cnt, item_ptr, I, nullptr);
-    if (rcode) return rcode;
-    if (!wide) {
-        rcode = xmap_user_stats(stream, R, u_avg, u_norm);
-        if (rcode) return rcode;
-    }
-    // rater-count histogram -> partner bounds, heavy set (as xmap_sim2_layout)
-    const int HB = (int)R->n_users + 2;
-    XM_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)HB, st));
-    XM_HIP(hipMemsetAsync(ctl, 0x7f, sizeof(int32_t), st));          // CH = 0x7f7f7f7f: "no heavy rows"
-    XM_HIP(hipMemsetAsync(ctl + 1, 0, 3 * sizeof(int32_t), st));
-    if (I > 0) {
-        k_hist<<<dim3((unsigned)((I + 256 * HIST_PER - 1) / (256 * HIST_PER))), dim3(256), 0, st>>>(I, (const long long *)item_ptr, HB, hist);
-        XM_LAUNCH_CHECK();
-    }
-    rcode = xmap_exclusive_scan_i32_to_i64(stream, hist, pre, HB, nullptr);
-    if (rcode) return rcode;
-    if (HB - 1 > ch_min) {
-        k_threshold<<<dim3((unsigned)((HB + 255) / 256)), dim3(256), 0, st>>>(I, HB, (const long long *)pre, ch_min, ctl);
-        XM_LAUNCH_CHECK();
-    }
-    if (I > 0) {
-        k_mark_heavy<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, (const long long *)item_ptr, ctl, hid, hlist, ctl + 1);
-        XM_LAUNCH_CHECK();
-    }
-    // sorted profiles + sort records (no mutuality flags yet)
-    if (R->n_users > 0 && nnz > 0) {
-        const dim3 grid((unsigned)((R->n_users + 15) / 16));
-        if (wide)
-            k_sort_profiles3<true><<<grid, dim3(256), 0, st>>>(R->n_users, (const long long *)R->user_ptr, R->user_item, nullptr, rating64,
-                                                               cnt, (unsigned long long *)ub_key, ub, (unsigned long long *)srec);
-        else
-            k_sort_profiles3<false><<<grid, dim3(256), 0, st>>>(R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating,
-                                                                nullptr, cnt, (unsigned long long *)ub_key, ub, (unsigned long long *)srec);
-        XM_LAUNCH_CHECK();
-    }
-    // sort records -> rater records in item order, W+
-    XM_HIP(hipMemsetAsync(Wp, 0, sizeof(uint64_t) * In, st));
-    if (nnz > 0 && I > 0) {
-        ts::Geo G;
-        ts_geometry(I, nnz, G);
-        rcode = ts_prepare(st, G, (const long long *)item_ptr);
-        if (rcode) return rcode;
-        const dim3 gridA((unsigned)((nnz + ts::CH - 1) / ts::CH)), gridB((unsigned)G.clist_cap), gridL((unsigned)G.slist_cap);
-        if (wide) {
-            ts::RecLoader<3> LA{(const unsigned long long *)srec}, LB{(const unsigned long long *)bufA};
-            ts::k_ts_bin<3, false, ts::RecLoader<3>><<<gridA, dim3(ts::BT), 0, st>>>(G, LA, nnz, (unsigned long long *)bufA);
-            XM_LAUNCH_CHECK();
-            ts::k_ts_bin<3, true, ts::RecLoader<3>><<<gridB, dim3(ts::BT), 0, st>>>(G, LB, nnz, (unsigned long long *)bufB);
-            XM_LAUNCH_CHECK();
-            k_rc_tiles<true><<<dim3((unsigned)G.T), dim3(ts::CT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)R->user_ptr,
-                                                                          (ulonglong2 *)rc, (unsigned long long *)Wp);
-            XM_LAUNCH_CHECK();
-            k_rc_large<true><<<gridL, dim3(ts::LT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)R->user_ptr,
-                                                             (ulonglong2 *)rc, (unsigned long long *)Wp);
-            XM_LAUNCH_CHECK();
-        } else {
-            ts::RecLoader<2> LA{(const unsigned long long *)srec}, LB{(const unsigned long long *)bufA};
-            ts::k_ts_bin<2, false, ts::RecLoader<2>><<<gridA, dim3(ts::BT), 0, st>>>(G, LA, nnz, (unsigned long long *)bufA);
-            XM_LAUNCH_CHECK();
-            ts::k_ts_bin<2, true, ts::RecLoader<2>><<<gridB, dim3(ts::BT), 0, st>>>(G, LB, nnz, (unsigned long long *)bufB);
-            XM_LAUNCH_CHECK();
-            k_rc_tiles<false><<<dim3((unsigned)G.T), dim3(ts::CT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)R->user_ptr,
-                                                                           (ulonglong2 *)rc, (unsigned long long *)Wp);
-            XM_LAUNCH_CHECK();
-            k_rc_large<false><<<gridL, dim3(ts::LT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)R->user_ptr,
-                                                              (ulonglong2 *)rc, (unsigned long long *)Wp);
-            XM_LAUNCH_CHECK();
-        }
-    }
-    // item statistics from the rater records (+ their mutuality flags), big items in chunks; then the profile copy's flags
-    if (I > 0) {
-        BigList B;
-        B.chunk_cap = nnz / STAT_CHK + nnz / STAT_BIG + 2;
-        B.item_cap = nnz / STAT_BIG + 2;
-        XM_HIP(xm_malloc_async((void **)&B.counters, 2 * sizeof(unsigned), st));
-        XM_HIP(xm_malloc_async((void **)&B.chunks, sizeof(int2) * (size_t)B.chunk_cap, st));
-        XM_HIP(xm_malloc_async((void **)&B.items, sizeof(int4) * (size_t)B.item_cap, st));
-        XM_HIP(xm_malloc_async((void **)&B.part, sizeof(double) * 5 * (size_t)B.chunk_cap, st));
-        XM_HIP(hipMemsetAsync(B.counters, 0, 2 * sizeof(unsigned), st));
-        const dim3 grid((unsigned)((I + 15) / 16)), gridC((unsigned)((B.chunk_cap + 3) / 4)), gridI((unsigned)((B.item_cap + 63) / 64));
-        if (wide) {
-            const RcWideSrc src{(const RaterRecWide *)rc};
-            k_item_stats3<RcWideSrc><<<grid, dim3(256), 0, st>>>(I, (const long long *)item_ptr, src, info, norms, B);
-            XM_LAUNCH_CHECK();
-            k_item_chunks<RcWideSrc><<<gridC, dim3(256), 0, st>>>((const long long *)item_ptr, src, B);
-            XM_LAUNCH_CHECK();
-            k_item_big<<<gridI, dim3(64), 0, st>>>(I, B, info, norms);
-            XM_LAUNCH_CHECK();
-        } else {
-            const RcSrc src{(RaterRec *)rc, u_avg};
-            k_item_stats3<RcSrc><<<grid, dim3(256), 0, st>>>(I, (const long long *)item_ptr, src, info, norms, B);
-            XM_LAUNCH_CHECK();
-            k_item_chunks<RcSrc><<<gridC, dim3(256), 0, st>>>((const long long *)item_ptr, src, B);
-            XM_LAUNCH_CHECK();
-            k_item_big<<<gridI, dim3(64), 0, st>>>(I, B, info, norms);
-            XM_LAUNCH_CHECK();
-            k_item_big_flags<RcSrc><<<gridC, dim3(256), 0, st>>>((const long long *)item_ptr, src, B, info);
-            XM_LAUNCH_CHECK();
-            if (nnz > 0) {
-                k_ub_flags<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st>>>(nnz, (int2 *)ub, info);
-                XM_LAUNCH_CHECK();
-            }
-        }
-    }
-    if (h_ctl) {
-        XM_HIP(hipMemcpyAsync(h_ctl, ctl, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        XM_HIP(hipStreamSynchronize(st));
-        if (h_ctl[1] > HMAX) {
-            set_error("heavy set larger than %d", HMAX);
-            return XMAP_ERR_OVERFLOW;
-        }
-    }
-    return XMAP_OK;
-}
-
-int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
-                     const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *d_shards, int64_t n_pairs,
-                     const int32_t *own, const int32_t *mir, int32_t *tot, int64_t *row_ptr, int64_t *mptr, int32_t *fill,
-                     void *bufA, void *bufB, int32_t *col, double *sim, int32_t *mutu, int32_t *nij) {
-    XM_SCOPE(stream);
-    XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && own && mir && tot && row_ptr && mptr && fill && bufA && bufB);
-    XM_ARG(col && sim && mutu && nij && n_items >= 0 && coo_cap >= 0 && n_pairs >= 0 && n_pairs < 0x7fffffffLL);
-    XM_ARG(d_shards ? (coo_cap >= COO_SHARDS) : (n_pairs <= coo_cap));
-    hipStream_t st = (hipStream_t)stream;
-    const int I = n_items;
-    if (I > 0) {
-        k_row_totals<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, own, mir, tot);
-        XM_LAUNCH_CHECK();
-    }
-    int rcode = xmap_exclusive_scan_i32_to_i64(stream, tot, row_ptr, I, nullptr);
-    if (rcode) return rcode;
-    rcode = xmap_exclusive_scan_i32_to_i64(stream, mir, mptr, I, nullptr);
-    if (rcode) return rcode;
-    if (n_pairs == 0 || I == 0 || coo_cap == 0) return XMAP_OK;
-    XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)I, st));
-    ts::Geo G;
-    ts_geometry(I, n_pairs, G);
-    rcode = ts_prepare(st, G, (const long long *)mptr);
-    if (rcode) return rcode;
-    // the COO's chunks: from the shard cursors of the pair kernels, or one range of n_pairs records
-    const int n_shards = d_shards ? COO_SHARDS : 1;
-    const long long shard_cap = d_shards ? coo_cap / COO_SHARDS : coo_cap;
-    const long long chunk_cap = n_pairs / ts::CH + n_shards + 1;
-    longlong2 *chunks = nullptr;
-    unsigned *n_chunks = nullptr;
-    XM_HIP(xm_malloc_async((void **)&chunks, sizeof(longlong2) * (size_t)chunk_cap, st));
-    XM_HIP(xm_malloc_async((void **)&n_chunks, sizeof(unsigned), st));
-    XM_HIP(hipMemsetAsync(n_chunks, 0, sizeof(unsigned), st));
-    k_coo_chunks<<<dim3((unsigned)((n_shards + 255) / 256)), dim3(256), 0, st>>>(n_shards, shard_cap, (const unsigned long long *)d_shards,
-                                                                                 n_pairs, chunks, n_chunks, chunk_cap);
-    XM_LAUNCH_CHECK();
-    CooLoader LA{coo_i, coo_j, coo_sim, coo_mutu, coo_nij, chunks, n_chunks, (const long long *)row_ptr, fill, col, sim, mutu, nij};
-    ts::RecLoader<3> LB{(const unsigned long long *)bufA};
-    ts::k_ts_bin<3, false, CooLoader><<<dim3((unsigned)chunk_cap), dim3(ts::BT), 0, st>>>(G, LA, coo_cap, (unsigned long long *)bufA);
-    XM_LAUNCH_CHECK();
-    ts::k_ts_bin<3, true, ts::RecLoader<3>><<<dim3((unsigned)G.clist_cap), dim3(ts::BT), 0, st>>>(G, LB, n_pairs, (unsigned long long *)bufB);
-    XM_LAUNCH_CHECK();
-    k_mir_tiles<<<dim3((unsigned)G.T), dim3(ts::CT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)row_ptr, own, col, sim,
-                                                              mutu, nij);
-    XM_LAUNCH_CHECK();
-    k_mir_large<<<dim3((unsigned)G.slist_cap), dim3(ts::LT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)row_ptr, own, col,
-                                                                       sim, mutu, nij);
-    XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
 }

@@ -1,0 +1,404 @@
+// stage_d.hip -- dense item-factor variant of the cross-domain similarity (BASELINE.json configs[4]; not in the
+// reference: SURVEY.md 8c/8f-4).  Items carry K-dimensional factors; xsim(t, s) = cosine(F_t, F_s) is a dense
+// (n_t x K) x (K x n_s) contraction on the fp32 matrix cores with the per-row top-k fused behind it, so the
+// n_t x n_s similarity matrix (1.6e11 B at 200k x 200k) never exists in memory.
+//
+//   k_dense_normalize : Fn = F / ||F||  (norm in fp64, k order), rows staged through LDS
+//   k_dense_topk      : one workgroup of 8 waves = 256 target rows per CU, two waves per SIMD.  Wave w keeps the A
+//                       fragments of its 32 rows for the whole K in registers (K/2 VGPRs); the source items stream
+//                       through a double-buffered LDS stage of 4 x 32 rows, filled by LDS-direct global loads
+//                       (one barrier per 128 source items); a wave multiplies two 32x32 tiles at a time (two
+//                       independent accumulator chains of v_mfma_f32_32x32x2_f32, operands by ds_read_b128 issued
+//                       one group ahead).  An MFMA f32 accumulation is bit for bit the k-ordered fmaf chain, which
+//                       is what the oracle computes.
+//                       The barriers keep all waves on the same stage, so the two waves of a SIMD would multiply
+//                       together and rank together; waves 4..7 therefore rank a tile pair BEFORE the next pair's
+//                       MFMAs and waves 0..3 AFTER their own: one wave's ranking runs under the other's MFMAs.
+//                       Ranking: the 32 top-k lists of a wave live in registers, one VGPR pair (value, index) per
+//                       row with one list entry per lane (k <= 64).  Each lane also keeps, per accumulator
+//                       register, the |sim| of its row's worst kept entry; a tile's values are compared against
+//                       it in registers (one ballot per accumulator register), the few that pass replace the worst
+//                       entry (v_cndmask at the worst lane) and a DPP min-reduction gives the new bound.  No LDS or
+//                       memory traffic for the lists until the final write.
+//   k_dense_merge     : folds the partial lists when the source items were split over several workgroups.
+// MFMA-bound by design: 2 K n_t n_s flop against the 157 TFLOP/s fp32 matrix peak.
+#include "common.h"
+
+namespace xmap {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D_WAVES = 8;       // waves per workgroup (two per SIMD)
+constexpr int D_ROWS = 32 * D_WAVES;   // target rows per workgroup (32 per wave)
+constexpr int D_THREADS = 64 * D_WAVES;
+constexpr int D_TILE = 32;       // source items per MFMA tile
+constexpr int D_GROUP = 4;       // tiles per LDS stage (one barrier per stage), multiplied in pairs
+constexpr int D_TOPK = 64;       // list capacity per row (k <= 64: one lane per entry)
+
+// 64 rows per workgroup: coalesced load into LDS, one thread per row sums the squares in k order (fp64; the order is
+// part of the definition the oracle pins), coalesced write of the quotients
+constexpr int DN_ROWS = 64;
+template <int K>
+__global__ __launch_bounds__(256) void k_dense_normalize(int n, const float *F, float *Fn) {
+    __shared__ float T[DN_ROWS][K + 1];
+    __shared__ double nrm[DN_ROWS];
+    const int r0 = blockIdx.x * DN_ROWS;
+    const int rows = min(DN_ROWS, n - r0);
+    for (int e = threadIdx.x; e < rows * K; e += 256) T[e / K][e % K] = F[(size_t)r0 * K + e];
+    __syncthreads();
+    if (threadIdx.x < rows) {
+        double q = 0.0;
+        for (int k = 0; k < K; k++) { const double x = (double)T[threadIdx.x][k]; q += x * x; }
+        nrm[threadIdx.x] = sqrt(q);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * K; e += 256) {
+        const double d = nrm[e / K];
+        Fn[(size_t)r0 * K + e] = (d > 0.0) ? (float)((double)T[e / K][e % K] / d) : 0.f;
+    }
+}
+
+// (|v|, idx) order packed in one word: larger key = better candidate (|v| desc, then idx asc)
+__device__ __forceinline__ unsigned long long d_key(float v, int idx) {
+    return ((unsigned long long)__float_as_uint(fabsf(v)) << 32) | (unsigned)(~idx);
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// wave-wide minimum, uniform result: four DPP steps inside the rows of 16 lanes, then the four row results
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = min(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = min(v, dpp_u32<0x141>(v));   // row_half_mirror
+    v = min(v, dpp_u32<0x140>(v));   // row_mirror
+    const unsigned a = (unsigned)rl32((int)v, 0), b = (unsigned)rl32((int)v, 16);
+    const unsigned c = (unsigned)rl32((int)v, 32), d = (unsigned)rl32((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// The work is the grid of (row block of 256 target rows) x (tile of 32 source items), linearised row block major and
+// cut into equal shares, one per workgroup; the grid is one residency of the chip (one workgroup per CU), so there
+// is no tail round.  A share crosses row-block boundaries: each (row block, tile range) segment is ranked into its
+// own list ("piece" = number of share boundaries since the row block's first tile) and written sorted to
+// out[(row * n_pieces + piece) * k ...]; k_dense_merge folds a row's pieces.
+template <int K>
+__global__ __launch_bounds__(D_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, const float *Ft, const float *Fs, int k,
+                  int *out_idx, float *out_val) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][D_GROUP * D_TILE][K + 4];   // row stride K+4: conflict-free ds_read_b128
+
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const bool late = w >= D_WAVES / 2;   // waves w and w + 4 share a SIMD (checked with HW_REG_HW_ID, build -DD_TRACE)
+#ifdef D_TRACE
+    const unsigned long long rt0 = wall_clock64();
+#endif
+    const long long total = (long long)((n_t + D_ROWS - 1) / D_ROWS) * n_tiles;
+    const long long w_lo = blockIdx.x * share;
+    const long long w_hi = min(total, w_lo + share);
+    for (long long at = w_lo; at < w_hi;) {
+    const int rb = (int)(at / n_tiles);
+    const int t0 = (int)(at - (long long)rb * n_tiles);
+    const int t1 = (int)min((long long)n_tiles, t0 + (w_hi - at));
+    const int piece = (int)(blockIdx.x - ((long long)rb * n_tiles) / share);
+    at += t1 - t0;
+    const int row0 = rb * D_ROWS + w * 32;
+    const int s_lo = t0 * D_TILE;
+    const int s_hi = min(n_s, t1 * D_TILE);
+    // A fragments: lane l holds A[i = l&31][k = 2 kk + (l>>5)]
+    float a[K / 2];
+    {
+        const int i = row0 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < K / 2; kk++)
+            a[kk] = (i < n_t) ? Ft[(size_t)i * K + 2 * kk + (lane >> 5)] : 0.f;
+    }
+    // The lists: register pair q = 2 r + h holds the list of the row that accumulator register r carries on the lanes
+    // of half h (row (r&3) + 8 (r>>2) + 4 h of the wave's 32), entry p on lane p, SORTED by key (best on lane 0).
+    // Empty entries are (0, -1), the smallest key, so inserting into the sorted list also fills it; lanes >= k are
+    // scratch (the shift pushes the dropped entry there).
+    float Lv[32];
+    int Li[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) { Lv[q] = 0.f; Li[q] = -1; }
+    const unsigned long long kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    // thr[r]: |value| of the worst kept entry of the row accumulator register r carries on this lane's half (+inf for
+    // rows past n_t: nothing enters)
+    float thr[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        thr[r] = (row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) < n_t) ? 0.f : __builtin_inff();
+
+    // staging: global -> LDS directly (global_load_lds_dword: lane i of a wave-load fills LDS dword base + i, the
+    // global address is per lane).  A row of the stage holds the even k first and the odd k behind them, so lane
+    // (j, h) finds its operands B[k = 2 kk + h][j] for 4 consecutive kk in one ds_read_b128; the permutation is done
+    // on the global side (lane i of the load for half q reads k = 2 i + q).  Of the 128 rows of a stage wave w moves
+    // rows 16 w + 8 part .. + 7 in call `part` (0, 1).  Columns past s_hi are never ranked, so their rows only need
+    // a valid address (clamped), not zeros.
+    constexpr int FROWS = D_GROUP * D_TILE / D_WAVES / 2;
+    auto fetch = [&](int buf, int part, int cbase) {
+#pragma unroll
+        for (int jj = 0; jj < FROWS; jj++) {
+            const int jr = w * 2 * FROWS + part * FROWS + jj;
+            const int j = min(cbase + jr, n_s - 1);
+            const float *src = Fs + (size_t)j * K;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (K >= 128 || lane < K / 2)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * lane + q),
+                                                     (__attribute__((address_space(3))) void *)&Bs[buf][jr][q * (K / 2)], 4, 0, 0);
+            }
+        }
+    };
+    // ranking of one 32 x 32 tile.  insert(): the candidates of one row (the set bits of mm, lanes lane_base + bit),
+    // one by one, all lanes cooperating: position = number of kept entries with a larger key (one 64-bit compare +
+    // popcount), entries behind it move one lane up (DPP wave_shr:1), the candidate takes the gap, and the k-th
+    // entry is the new bound.
+    auto insert = [&](float &lv, int &li, float &th, unsigned mm, int lane_base, float v, int c0, bool upper) {
+        while (mm) {
+            const int l = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const float cv = rlf(v, lane_base + l);
+            const int cj = c0 + l;
+            const unsigned long long ckey = d_key(cv, cj);
+            const unsigned long long key = ((unsigned long long)(__float_as_uint(lv) & 0x7fffffffu) << 32) | (unsigned)(~li);
+            const int pos = __popcll(__ballot(key > ckey) & kmask);
+            if (pos >= k) continue;   // an earlier candidate of this tile raised the bar, or an index tie lost
+            const float sv = __uint_as_float(dpp_u32<0x138>(__float_as_uint(lv)));   // wave_shr:1
+            const int si = (int)dpp_u32<0x138>((unsigned)li);
+            lv = lane > pos ? sv : (lane == pos ? cv : lv);
+            li = lane > pos ? si : (lane == pos ? cj : li);
+            const float nb = fabsf(rlf(lv, k - 1));
+            if ((lane >= 32) == upper) th = nb;
+        }
+    };
+    auto rank_tile = [&](const f32x16 &acc, int c0) {
+        const int j = c0 + (lane & 31);
+        const bool jv = j < s_hi;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float v = acc[r];
+            const unsigned long long m = __ballot(jv && fabsf(v) >= thr[r]);
+#ifdef D_NOINSERT
+            if (m == 0x123456789abcull) out_val[1] = 1.f;
+#else
+            if (m) {
+                insert(Lv[2 * r], Li[2 * r], thr[r], (unsigned)m, 0, v, c0, false);
+                insert(Lv[2 * r + 1], Li[2 * r + 1], thr[r], (unsigned)(m >> 32), 32, v, c0, true);
+            }
+#endif
+        }
+    };
+
+    const int n_groups = ((s_hi - s_lo + D_TILE - 1) / D_TILE + D_GROUP - 1) / D_GROUP;
+    fetch(0, 0, s_lo);
+    fetch(0, 1, s_lo);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the LDS-direct loads have landed
+    __syncthreads();
+    f32x16 acc0, acc1;
+    bool pend = false;    // acc0/acc1 hold a multiplied pair that is not ranked yet (tiles at pend_c0, pend_c0 + 32)
+    int pend_c0 = 0;
+    // one pass more than there are stages: the late waves rank their last pair in it
+    for (int g = 0; g <= n_groups; g++) {
+        const int buf = g & 1;
+        const bool more = g + 1 < n_groups;
+#pragma nounroll
+        for (int p = 0; p < D_GROUP / 2; p++) {
+            const int c0 = s_lo + (g * D_GROUP + 2 * p) * D_TILE;
+            // the next stage, into the buffer that was last read before the previous barrier
+            if (more) fetch(buf ^ 1, p, s_lo + (g + 1) * D_GROUP * D_TILE);
+#pragma nounroll
+            for (int sub = 0; sub < 2; sub++) {
+                if ((sub == 0) == late && pend) {
+#ifdef D_NORANK
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sacc += acc0[r] + acc1[r];
+                    if (sacc == 123.456f) out_val[0] = sacc;
+#else
+                    rank_tile(acc0, pend_c0);
+                    rank_tile(acc1, pend_c0 + D_TILE);
+#endif
+                    pend = false;
+                }
+                if (sub == 0 && g < n_groups && c0 < s_hi) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+                    const f32x4 *b0 = (const f32x4 *)&Bs[buf][2 * p * D_TILE + (lane & 31)][(lane >> 5) * (K / 2)];
+                    const f32x4 *b1 = (const f32x4 *)&Bs[buf][(2 * p + 1) * D_TILE + (lane & 31)][(lane >> 5) * (K / 2)];
+                    f32x4 x0 = b0[0], x1 = b1[0];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int c = 0; c < K / 8; c++) {   // 4 k pairs per ds_read_b128 and tile
+                        const f32x4 n0 = b0[c + 1 < K / 8 ? c + 1 : c], n1 = b1[c + 1 < K / 8 ? c + 1 : c];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + i], x0[i], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * c + i], x1[i], acc1, 0, 0, 0);
+                        }
+                        x0 = n0; x1 = n1;
+                        // the next two ds_read_b128 go out behind the first of these MFMAs: the wait for this
+                        // chunk's operands (lgkmcnt(0): the LDS-direct loads make the compiler count
+                        // conservatively) then sits before the new reads are issued, and they have 7 MFMAs to land
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+                    }
+                    pend = true;
+                    pend_c0 = c0;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+    // the lists are sorted: entry p of a row goes to position p
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int r = q >> 1, h = q & 1;
+        const int gi = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (gi < n_t && lane < k) {
+            const size_t base = ((size_t)gi * n_pieces + piece) * k;
+            const bool valid = Li[q] >= 0;
+            out_idx[base + lane] = valid ? Li[q] : -1;
+            out_val[base + lane] = valid ? Lv[q] : 0.f;
+        }
+    }
+    }   // segments
+#ifdef D_TRACE
+    if (lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *tr = (unsigned long long *)out_val;
+        const size_t o = ((size_t)blockIdx.x * D_WAVES + w) * 4;
+        tr[o + 0] = rt0; tr[o + 1] = wall_clock64(); tr[o + 2] = hw; tr[o + 3] = xcc;
+    }
+#endif
+}
+
+// fold the n_split sorted partial lists of a row (wave per row): a candidate's final rank is the sum over the lists of
+// the number of better entries, found by binary search (keys are unique; padding has key 0)
+constexpr int D_MAXSPLIT = 16;
+__global__ __launch_bounds__(256) void k_dense_merge(int n_t, int n_tiles, long long share, int n_pieces, int k,
+                                                     const int *p_idx, const float *p_val, int *out_idx, float *out_val) {
+    __shared__ unsigned long long keys[4][D_MAXSPLIT * D_TOPK];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= n_t) return;
+    const long long rb = row / D_ROWS;
+    const int ns = (int)(((rb + 1) * n_tiles - 1) / share - (rb * n_tiles) / share) + 1;   // pieces this row block has
+    const int n = ns * k;
+    const int *pi = p_idx + (size_t)row * n_pieces * k;
+    const float *pv = p_val + (size_t)row * n_pieces * k;
+    int total = 0;
+    for (int c = lane; c < n; c += 64) {
+        const int id = pi[c];
+        keys[wv][c] = id >= 0 ? d_key(pv[c], id) : 0ull;
+        total += id >= 0;
+    }
+    total = (int)wave_sum_ll(total);
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < n; c += 64) {
+        const unsigned long long key = keys[wv][c];
+        if (key == 0ull) continue;
+        int rank = 0;
+        for (int s = 0; s < ns && rank < k; s++) {   // entries of list s that are better: lower bound in a descending list
+            const unsigned long long *L = keys[wv] + s * k;
+            int lo = 0, hi = k;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (L[mid] > key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) { out_idx[(size_t)row * k + rank] = pi[c]; out_val[(size_t)row * k + rank] = pv[c]; }
+    }
+    for (int p = (total < k ? total : k) + lane; p < k; p += 64) { out_idx[(size_t)row * k + p] = -1; out_val[(size_t)row * k + p] = 0.f; }
+}
+
+}  // namespace xmap
+
+using namespace xmap;
+
+extern "C" {
+
+int xmap_dense_normalize(void *stream, int32_t n, int32_t dim, const float *F, float *Fn) {
+    XM_ARG(F && Fn && n >= 0);
+    if (dim != 128 && dim != 64) {
+        set_error("dense variant: factor dimension %d not built (64 and 128 are)", dim);
+        return XMAP_ERR_ARG;
+    }
+    if (n == 0) return XMAP_OK;
+    dim3 grid((unsigned)((n + DN_ROWS - 1) / DN_ROWS)), block(256);
+    if (dim == 128) k_dense_normalize<128><<<grid, block, 0, (hipStream_t)stream>>>(n, F, Fn);
+    else k_dense_normalize<64><<<grid, block, 0, (hipStream_t)stream>>>(n, F, Fn);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+// share of the (row block x tile) grid per workgroup and the largest number of pieces a row block is cut into
+static void dense_layout(int n_t, int n_s, int &n_tiles, long long &share, int &n_wg, int &n_pieces) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    n_tiles = (n_s + D_TILE - 1) / D_TILE;
+    if (n_tiles < 1) n_tiles = 1;
+    const long long n_rb = (n_t + D_ROWS - 1) / D_ROWS;
+    const long long total = n_rb * n_tiles;
+    share = (total + cus - 1) / cus;   // one workgroup per CU
+    const long long cap = (n_tiles + D_MAXSPLIT - 3) / (D_MAXSPLIT - 2);   // at most D_MAXSPLIT pieces per row block
+    if (share < cap) share = cap;
+    if (share < 16) share = 16;
+    n_wg = (int)((total + share - 1) / share);
+    n_pieces = 1;
+    for (long long rb = 0; rb < n_rb; rb++) {
+        const int p = (int)(((rb + 1) * n_tiles - 1) / share - (rb * n_tiles) / share) + 1;
+        if (p > n_pieces) n_pieces = p;
+    }
+}
+
+int xmap_dense_layout(int32_t n_t, int32_t n_s, int32_t *n_pieces) {
+    XM_ARG(n_pieces && n_t >= 0 && n_s >= 0);
+    int n_tiles, n_wg;
+    long long share;
+    int np = 1;
+    dense_layout(n_t, n_s, n_tiles, share, n_wg, np);
+    *n_pieces = np;
+    return XMAP_OK;
+}
+
+int xmap_dense_topk(void *stream, int32_t n_t, int32_t n_s, int32_t dim, const float *Ft, const float *Fs, int32_t top_k,
+                    int32_t n_pieces, int32_t *part_idx, float *part_val, int32_t *out_idx, float *out_val) {
+    XM_ARG(Ft && Fs && out_idx && out_val && n_t >= 0 && n_s >= 0);
+    XM_ARG(top_k >= 1 && top_k <= D_TOPK);
+    if (dim != 128 && dim != 64) {
+        set_error("dense variant: factor dimension %d not built (64 and 128 are)", dim);
+        return XMAP_ERR_ARG;
+    }
+    if (n_t == 0) return XMAP_OK;
+    int n_tiles, n_wg, need;
+    long long share;
+    dense_layout(n_t, n_s, n_tiles, share, n_wg, need);
+    if (n_pieces < need || (need > 1 && !(part_idx && part_val))) {
+        set_error("dense variant: scratch for %d pieces per row needed (xmap_dense_layout), %d given", need, n_pieces);
+        return XMAP_ERR_CAPACITY;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *pi = need == 1 ? out_idx : part_idx;
+    float *pv = need == 1 ? out_val : part_val;
+    dim3 grid((unsigned)n_wg), block(D_THREADS);
+    if (dim == 128) k_dense_topk<128><<<grid, block, 0, st>>>(n_t, n_s, n_tiles, share, need, Ft, Fs, top_k, pi, pv);
+    else k_dense_topk<64><<<grid, block, 0, st>>>(n_t, n_s, n_tiles, share, need, Ft, Fs, top_k, pi, pv);
+    XM_LAUNCH_CHECK();
+    if (need > 1) {
+        k_dense_merge<<<dim3((unsigned)((n_t + 3) / 4)), dim3(256), 0, st>>>(n_t, n_tiles, share, need, top_k, pi, pv,
+                                                                               out_idx, out_val);
+        XM_LAUNCH_CHECK();
+    }
+    return XMAP_OK;
+}
+}

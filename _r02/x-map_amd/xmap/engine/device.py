@@ -25,13 +25,10 @@ class DeviceRatings(object):
     derived on the device at the start of every stage-A pass (Engine.build_csc); only the id dictionary and the
     H2D upload are one-off host work."""
 
-    def __init__(self, user_ptr, item, rating, time, n_items, attrs, device="cuda:0", rating64=False):
-        """rating64: also keep the ratings as fp64 (RecommenderSim runs over AlterEgo rows, whose ratings are np.float64 means,
-        reference core/generator.py:123-138 -> core/recommenderSim.py:64-133; the three stages of the path read float32)"""
+    def __init__(self, user_ptr, item, rating, time, n_items, attrs, device="cuda:0"):
         self.device = torch.device(device)
         user_ptr = np.ascontiguousarray(user_ptr, np.int64)
         item = np.ascontiguousarray(item, np.int32)
-        r64 = np.ascontiguousarray(rating, np.float64) if rating64 else None
         rating = np.ascontiguousarray(rating, np.float32)
         time = np.ascontiguousarray(time, np.int64)
         self.n_users = len(user_ptr) - 1
@@ -47,7 +44,6 @@ class DeviceRatings(object):
         self.user_ptr = t(user_ptr).to(d)
         self.user_item = t(item).to(d)
         self.user_rating = t(rating).to(d)
-        self.user_rating64 = t(r64).to(d) if r64 is not None else None
         self.user_time = t(time).to(d)
         self.item_ptr = torch.zeros(self.n_items + 1, dtype=torch.int64, device=d)
         self.item_user = torch.zeros(max(self.nnz, 1), dtype=torch.int32, device=d)
@@ -393,11 +389,9 @@ class Engine(object):
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
-    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False):
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
-        rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity).
-        split: count a row's own pairs (rowcnt) and the pairs lighter rows computed for it (a 5th return value) apart --
-        what tri_mirror takes."""
+        rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity)."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -415,7 +409,6 @@ class Engine(object):
             coo_nij = self._empty(cap_coo, torch.int32)
             coo_ls = self._empty(cap_coo, torch.float64) if (rec or raw) else None    # raw: the error column of the dot
             rowcnt = self._empty(max(I, 1), torch.int32)
-            mircnt = self._empty(max(I, 1), torch.int32) if split else None
             nh = L.n_heavy_units if do_heavy else 0
             hp_hi = self._empty(max(nh, 1) * 1024, torch.float64)
             hp_lo = self._empty(max(nh, 1) * 1024, torch.float64)
@@ -432,7 +425,7 @@ class Engine(object):
                     vp(L.uq_q), L.cls_ptr, i64(lo), i64(hi), vp(L.hid), vp(L.hlist), vp(L.ctl), vp(L.C), vp(L.uc_ptr),
                     vp(L.uc_item), vp(L.uc_c), i32(nh), i32(L.n_heavy), phases,
                     vp(hp_hi), vp(hp_lo), vp(hp_cnt), vp(hp_mut), i64(cap_coo), vp(coo_i), vp(coo_j), vp(coo_sim),
-                    vp(coo_mutu), vp(coo_nij), vp(coo_ls), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt), vp(mircnt)))
+                    vp(coo_mutu), vp(coo_nij), vp(coo_ls), vp(rowcnt), vp(rowcnt_h), vp(d_shards), vp(d_cnt)))
             if os.environ.get("XMAP_SPLIT_PHASES") == "1":        # one timer per phase (analysis)
                 with self.timed("pair_heavy"):
                     run(8 | (1 if do_heavy else 0))
@@ -461,8 +454,6 @@ class Engine(object):
         n, n_unordered = int(sh[0]), int(sh[1])
         coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if (rec or raw) else ())
         out = (coo, rowcnt, n, n_unordered)
-        if split:
-            return out + (mircnt, d_shards)
         return out if retry else out + (0,)
 
     def tri_scatter(self, coo, rowcnt, info, n=None, L=None):
@@ -500,9 +491,15 @@ class Engine(object):
         sensitivity of every directed item pair with a co-rater, CSR by first item (col, sim, nij, ls).  The same
         pair machinery as stage A: exact (double-double) sums with a zero user average, no heavy set."""
         R = self.R
+        st = _stream(self.dev)
         with self.timed("rec_stats"):
-            stats, L = self.layout3(slot_target, ch_min=max(64, R.n_users + 2), wide=True)      # no heavy set
-        info = stats[2]
+            self.build_csc()
+            zero_avg = self._zeros(max(R.n_users, 1), torch.float64)
+            info = self._zeros((max(R.n_items, 1), 4), torch.float64)
+            self.norms = self._zeros(2 * max(R.n_items, 1), torch.float64)
+            check(lib.xmap_item_stats(st, C.byref(R.c), vp(zero_avg), vp(info), vp(self.norms), None, None, i32(0), i32(R.n_items)))
+        stats = (zero_avg, None, info, None, None)
+        L = self.tri_layout(stats, slot_target, ch_min=max(64, R.n_users + 2), dups=True)
         coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
         S = self.tri_scatter(coo, rowcnt, info, n, L)
         S.cap, S.n_unordered, S.layout = int(cap), n_unordered, L
@@ -523,92 +520,13 @@ class Engine(object):
                                       vp(col), vp(sim), vp(ls)))
         return cnt[:I], col[:I], sim[:I], ls[:I]
 
-    def layout3(self, slot_target=640, ch_min=1024, wide=False):
-        """Round-3 layout of the "tri" formulation, one transposition per pass (xmap_sim3_layout): item counts, user and
-        item info, weight-sorted profiles, rater records through the tile sort, heavy set, work units.  Returns (stats, L)
-        like stats() + tri_layout().  wide: fp64 ratings (R.user_rating64) with zero user averages -- the RecommenderSim
-        variant."""
-        R = self.R
-        st = _stream(self.dev)
-        I, U, nnz = R.n_items, R.n_users, R.nnz
-        n1, i1 = max(nnz, 1), max(I, 1)
-        rw = 3 if wide else 2                                    # 64-bit words per sort record
-        L = SimResult()
-        cnt = self._empty(i1, torch.int32)
-        u_avg = self._zeros(max(U, 1), torch.float64) if wide else self._empty(max(U, 1), torch.float64)
-        u_norm = None if wide else self._empty(max(U, 1), torch.float64)
-        L.hist = self._empty(U + 2, torch.int32)
-        L.pre = self._empty(U + 3, torch.int64)
-        L.ctl = self._empty(4, torch.int32)
-        L.hid = self._empty(i1, torch.int32)
-        L.hlist = self._zeros(1024, torch.int32)
-        L.ub_key = self._empty(n1, torch.int64)
-        L.ub = self._empty(n1 * (2 if wide else 1), torch.int64)
-        srec = self._empty(n1 * rw, torch.int64)
-        buf_a = self._empty(n1 * rw, torch.int64)
-        buf_b = self._empty(n1 * rw, torch.int64)
-        L.rc = self._empty(n1 * 2, torch.int64)
-        L.Wp = self._empty(i1, torch.int64)
-        L.dups = bool(wide)
-        L.wide = bool(wide)
-        info = self._out((i1, 4), torch.float64, I > 0)
-        self.norms = self._out(2 * i1, torch.float64, I > 0)
-        h_ctl = (C.c_int32 * 2)()
-        r64 = None
-        if wide:
-            r64 = R.user_rating64 if R.user_rating64 is not None else R.user_rating.double()
-        with self.timed("layout3"):
-            check(lib.xmap_sim3_layout(st, C.byref(R.c), vp(R.item_ptr), vp(r64), i32(ch_min), vp(cnt),
-                                       vp(u_avg), vp(u_norm), vp(L.hist), vp(L.pre), vp(L.ctl), vp(L.hid), vp(L.hlist),
-                                       vp(L.ub_key), vp(L.ub), vp(srec), vp(buf_a), vp(buf_b), vp(L.rc), vp(L.Wp), vp(info),
-                                       vp(self.norms), h_ctl))
-        R.csc_ready = False             # item_ptr is current; item_user / item_rating are not built on this path
-        L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
-        L.slot_target = slot_target
-        self._tri_plan(L, slot_target)
-        both = torch.stack([L.Wp[:I].sum(), L.Wp[L.hlist[:L.n_heavy].long()].sum()]).tolist() if I else [0, 0]   # one sync
-        L.half_contrib, L.heavy_half = int(both[0]), int(both[1])
-        return (u_avg, u_norm, info, None, None), L
-
-    def tri_mirror(self, coo, own, mir, info, n, shards=None):
-        """round-3 mirror (xmap_sim3_mirror): a complete half COO with n valid entries, own[i] = pairs row i computed,
-        mir[j] = pairs computed in lighter rows -> CSR, row = [own | mirrored].  shards: the cursors tri_pairs left (the
-        COO is cut into 4096 shards filled from their start); None: the COO is one range of n records."""
-        R = self.R
-        st = _stream(self.dev)
-        I = R.n_items
-        coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo[:5]]
-        cap = int(coo_i.numel())
-        kept = 2 * int(n)
-        row_ptr = self._out(I + 1, torch.int64, I > 0)
-        mptr = self._empty(I + 1, torch.int64)
-        tot = self._empty(max(I, 1), torch.int32)
-        fill = self._empty(max(I, 1), torch.int32)
-        buf_a = self._empty(max(int(n), 1) * 3, torch.int64)
-        buf_b = self._empty(max(int(n), 1) * 3, torch.int64)
-        col = self._empty(max(kept, 1), torch.int32)
-        sim = self._empty(max(kept, 1), torch.float64)
-        mutu = self._empty(max(kept, 1), torch.int32)
-        nij = self._empty(max(kept, 1), torch.int32)
-        with self.timed("scatter"):
-            check(lib.xmap_sim3_mirror(st, i32(I), i64(cap), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu), vp(coo_nij), vp(shards), i64(n),
-                                       vp(own), vp(mir), vp(tot), vp(row_ptr), vp(mptr), vp(fill), vp(buf_a), vp(buf_b), vp(col),
-                                       vp(sim), vp(mutu), vp(nij)))
-        return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
-
     def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
-        """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU).  XMAP_A_V2=1: the round-2 sequence
-        (CSC build, CSC-driven rater records, cursor-atomic mirror) -- kept as a cross-check of the round-3 one."""
-        if os.environ.get("XMAP_A_V2") == "1":
-            with self.timed("stats"):
-                stats = self.stats()
-            L = self.tri_layout(stats, slot_target, ch_min)
-            coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
-            S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
-        else:
-            stats, L = self.layout3(slot_target, ch_min)
-            coo, rowcnt, n, n_unordered, mir, shards = self.tri_pairs(method, cap, stats, L, split=True)
-            S = self.tri_mirror(coo, rowcnt, mir, stats[2], n, shards)
+        """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU)."""
+        with self.timed("stats"):
+            stats = self.stats()
+        L = self.tri_layout(stats, slot_target, ch_min)
+        coo, rowcnt, n, n_unordered = self.tri_pairs(method, cap, stats, L)
+        S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
         S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
         S.cap = int(cap)
         S.u_avg, S.u_norm = stats[0], stats[1]
@@ -869,15 +787,7 @@ class Engine(object):
     def ext_tables(self, S, top_k, comm=None):
         """B1-B5b: bridge flags, classified top-k lists and the three reverse adjacencies (attach / src / rnn).
         comm (xmap.engine.sharded.Comm of several ranks): every rank classifies a share of the rows -- contiguous ranges of
-        equal entry counts -- and the tables are all-gathered (the reference broadcasts them, utils/assist.py:93-95).
-        Three phases (a sharded caller puts its collective error check between them: ext_knn and ext_reverse may raise,
-        ext_gather holds every collective and nothing else)."""
-        E = self.ext_knn(S, top_k, comm)
-        self.ext_gather(E, comm)
-        return self.ext_reverse(S, E)
-
-    def ext_knn(self, S, top_k, comm=None):
-        """local part: the classified top-k lists of this rank's share of the rows (all rows without comm)"""
+        equal entry counts -- and the tables are all-gathered (the reference broadcasts them, utils/assist.py:93-95)."""
         I = self.R.n_items
         rows = None
         if comm is not None and comm.world > 1 and I > 0:
@@ -887,31 +797,17 @@ class Engine(object):
             cuts = np.maximum.accumulate(np.asarray(cuts))
             rows = (int(cuts[comm.rank]), int(cuts[comm.rank + 1]))
         E = self.knn(S, top_k, rows=rows)
-        E.rows = rows
         ok = C.c_int32(1)
         check(lib.xmap_edge_ranges(_stream(self.dev), C.byref(S.c), C.byref(ok)))
         E.fast_div = int(ok.value)       # the bare division sequence of k_paths4 is the division for these edge values
-        return E
-
-    def ext_gather(self, E, comm):
-        """collectives only: the ranks' shares of the knn tables, all-gathered"""
-        rows = getattr(E, "rows", None)
-        if rows is None:
-            return E
-        I = self.R.n_items
-        lo, hi = rows
-        with self.timed("knn_gather"):
-            k = E.k
-            E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
-            E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
-            E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)
-            E.kval[:I] = comm.all_gather_var(E.kval[lo:hi].reshape(-1)).view(I, 2, k, 3)
-        E.rows = None
-        return E
-
-    def ext_reverse(self, S, E):
-        """local part: list thresholds and the three reverse adjacencies from the complete knn tables"""
-        I = self.R.n_items
+        if rows is not None:
+            lo, hi = rows
+            with self.timed("knn_gather"):
+                k = E.k
+                E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
+                E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
+                E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)
+                E.kval[:I] = comm.all_gather_var(E.kval[lo:hi].reshape(-1)).view(I, 2, k, 3)
         st = _stream(self.dev)
         with self.timed("reverse"):
             E.thr = self._empty(max(I, 1) * 4, torch.float64)      # last entry of every list, 16 B each
@@ -1119,65 +1015,43 @@ class Engine(object):
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
-        n_top = self._out(max(I, 1), torch.int32, I > 0)      # written for every start / filled by the library
-        choice = self._out(max(I, 1), torch.int32, I > 0)
-        mp = self._out(max(I, 1), torch.int32, I > 0)
+        n_top = self._zeros(max(I, 1), torch.int32)
+        choice = self._zeros(max(I, 1), torch.int32)
+        mp = self._zeros(max(I, 1), torch.int32)
         pk = None
         if picks is not None:
             pk = torch.from_numpy(np.ascontiguousarray(picks, np.int32)).to(self.dev)
-        with self.timed("c_select"):
-            check(lib.xmap_select_map(st, i32(I), 1 if private else 0, vp(E.n_cand), vp(E.top_end), vp(pk),
-                                      vp(n_top), vp(choice), vp(mp)))
+        check(lib.xmap_select_map(st, i32(I), 1 if private else 0, vp(E.n_cand), vp(E.top_end), vp(pk),
+                                  vp(n_top), vp(choice), vp(mp)))
         return n_top, choice, mp
 
     def alterego(self, mp):
         R = self.R
         st = _stream(self.dev)
         U = R.n_users
-        cnt_t = self._empty(max(U, 1), torch.int32)
-        cnt_m = self._empty(max(U, 1), torch.int32)
-        if U == 0:
-            cnt_t.zero_(); cnt_m.zero_()
-        d_prof = self._zeros(1, torch.int64)
-        with self.timed("c_count"):
-            check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m), vp(d_prof)))
-            off_t = self._empty(U + 1, torch.int64)
-            off_m = self._empty(U + 1, torch.int64)
-            check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_t), vp(off_t), i64(U), None))
-            check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_m), vp(off_m), i64(U), None))
-            # the three totals in ONE synchronisation (the scans leave theirs in out[U])
-            h = self._pinned3()
-            h[0:1].copy_(off_t[U:U + 1], non_blocking=True)
-            h[1:2].copy_(off_m[U:U + 1], non_blocking=True)
-            h[2:3].copy_(d_prof, non_blocking=True)
-            torch.cuda.current_stream(self.dev).synchronize()
-            nt, nm, n_prof = int(h[0]), int(h[1]), int(h[2])
-        n = nt + nm
+        cnt_t = self._zeros(max(U, 1), torch.int32)
+        cnt_m = self._zeros(max(U, 1), torch.int32)
+        check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m)))
+        off_t = self._zeros(U + 1, torch.int64)
+        off_m = self._zeros(U + 1, torch.int64)
+        nt, nm = C.c_int64(0), C.c_int64(0)
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_t), vp(off_t), i64(U), C.byref(nt)))
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_m), vp(off_m), i64(U), C.byref(nm)))
+        n = int(nt.value) + int(nm.value)
         G = GenResult()
         G.user = self._empty(max(n, 1), torch.int32)
         G.item = self._empty(max(n, 1), torch.int32)
         G.rating = self._empty(max(n, 1), torch.float64)      # pass-through ratings and np.mean of the merged ones (fp64)
         G.time = self._empty(max(n, 1), torch.int64)
-        with self.timed("c_fill"):
-            check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt),
-                                         vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))
-        G.n_rows, G.n_target_rows = n, nt
+        check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt.value),
+                                     vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))
+        G.n_rows, G.n_target_rows = n, int(nt.value)
         G.cnt_t, G.cnt_m = cnt_t, cnt_m
-        G.n_profiles = n_prof
         G.user, G.item, G.rating, G.time = G.user[:n], G.item[:n], G.rating[:n], G.time[:n]
         return G
 
-    def _pinned3(self):
-        h = getattr(self, "_h3", None)
-        if h is None:
-            h = self._h3 = torch.empty(3, dtype=torch.int64, pin_memory=True)
-        return h
-
     def n_profiles(self, G):
         """distinct users present in the AlterEgo output (profiles/s numerator)."""
-        n = getattr(G, "n_profiles", None)      # counted by the count pass of alterego()
-        if n is not None:
-            return int(n)
         U = self.R.n_users
         return int(((G.cnt_t[:U] + G.cnt_m[:U]) > 0).sum().item())
 

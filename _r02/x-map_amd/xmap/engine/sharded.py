@@ -1,0 +1,343 @@
+"""One pass of the hot path, optionally item-sharded over the ranks of one node.
+
+Sharding: inputs (CSR + CSC) are replicated in every GPU's HBM; the work is sharded by
+item.  Stage A: the per-item statistics are computed for a share of the items and all-gathered (32 B x I: the all-gather of
+item norms); the work units (item, partition) of the pair kernel are split into contiguous ranges of
+equal rater-steps; each rank appends the kept pairs of its units to a half COO (every unordered pair is
+owned by exactly one unit, so there are no cross-GPU partials) and mirrors them into a CSR of its own:
+that is the rank's partition of item2item_simRDD (both directions of its pairs), and where stage A ends.  Stage B starts with the exchange its input needs (the reference
+broadcasts the knn tables, utils/assist.py:88-101): the per-item row counts are all-reduced, the COO parts
+all-gathered (S4/S6 of SURVEY 2.3) and every rank mirrors the full COO into the CSR; then
+every rank classifies the top-k lists of a share of the rows and the knn tables are all-gathered (S7; round 1 rebuilt them
+everywhere), the reverse and middle lists are still derived on every rank, the path enumeration is sharded by start item
+(ranges of equal path counts), and the
+fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
+passes over nnz and is replicated.
+
+run_step_users is the other split (inputs sharded by USER, the partial similarities of a pair exchanged and added up at
+the pair's owner): see its docstring.
+
+Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on the MI355X node; "gloo"
+(host staging) is used by the CPU-side tests and for rehearsals with several ranks on one GPU.
+"""
+import numpy as np
+import torch
+
+
+# ----------------------------------------------------------------------------- host-side helpers
+def balanced_ranges(weights, world):
+    """Split [0, n) into `world` contiguous ranges of near-equal total weight.
+    weights: 1-D array-like of non-negative numbers.  Returns [(lo, hi)] * world."""
+    w = np.asarray(weights, dtype=np.float64)
+    n = len(w)
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    total = c[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        cuts.append(int(min(max(np.searchsorted(c, target, side="left"), cuts[-1]), n)))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def unit_cuts(c, w_heavy, world):
+    """Cut points of the light work units over `world` ranks.  c: inclusive prefix sum (float64 tensor) of the units' rater
+    steps; w_heavy: rater visits of the heavy rows (0-d tensor or None), which rank 0 computes as well and which therefore
+    count against its share.  Returns world + 1 non-decreasing unit indices from 0 to len(c)."""
+    n = int(c.numel())
+    if n == 0:
+        return np.zeros(world + 1, np.int64)
+    wh = w_heavy if w_heavy is not None else torch.zeros((), dtype=torch.float64, device=c.device)
+    first = torch.minimum(((c[-1] + wh) / world - wh).clamp(min=0.0), c[-1])
+    tgt = first + (c[-1] - first) / max(world - 1, 1) * torch.arange(0, world - 1, dtype=torch.float64, device=c.device)
+    cuts = [0] + torch.searchsorted(c, tgt).clamp(max=n).tolist() + [n]
+    return np.maximum.accumulate(np.asarray(cuts, np.int64))
+
+
+class Comm(object):
+    """Thin wrapper over torch.distributed that stages through the host for gloo."""
+    A2A_PIECE_BYTES = 1 << 28
+
+    def __init__(self, dist, group=None):
+        """group: a torch.distributed process group (None = all ranks); rank / world are relative to it"""
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.host = dist.get_backend(group) == "gloo"
+
+    def all_reduce(self, t, op="sum"):
+        ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}
+        if self.host and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=ops[op], group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=ops[op], group=self.group)
+        return t
+
+    def agree(self, err, what):
+        """Collective error check: every rank calls it with its own exception (or None); if ANY rank failed, EVERY rank
+        raises, so that nobody is left waiting in the next collective."""
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int64)
+        if not self.host:
+            flag = flag.cuda()
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            if err is not None:
+                raise err
+            raise RuntimeError("%s failed on another rank (this is rank %d of %d)" % (what, self.rank, self.world))
+
+    def all_gather_var(self, t):
+        """Concatenate 1-D tensors of different lengths from all ranks, in rank order."""
+        dev = t.device
+        n = torch.tensor([t.numel()], dtype=torch.int64, device="cpu" if self.host else dev)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        m = max(max(sizes), 1)
+        src = t.cpu() if self.host else t
+        pad = torch.zeros(m, dtype=t.dtype, device=src.device)
+        pad[:t.numel()] = src
+        parts = [torch.empty(m, dtype=t.dtype, device=src.device) for _ in range(self.world)]
+        self.dist.all_gather(parts, pad, group=self.group)
+        out = torch.cat([p[:s] for p, s in zip(parts, sizes)])
+        return out.to(dev)
+
+
+    def all_gather_fixed(self, t):
+        """[world, *t.shape]: the same-shaped tensor of every rank, in rank order"""
+        src = t.contiguous().cpu() if self.host else t.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(parts, src, group=self.group)
+        return torch.stack(parts).to(t.device)
+
+    def all_to_all_rows(self, rows, cuts):
+        """rows [n, w] int64 cut into `world` consecutive row ranges by cuts (world + 1 indices): range r goes to rank r.
+        Returns the ranges received, concatenated in rank order.  RCCL: one all_to_all_single with the split sizes; gloo
+        (no all-to-all): every rank all-gathers everything and keeps its ranges."""
+        w = int(rows.shape[1])
+        send = [int(cuts[r + 1] - cuts[r]) for r in range(self.world)]
+        table = torch.tensor(send, dtype=torch.int64)
+        if not self.host:
+            table = table.to(rows.device)
+        tabs = [torch.zeros_like(table) for _ in range(self.world)]
+        self.dist.all_gather(tabs, table, group=self.group)
+        tabs = torch.stack(tabs).cpu()                     # tabs[s][r]: rows rank s sends to rank r
+        if self.host:
+            allrows = self.all_gather_var(rows.reshape(-1)).view(-1, w)
+            start = torch.cumsum(tabs.sum(dim=1), 0) - tabs.sum(dim=1)      # first row of rank s in allrows
+            inner = torch.cumsum(tabs, 1) - tabs                            # offset of the range for r inside s's rows
+            parts = [allrows[int(start[s] + inner[s][self.rank]):int(start[s] + inner[s][self.rank] + tabs[s][self.rank])]
+                     for s in range(self.world)]
+            return torch.cat(parts) if parts else allrows[:0]
+        recv = [int(tabs[s][self.rank]) for s in range(self.world)]
+        out = torch.empty((sum(recv), w), dtype=rows.dtype, device=rows.device)
+        # In pieces of at most 256 MiB per peer: RCCL 2.26's all_to_all_single returned wrong data for pieces above 1 GiB
+        # (measured with one rank: 1.28 GB of int64 rows came back wrong from byte 640 M on; all_gather / all_reduce of
+        # 2 GiB were fine).  Piece c of sender s lands behind its pieces 0 .. c-1, so the result is sender-major as above.
+        piece = max(1, self.A2A_PIECE_BYTES // (rows.element_size() * w))
+        rounds = (int(tabs.max()) + piece - 1) // piece
+        first = [sum(recv[:s_]) for s_ in range(self.world)]
+        for c in range(rounds):
+            send_c = [min(max(n_ - c * piece, 0), piece) for n_ in send]
+            recv_c = [min(max(n_ - c * piece, 0), piece) for n_ in recv]
+            buf = torch.cat([rows[int(cuts[r]) + c * piece:int(cuts[r]) + c * piece + send_c[r]] for r in range(self.world)])
+            tmp = torch.empty((sum(recv_c), w), dtype=rows.dtype, device=rows.device)
+            self.dist.all_to_all_single(tmp, buf.contiguous(), output_split_sizes=recv_c, input_split_sizes=send_c, group=self.group)
+            at = 0
+            for s_ in range(self.world):
+                out[first[s_] + c * piece:first[s_] + c * piece + recv_c[s_]] = tmp[at:at + recv_c[s_]]
+                at += recv_c[s_]
+        return out
+
+
+# ----------------------------------------------------------------------------- the step
+def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=False, group=None):
+    """stage A -> B -> C once.  Returns the counters the bench reports.  group: the process group that shares this
+    problem (None: all ranks); rank / world are then taken from it."""
+    I = eng.R.n_items
+    if dist is not None and group is not None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if dist is None or world == 1:
+        with eng.timed("stage_a"):
+            S = eng.item_sim(method, cap)
+        with eng.timed("stage_b"):
+            E = eng.extend(S, k, full=full)
+        with eng.timed("stage_c"):
+            n_top, choice, mp = eng.select(E, private)
+            G = eng.alterego(mp)
+            n_prof = eng.n_profiles(G)
+        L = S.layout
+        return dict(n_eval=S.n_eval, n_kept=S.n_kept, n_contrib=S.n_contrib,
+                    n_contrib_light=2 * (L.half_contrib - L.heavy_half), n_kept_local=S.n_kept,
+                    n_paths=E.n_paths, n_out=E.n_out, n_rows=G.n_rows, n_profiles=n_prof,
+                    knn_entries=int(E.kcnt.sum().item()), S=S, E=E, G=G, choice=choice, map=mp)
+
+    comm = Comm(dist, group)
+    dev = eng.dev
+    # ---- stage A: every rank lays out the (replicated) ratings, computes the pairs of its share of the
+    # work units into a half COO, the COO parts are all-gathered and mirrored into the full CSR everywhere
+    with eng.timed("stage_a"):
+        # per-item statistics of a share of the items, then ONE all-gather of the 32-byte item records and the two dense
+        # norm columns (S3 of SURVEY 2.3: the reference collects and broadcasts item_info, utils/assist.py:71-73)
+        ilo, ihi = I * rank // world, I * (rank + 1) // world
+        stats = eng.stats(item_range=(ilo, ihi))
+        with eng.timed("stats_gather"):
+            info = stats[2]
+            info[:I] = comm.all_gather_var(info[ilo:ihi].reshape(-1)).view(I, 4)
+            nI = max(I, 1)
+            for c0 in (0, nI):
+                eng.norms[c0:c0 + I] = comm.all_gather_var(eng.norms[c0 + ilo:c0 + ihi].contiguous())
+        L = eng.tri_layout(stats)
+        while True:
+            # contiguous unit ranges of equal rater-steps: prefix sum and cut points on the device (the units are listed
+            # by table class, every rank gets a slice of every class boundary it spans)
+            lo, hi = 0, 0
+            if L.n_light:
+                n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
+                c = torch.cumsum(n_i[L.uq_item[:L.n_light].long()].double(), 0)
+                w_heavy = n_i[L.hlist[:L.n_heavy].long()].sum().double() if L.n_heavy else None
+                cuts = unit_cuts(c, w_heavy, world)
+                lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+            err, ovf = None, 0
+            try:
+                coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
+                                                                 do_heavy=(rank == 0), retry=False)
+            except Exception as e:          # e.g. half-COO overflow on this rank only
+                err = e
+            comm.agree(err, "stage A (pair kernels)")
+            flag = torch.tensor([ovf], dtype=torch.int64, device=dev)
+            comm.all_reduce(flag, "max")
+            if int(flag.item()) == 0:
+                break
+            eng._tri_plan(L, L.slot_target // 2)      # every rank re-plans identically
+        # the rank's partition of item2item_simRDD: both directions of ITS kept pairs, CSR by first item (the same
+        # mirror step a single GPU does for all pairs)
+        S_part = eng.tri_scatter(coo, rowcnt, stats[2], n, L)
+        tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
+        comm.all_reduce(tot)
+        it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
+        light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
+    S, E, pt = _stage_b(eng, comm, coo, rowcnt, stats[2], L, k, rank, world, n)
+    # ---- stage C: replicated (a few ms)
+    with eng.timed("stage_c"):
+        n_top, choice, mp = eng.select(E, private)
+        G = eng.alterego(mp)
+        n_prof = eng.n_profiles(G)
+    return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * L.half_contrib,
+                n_contrib_light=light_local, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
+                n_rows=G.n_rows, n_profiles=n_prof, knn_entries=int(E.kcnt.sum().item()),
+                S=S, S_part=S_part, E=E, G=G, choice=choice, map=mp)
+
+
+class _Rows(object):
+    """AlterEgo rows gathered from the ranks (same attributes as the engine's GenResult)"""
+    pass
+
+
+def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot_target=640):
+    """stage A -> B -> C once over USER-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard
+    partial similarities"): eng.R holds the complete profiles of this rank's users -- users [user_lo, user_lo + n_users) of
+    the whole data set, items indexed globally -- instead of a replica of all ratings.
+
+    Stage A: every rank sums its users' contributions.  Item statistics: the shares [I][5] are all-gathered (the all-gather
+    of per-item norms) and added up in rank order, the adjusted norm exactly.  Pairs: the pair kernel runs over the rank's
+    users in "raw" mode and emits, per pair two of its users co-rated, the partial dot product (an exact (value, error)
+    pair), n_ij and the mutuality; the 32-byte records are sorted by pair key and sent to the rank that owns the pair's
+    lower item (all-to-all of sparse partials = the reduce-scatter: every rank receives only the shares of its own pairs,
+    added up on arrival -- the dot product exactly, so the result does not depend on the number of ranks); the owner
+    finishes the pair (cosine, significance weighting, zero filter).  From there the step is the item-sharded one: the kept
+    pairs are exchanged for stage B, the path enumeration is sharded by start item.  Stage C runs over the rank's own users
+    and the AlterEgo rows are concatenated in rank (= user) order."""
+    comm = Comm(dist, group)
+    rank, world = comm.rank, comm.world
+    I = eng.R.n_items
+    dev = eng.dev
+    with eng.timed("stage_a"):
+        u_avg, u_norm, partial = eng.stats_partial()
+        with eng.timed("stats_gather"):
+            parts = comm.all_gather_fixed(partial)
+        info = eng.stats_merge(parts)
+        # the layout of the rank's pair kernel orders items by their LOCAL rater counts (its partner bounds are local);
+        # the item averages behind the mutuality flags are the global ones
+        info_loc = info.clone()
+        if I:
+            info_loc[:I, 3] = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1]).double()
+        stats_loc = (u_avg, u_norm, info_loc, None, None)
+        err, out = None, None
+        try:
+            L = eng.tri_layout(stats_loc, slot_target, ch_min=max(64, eng.R.n_users + 2))       # no heavy set
+            out = eng.tri_pairs(method, cap, stats_loc, L, do_heavy=False, raw=True)
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage A (pair kernels)")
+        coo_raw, _, n_raw, _ = out
+        rec = eng.partial_records(coo_raw, n_raw, world)         # grouped by owner of the lower item (key = lower << 32 | higher)
+        del coo_raw, out
+        with eng.timed("exchange_partials"):
+            thr = torch.tensor([(I * r // world) << 32 for r in range(1, world)], dtype=torch.int64, device=dev)
+            # (the keys are ordered group-wise only: "key < first key of rank r" is still monotone along the array)
+            inner = torch.searchsorted(rec[:, 0].contiguous(), thr).tolist() if n_raw else [0] * (world - 1)
+            cuts = [0] + [int(x) for x in inner] + [n_raw]
+            got = comm.all_to_all_rows(rec, cuts)
+        err = None
+        try:
+            got = eng.sort_records(got)                          # stable: the shares of a pair stay in rank order
+            coo, rowcnt, n, n_unordered = eng.merge_records(got, method, cap)
+            S_part = eng.tri_scatter(coo, rowcnt, info, n, L)
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage A (merge of the partial similarities)")
+        tot = torch.tensor([n_unordered, n, L.half_contrib], dtype=torch.int64, device=dev)
+        comm.all_reduce(tot)
+    S, E, pt = _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n)
+    S.u_avg = None                         # user info stays with the rank that holds the users
+    with eng.timed("stage_c"):
+        n_top, choice, mp = eng.select(E, private)
+        Gl = eng.alterego(mp)
+        G = _Rows()
+        G.user = comm.all_gather_var(Gl.user.long() + int(user_lo))
+        G.item = comm.all_gather_var(Gl.item)
+        G.rating = comm.all_gather_var(Gl.rating)
+        G.time = comm.all_gather_var(Gl.time)
+        G.n_rows = int(G.user.numel())
+        prof = torch.tensor([eng.n_profiles(Gl)], dtype=torch.int64, device=dev)
+        comm.all_reduce(prof)
+    return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * int(tot[2].item()),
+                n_contrib_light=2 * L.half_contrib, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
+                n_rows=G.n_rows, n_profiles=int(prof.item()), knn_entries=int(E.kcnt.sum().item()),
+                S=S, S_part=S_part, E=E, G=G, G_local=Gl, choice=choice, map=mp, info=info)
+
+
+def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
+    """stage B of a sharded step: coo / rowcnt = the n_local kept pairs this rank holds (any orientation, every unordered pair
+    on exactly one rank).  Returns (S: the full similarity matrix, E: the extension with the candidate arrays of ALL starts,
+    [paths, candidates] over all ranks)."""
+    dev = eng.dev
+    # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
+    # ranges balanced by the exact per-start path counts
+    with eng.timed("stage_b"):
+        # The extension needs the whole similarity matrix on every rank (the reference broadcasts its knn tables,
+        # utils/assist.py:88-101): the ranks' COO parts are exchanged here -- per-item row counts all-reduced, the
+        # compacted parts (one index list for the five columns) sent as ONE variable-length all-gather of 24-byte
+        # records (i | j << 32, sim bits, mutu | n_ij << 32) -- and every rank mirrors the full COO into the CSR.
+        with eng.timed("exchange"):
+            comm.all_reduce(rowcnt)
+            rec = eng.pack_pairs(coo, n_local)                                  # library kernels, no torch arithmetic
+            rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
+            coo = eng.unpack_pairs(rec)
+        err = None
+        try:
+            S = eng.tri_scatter(coo, rowcnt, info, None, L)
+            E = eng.extend(S, k, full=False, start_split=(rank, world), comm=comm)
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage B (extension)")
+        comm.all_reduce(E.n_cand)
+        comm.all_reduce(E.top_end, "max")             # -1 outside the local range
+        comm.all_reduce(E.top_val)                    # 0.0 outside the local range
+        pt = torch.tensor([E.n_paths, E.n_out], dtype=torch.int64, device=dev)
+        comm.all_reduce(pt)
+    return S, E, pt
+

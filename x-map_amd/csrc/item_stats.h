@@ -12,8 +12,10 @@ namespace xmap {
 // the CSC arrays (CscSrc) or the rater records of the pair kernel (stage_a2.hip: RcSrc / RcWideSrc).
 struct CscSrc {
     const int *iuser; const float *irating; const double *u_avg;
+    static constexpr bool has_flags = false;
     __device__ __forceinline__ void load(long long p, double &r, int &u) const { r = (double)irating[p]; u = iuser[p]; }
     __device__ __forceinline__ double uavg(int u) const { return u_avg[u]; }
+    __device__ __forceinline__ void set_flag(long long, bool) const {}
 };
 template <int G, typename Src>
 __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, const long long *iptr, const Src src,
@@ -104,6 +106,12 @@ __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, 
             norms[(size_t)I + i] = sqrt(a2);
         }
     }
+    if (Src::has_flags)     // the rater records carry `rating >= item average` (retrieve_path_info, baselinerSim.py:97-113)
+        for (long long p = p0 + gl; p < p1; p += G) {
+            double r; int u;
+            src.load(p, r, u);
+            src.set_flag(p, r >= avg);
+        }
     if (!ia_user) return;   // the flag-packed copies are read by the complete-rows formulation only
     for (long long p = p0 + gl; p < p1; p += G) {
         double r; int u;

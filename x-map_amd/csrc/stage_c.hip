@@ -33,12 +33,16 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
                                                   int *cnt_t, int *cnt_m, const long long *off_t,
                                                   const long long *off_m, long long n_t_total, int *out_user,
                                                   int *out_item, double *out_rating, long long *out_time,
-                                                  unsigned long long *n_prof) {
+                                                  unsigned long long *n_prof, int min_len) {
     long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = u < U;
+    bool in = u < U;
     if (FILL && !in) return;      // (the count pass keeps the whole wave: it ends in a ballot)
     long long a = 0, b = 0;
     if (in) { a = ptr[u]; b = ptr[u + 1]; }
+    if (b - a < min_len) {        // shorter profiles are k_alterego_grp's
+        if (FILL) return;
+        in = false; b = a;
+    }
     long long ot = FILL ? off_t[u] : 0, om = FILL ? n_t_total + off_m[u] : 0;
     int ct = 0, cm = 0;
     for (long long e = a; e < b; e++) {
@@ -75,6 +79,100 @@ __global__ __launch_bounds__(256) void k_alterego(long long U, const long long *
     }
 }
 
+// The same rows for profiles of at most 64 ratings (all but ~0.05 % at BASELINE configs[1]), one entry per lane: four
+// profiles of up to 16 ratings per wave, one per 16-lane group, longer ones on the whole wave -- coalesced loads of the
+// profile, the first-seen grouping of avoid_duplicate_ratings (generator.py:123-138) by broadcasting every entry through
+// its group (sums in profile order, like the reference's list), rows written in runs.  One thread per user -- the form
+// above, kept for profiles beyond a wave -- walked its profile alone with uncoalesced loads and re-scanned it per mapped
+// entry: 1.1 ms for the fill pass, 3 ms on a slow day (driver run of round 2).
+constexpr int AE_WAVE_MAX = 64;
+template <bool FILL, int G>
+__device__ __forceinline__ void alterego_group(bool on, long long u, long long a, int d, int gl, int gbase, const int *item,
+                                               const float *rating, const long long *time, const uint8_t *flags, const int *map,
+                                               int *cnt_t, int *cnt_m, const long long *off_t, const long long *off_m,
+                                               long long n_t_total, int *out_user, int *out_item, double *out_rating,
+                                               long long *out_time, int &any) {
+    const bool act = on && gl < d;
+    int it = -1, m = -1;
+    float r = 0.f;
+    bool is_t = false;
+    if (act) {
+        it = item[a + gl];
+        r = rating[a + gl];
+        is_t = (flags[it] & 2) != 0;          // "T:" in iid: pass-through row
+        m = map[it];
+    }
+    bool first = act && m >= 0;
+    double s = 0.0;
+    int n = 0;
+    const int dmax = G == 64 ? d : 16;
+    for (int t = 0; t < dmax; t++) {          // entry t of the group's profile, broadcast
+        const int mt = __shfl(m, gbase + t, 64);
+        const float rt = __shfl(r, gbase + t, 64);
+        if (act && m >= 0 && mt == m) {
+            if (t < gl) first = false;
+            s += (double)rt; n++;
+        }
+    }
+    const unsigned long long gmask = G == 64 ? ~0ull : (0xffffull << gbase);
+    const unsigned long long bt = __ballot(act && is_t) & gmask, bm = __ballot(first) & gmask;
+    const unsigned long long lt = lanemask_lt();
+    if (!FILL) {
+        if (on && gl == 0) {
+            const int ct = __popcll(bt), cm = __popcll(bm);
+            cnt_t[u] = ct; cnt_m[u] = cm;
+            any = (ct + cm) > 0;
+        }
+        return;
+    }
+    if (!on) return;
+    if (act && is_t) {
+        const long long o = off_t[u] + __popcll(bt & lt);
+        out_user[o] = (int)u; out_item[o] = it; out_rating[o] = (double)r; out_time[o] = time[a + gl];
+    }
+    if (first) {
+        const long long o = n_t_total + off_m[u] + __popcll(bm & lt);
+        out_user[o] = (int)u; out_item[o] = m; out_rating[o] = s / (double)n;      // np.mean of the group (fp64, generator.py:134)
+        out_time[o] = time[a + gl];
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_alterego_grp(long long U, const long long *ptr, const int *item, const float *rating,
+                                                      const long long *time, const uint8_t *flags, const int *map, int *cnt_t,
+                                                      int *cnt_m, const long long *off_t, const long long *off_m,
+                                                      long long n_t_total, int *out_user, int *out_item, double *out_rating,
+                                                      long long *out_time, unsigned long long *n_prof) {
+    const long long u0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (u0 >= U) return;
+    const int lane = lane_id();
+    int any = 0;
+    {
+        const int g = lane >> 4;
+        const long long u = u0 + g;
+        long long a = 0;
+        int d = 0;
+        if (u < U) { a = ptr[u]; d = (int)min(ptr[u + 1] - a, (long long)(AE_WAVE_MAX + 1)); }
+        alterego_group<FILL, 16>(u < U && d <= 16, u, a, d, lane & 15, g << 4, item, rating, time, flags, map, cnt_t, cnt_m, off_t,
+                                 off_m, n_t_total, out_user, out_item, out_rating, out_time, any);
+    }
+    for (int q = 0; q < 4; q++) {
+        const long long u = u0 + q;
+        if (u >= U) break;
+        const long long a = ptr[u];
+        const long long dl = ptr[u + 1] - a;
+        if (dl <= 16 || dl > AE_WAVE_MAX) continue;
+        int any1 = 0;
+        alterego_group<FILL, 64>(true, u, a, (int)dl, lane, 0, item, rating, time, flags, map, cnt_t, cnt_m, off_t, off_m, n_t_total,
+                                 out_user, out_item, out_rating, out_time, any1);
+        any += any1;        // (lane 0 carries it)
+    }
+    if (!FILL && n_prof) {
+        const int tot = (int)wave_sum_ll((long long)any);
+        if (lane == 0 && tot) atomicAdd(n_prof, (unsigned long long)tot);
+    }
+}
+
 }  // namespace xmap
 
 using namespace xmap;
@@ -97,10 +195,15 @@ int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_
                         int64_t *d_profiles /* zeroed by the caller, or NULL */) {
     XM_ARG(R && map_src2tgt && cnt_t && cnt_m);
     if (R->n_users == 0) return XMAP_OK;
-    k_alterego<false><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+    k_alterego_grp<false><<<dim3((unsigned)((R->n_users + 15) / 16)), dim3(256), 0, (hipStream_t)stream>>>(
         R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
         R->flags, map_src2tgt, cnt_t, cnt_m, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
         (unsigned long long *)d_profiles);
+    XM_LAUNCH_CHECK();
+    k_alterego<false><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(       // profiles beyond a wave
+        R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
+        R->flags, map_src2tgt, cnt_t, cnt_m, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+        (unsigned long long *)d_profiles, AE_WAVE_MAX + 1);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -110,10 +213,15 @@ int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_s
                        int64_t *out_time) {
     XM_ARG(R && map_src2tgt && off_t && off_m && out_user && out_item && out_rating && out_time);
     if (R->n_users == 0) return XMAP_OK;
-    k_alterego<true><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+    k_alterego_grp<true><<<dim3((unsigned)((R->n_users + 15) / 16)), dim3(256), 0, (hipStream_t)stream>>>(
         R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
         R->flags, map_src2tgt, nullptr, nullptr, (const long long *)off_t, (const long long *)off_m, n_t_total, out_user,
         out_item, out_rating, (long long *)out_time, nullptr);
+    XM_LAUNCH_CHECK();
+    k_alterego<true><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
+        R->flags, map_src2tgt, nullptr, nullptr, (const long long *)off_t, (const long long *)off_m, n_t_total, out_user,
+        out_item, out_rating, (long long *)out_time, nullptr, AE_WAVE_MAX + 1);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

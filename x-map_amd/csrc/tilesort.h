@@ -110,21 +110,31 @@ __device__ __forceinline__ void block_scan_2(const unsigned *cnt, unsigned *off,
 }
 
 // records of RW 64-bit words, key = low 32 bits of word 0
+constexpr unsigned NOKEY = 0xffffffffu;
 template <int RW>
 struct RecLoader {
-    const unsigned long long *in;
-    __device__ __forceinline__ bool key(long long idx, unsigned &k) const { k = (unsigned)in[idx * RW]; return true; }
+    const unsigned long long *__restrict__ in;
+    static constexpr bool listed = false;                 // level A: chunk c = records [c CH, (c + 1) CH)
+    __device__ __forceinline__ bool chunk(long long n_in, long long &i0, long long &i1) const {
+        i0 = (long long)blockIdx.x * CH;
+        i1 = min(n_in, i0 + CH);
+        return true;
+    }
+    __device__ __forceinline__ unsigned key(long long idx) const { return (unsigned)in[idx * RW]; }
     __device__ __forceinline__ void get(long long idx, unsigned long long (&w)[RW]) const {
 #pragma unroll
         for (int x = 0; x < RW; x++) w[x] = in[idx * RW + x];
     }
+    __device__ __forceinline__ void extra(long long, long long) const {}
 };
 
-// One binning level.  LEVEL_B = false: chunk c of the loader's index space [0, n_in), buckets = level-A buckets.
+// One binning level.  LEVEL_B = false: a chunk of the loader's index space (L.chunk), buckets = level-A buckets.
 // LEVEL_B = true: a listed chunk of a level-A bucket's range in the input (position space), buckets = the bucket's fine
 // tiles (small part) + their large keys.
+// Memory-level parallelism is what the kernel lives on: the EPT keys of a thread are requested together, then their tile
+// words, then the ranks are taken; the copy-out gathers UNC records before it stores them.
 template <int RW, bool LEVEL_B, typename Loader>
-__global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, unsigned long long *out) {
+__global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, unsigned long long *__restrict__ out) {
     constexpr int NBK = LEVEL_B ? 2 * NB : NA_MAX;
     __shared__ unsigned hist[NBK];
     __shared__ unsigned off[NBK + 1];
@@ -143,24 +153,26 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
         i0 = G.tile_pos0[t0] + (long long)c.y * CH;
         i1 = min(G.tile_pos0[t1], i0 + CH);
     } else {
-        i0 = (long long)blockIdx.x * CH;
-        i1 = min(n_in, i0 + CH);
+        if (!L.chunk(n_in, i0, i1)) return;
     }
     const int nbk = LEVEL_B ? 2 * NB : G.NA;
     for (int b = tid; b < nbk; b += BT) hist[b] = 0u;
     __syncthreads();
-    unsigned br[EPT];       // bucket << 16 | rank, or 0xffffffff
+    unsigned kk[EPT], br[EPT];       // key, then bucket << 16 | rank (0xffffffff: no record)
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
         const long long idx = i0 + r * BT + tid;
-        br[r] = 0xffffffffu;
-        unsigned k;
-        if (idx < i1 && L.key(idx, k)) {
-            const unsigned tkv = G.tk[k];
-            const int t = (int)(tkv & 0x7fffffffu);
-            const int b = LEVEL_B ? ((t & (NB - 1)) | ((tkv >> 31) ? NB : 0)) : (t >> NB_LOG);
-            br[r] = ((unsigned)b << 16) | atomicAdd(&hist[b], 1u);
-        }
+        kk[r] = idx < i1 ? L.key(idx) : NOKEY;
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; r++) br[r] = kk[r] != NOKEY ? G.tk[kk[r]] : 0u;
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        if (kk[r] == NOKEY) { br[r] = 0xffffffffu; continue; }
+        const unsigned tkv = br[r];
+        const int t = (int)(tkv & 0x7fffffffu);
+        const int b = LEVEL_B ? ((t & (NB - 1)) | ((tkv >> 31) ? NB : 0)) : (t >> NB_LOG);
+        br[r] = ((unsigned)b << 16) | atomicAdd(&hist[b], 1u);
     }
     __syncthreads();
     block_scan_2(hist, off, nbk, wsum);
@@ -188,14 +200,29 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
     }
     __syncthreads();
     const int n = (int)off[nbk];
-    for (int s = tid; s < n; s += BT) {
-        const unsigned b = sbk[s];
-        unsigned long long w[RW];
-        L.get(i0 + perm[s], w);
-        unsigned long long *o = out + (size_t)(gbase[b] + (long long)(s - off[b])) * RW;
+    constexpr int UNC = 4;
+    for (int s0 = tid; s0 < n; s0 += BT * UNC) {
+        unsigned long long w[UNC][RW];
+        long long dst[UNC];
 #pragma unroll
-        for (int x = 0; x < RW; x++) o[x] = w[x];
+        for (int u = 0; u < UNC; u++) {
+            const int s = s0 + u * BT;
+            dst[u] = -1;
+            if (s < n) {
+                const unsigned b = sbk[s];
+                dst[u] = gbase[b] + (long long)(s - off[b]);
+                L.get(i0 + perm[s], w[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNC; u++) {
+            if (dst[u] < 0) continue;
+            unsigned long long *o = out + (size_t)dst[u] * RW;
+#pragma unroll
+            for (int x = 0; x < RW; x++) o[x] = w[u][x];
+        }
     }
+    L.extra(i0, i1);
 }
 
 // what a level-C workgroup knows about its tile
