@@ -460,6 +460,9 @@ def main():
     wall = time.time() - t_start
     tm = eng.timer_ms()
     eng.timers = None
+    if os.environ.get("XMAP_BENCH_DUMP") == "1" and rank == 0:      # per-step values of every bracket (diagnosis)
+        for n_, v_ in sorted(tm.items()):
+            log("timer %-14s %s" % (n_, " ".join("%.3f" % x for x in v_)))
     if dist:
         w = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)

@@ -183,7 +183,7 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
  *   k_sort_profiles3  profiles sorted heaviest first: ub (8 B per entry; 16 B with rating64) and one sort record per entry
  *                     {item, position, rating, user} (16 B; 24 B with rating64)
  *   tile sort         (csrc/tilesort.h) sort records -> rater records rc in item order (any order inside an item), W+ summed
- *   k_item_stats3 ..  get_universal_item_info (:40-82) from the rater records -> info, norms; items with more than 4096
+ *   k_item_stats3 ..  get_universal_item_info (:40-82) from the rater records -> info, norms; items with more than 512
  *                     raters in chunks of 2048 on a wave each, merged in chunk order
  *   flags             `rating >= item average` (retrieve_path_info, :97-113) into the rater records and the profile copy
  * The CSC arrays (R->item_user / item_rating) are neither read nor written; R->item_ptr (= item_ptr) is written.
@@ -494,7 +494,8 @@ int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32
  * ("T:" in iid), cnt_m[u] AlterEgo rows (distinct mapped targets, first-seen order).  fill pass writes
  * rows [off_t[u]..) and [n_t_total + off_m[u]..): (user, item, rating = mean fp32, time of first row). */
 int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m,
-                        int64_t *d_profiles /* [1] device, zeroed by the caller: += users with at least one output row; or NULL */);
+                        int64_t *d_profiles /* [64] device, zeroed by the caller: the users with at least one output row are
+                                               added to these 64 counters (their sum is the number of profiles); or NULL */);
 int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, const int64_t *off_t,
                        const int64_t *off_m, int64_t n_t_total, int32_t *out_user, int32_t *out_item,
                        double *out_rating, int64_t *out_time);

@@ -17,13 +17,14 @@ struct CscSrc {
     __device__ __forceinline__ double uavg(int u) const { return u_avg[u]; }
     __device__ __forceinline__ void set_flag(long long, bool) const {}
 };
-template <int G, typename Src>
+// POP = false: the caller never brings an item with more than 64 * 8 raters (its 8-way unrolled walk is compiled out)
+template <int G, typename Src, bool POP = true>
 __device__ __forceinline__ void item_stats_group(bool on, int i, int gl, int I, const long long *iptr, const Src src,
                                                  double *info, double *norms, int *ia_user, double *partial = nullptr) {
     long long p0 = 0, p1 = 0;
     if (on) { p0 = iptr[i]; p1 = iptr[i + 1]; }
     double s = 0.0, q = 0.0, a2 = 0.0, a2lo = 0.0;
-    if (G < 64 || p1 - p0 <= 64 * 8) {
+    if (G < 64 || !POP || p1 - p0 <= 64 * 8) {
         for (long long p = p0 + gl; p < p1; p += G) {
             double r; int u;
             src.load(p, r, u);

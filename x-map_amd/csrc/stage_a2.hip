@@ -1260,11 +1260,12 @@ struct RcWideSrc {
     __device__ __forceinline__ void set_flag(long long, bool) const {}
 };
 
-// Items with more than STAT_BIG raters (up to 1e5 at BASELINE configs[1]: one wave walking them was the kernel's tail) are
+// Items with more than STAT_BIG raters (up to 1e5 at BASELINE configs[1]: one wave walking them was the kernel's tail, and
+// the unrolled walk they need cost every wave of the kernel its registers) are
 // cut into chunks of STAT_CHK raters: k_item_stats3 lists them, k_item_chunks sums every chunk on a wave of its own,
 // k_item_big adds an item's chunk sums up in chunk order (the adjusted norm exactly) and finishes it, k_item_big_flags sets
 // the flags of its rater records.
-constexpr int STAT_BIG = 4096;
+constexpr int STAT_BIG = 512;
 constexpr int STAT_CHK = 2048;
 struct BigList {
     unsigned *counters;       // [0] chunks listed, [1] big items listed
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_item_stats3(int I, const long long *ipt
     {
         const int i = i0 + (lane >> 4);
         const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
-        item_stats_group<16>(on, i, lane & 15, I, iptr, src, info, norms, nullptr, nullptr);
+        item_stats_group<16, Src, false>(on, i, lane & 15, I, iptr, src, info, norms, nullptr, nullptr);
     }
     for (int t = 0; t < 4; t++) {
         const int i = i0 + t;
@@ -1301,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_item_stats3(int I, const long long *ipt
             }
             continue;
         }
-        item_stats_group<64>(true, i, lane, I, iptr, src, info, norms, nullptr, nullptr);
+        item_stats_group<64, Src, false>(true, i, lane, I, iptr, src, info, norms, nullptr, nullptr);
     }
 }
 
@@ -1408,41 +1409,45 @@ struct CooLoader {
     const int *__restrict__ coo_mutu; const int *__restrict__ coo_nij;
     const longlong2 *chunks; const unsigned *n_chunks;
     const long long *row_ptr; int *fill; int *col; double *sim; int *mutu; int *nij;
-    static constexpr bool listed = true;
     __device__ __forceinline__ bool chunk(long long, long long &i0, long long &i1) const {
         if (blockIdx.x >= *n_chunks) return false;
         const longlong2 c = chunks[blockIdx.x];
         i0 = c.x; i1 = c.x + c.y;
         return true;
     }
-    __device__ __forceinline__ unsigned key(long long idx) const { return (unsigned)coo_j[idx]; }
-    __device__ __forceinline__ void get(long long idx, unsigned long long (&w)[3]) const {
+    __device__ __forceinline__ void load(long long idx, unsigned long long (&w)[3]) const {
         w[0] = (unsigned long long)(unsigned)coo_j[idx] | ((unsigned long long)(unsigned)coo_i[idx] << 32);
         w[1] = (unsigned long long)__double_as_longlong(coo_sim[idx]);
         w[2] = (unsigned long long)(unsigned)coo_mutu[idx] | ((unsigned long long)(unsigned)coo_nij[idx] << 32);
     }
-    __device__ __forceinline__ void extra(long long i0, long long i1) const {
+    // own half of the chunk: for a fixed r the lanes of a wave hold consecutive COO slots
+    __device__ __forceinline__ void extra(long long, const unsigned long long (&w)[ts::Chunk<3>::EPT][3],
+                                          const bool (&on)[ts::Chunk<3>::EPT]) const {
+        constexpr int E = ts::Chunk<3>::EPT;
         const int lane = lane_id();
-        for (long long g = i0 + (long long)(threadIdx.x >> 6) * 64; g < i1; g += ts::BT) {
-            const long long r = g + lane;
-            const bool valid = r < i1;
-            int i = 0, j = 0, m = 0, nn = 0;
-            double s = 0.0;
-            if (valid) { i = coo_i[r]; j = coo_j[r]; s = coo_sim[r]; m = coo_mutu[r]; nn = coo_nij[r]; }
-            const int iu = valid ? i : -1 - lane;       // inactive lanes: unique fake rows
+        int lead[E], base[E];
+        long long rp[E];
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            const int iu = on[r] ? (int)(w[r][0] >> 32) : -1 - lane;       // inactive lanes: unique fake rows
             const int prev = __shfl_up(iu, 1, 64);
             const bool leader = (lane == 0) || (prev != iu);
             const unsigned long long lm = __ballot(leader);
             const unsigned long long below = lm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-            const int lead = 63 - __clzll((long long)below);
+            lead[r] = 63 - __clzll((long long)below);
             const unsigned long long above = (lane == 63) ? 0ull : (lm >> (lane + 1));
             const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-            int base = 0;
-            if (leader && valid) base = atomicAdd(&fill[iu], next - lane);
-            base = __shfl(base, lead, 64);
-            if (valid) {
-                const long long a = row_ptr[iu] + base + (lane - lead);
-                col[a] = j; sim[a] = s; mutu[a] = m; nij[a] = nn;
+            base[r] = 0; rp[r] = 0;
+            if (leader && on[r]) base[r] = atomicAdd(&fill[iu], next - lane);
+            if (on[r]) rp[r] = row_ptr[iu];
+        }
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            const int bs = __shfl(base[r], lead[r], 64);
+            if (on[r]) {
+                const long long a = rp[r] + bs + (lane - lead[r]);
+                col[a] = (int)(unsigned)w[r][0]; sim[a] = __longlong_as_double((long long)w[r][1]);
+                mutu[a] = (int)(unsigned)w[r][2]; nij[a] = (int)(w[r][2] >> 32);
             }
         }
     }
@@ -1452,18 +1457,19 @@ struct CooLoader {
 // (cur == NULL: one range of n_fill records)
 __global__ __launch_bounds__(256) void k_coo_chunks(int n_shards, long long shard_cap, const unsigned long long *cur, long long n_fill,
                                                     longlong2 *chunks, unsigned *n_chunks, long long cap) {
+    constexpr int CH = ts::Chunk<3>::CH;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_shards) return;
     long long f = cur ? (long long)cur[s] : n_fill;
     if (f > shard_cap) f = shard_cap;
-    const int nch = (int)((f + ts::CH - 1) / ts::CH);
+    const int nch = (int)((f + CH - 1) / CH);
     if (nch == 0) return;
     const unsigned base = atomicAdd(n_chunks, (unsigned)nch);
     for (int x = 0; x < nch; x++)
         if ((long long)base + x < cap) {
             longlong2 c;
-            c.x = (long long)s * shard_cap + (long long)x * ts::CH;
-            c.y = min((long long)ts::CH, f - (long long)x * ts::CH);
+            c.x = (long long)s * shard_cap + (long long)x * CH;
+            c.y = min((long long)CH, f - (long long)x * CH);
             chunks[base + x] = c;
         }
 }
@@ -1558,8 +1564,8 @@ static SideStreams *side_streams() {
 // ---- tile sort: host side ---------------------------------------------------------------------------------------------
 namespace {
 // geometry for K keys and M records (tilesort.h): tile measure 2^ts_log, key weight KW, T = NA * NB tiles
-void ts_geometry(int K, long long M, ts::Geo &G) {
-    G.K = K; G.M = M;
+void ts_geometry(int K, long long M, int ch, ts::Geo &G) {
+    G.K = K; G.M = M; G.ch = ch;
     G.ts_log = 11;
     for (;;) {
         const long long TS = 1ll << G.ts_log;
@@ -1583,7 +1589,7 @@ void ts_geometry(int K, long long M, ts::Geo &G) {
 // tables of one sort (arena temporaries of the calling entry point) + plan and chunk kernels
 int ts_prepare(hipStream_t st, ts::Geo &G, const long long *ptr) {
     G.ptr = ptr;
-    G.clist_cap = G.M / ts::CH + G.NA + 1;
+    G.clist_cap = G.M / G.ch + G.NA + 1;
     G.slist_cap = G.M / ts::SL + (G.M >> G.ts_log) + 2;
     XM_HIP(xm_malloc_async((void **)&G.tk, sizeof(unsigned) * (size_t)(G.K > 0 ? G.K : 1), st));
     XM_HIP(xm_malloc_async((void **)&G.tile_key0, sizeof(int) * ((size_t)G.T + 1), st));
@@ -2014,10 +2020,10 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
     XM_HIP(hipMemsetAsync(Wp, 0, sizeof(uint64_t) * In, st));
     if (nnz > 0 && I > 0) {
         ts::Geo G;
-        ts_geometry(I, nnz, G);
+        ts_geometry(I, nnz, wide ? ts::Chunk<3>::CH : ts::Chunk<2>::CH, G);
         rcode = ts_prepare(st, G, (const long long *)item_ptr);
         if (rcode) return rcode;
-        const dim3 gridA((unsigned)((nnz + ts::CH - 1) / ts::CH)), gridB((unsigned)G.clist_cap), gridL((unsigned)G.slist_cap);
+        const dim3 gridA((unsigned)((nnz + G.ch - 1) / G.ch)), gridB((unsigned)G.clist_cap), gridL((unsigned)G.slist_cap);
         if (wide) {
             ts::RecLoader<3> LA{(const unsigned long long *)srec}, LB{(const unsigned long long *)bufA};
             ts::k_ts_bin<3, false, ts::RecLoader<3>><<<gridA, dim3(ts::BT), 0, st>>>(G, LA, nnz, (unsigned long long *)bufA);
@@ -2111,13 +2117,13 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
     if (n_pairs == 0 || I == 0 || coo_cap == 0) return XMAP_OK;
     XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)I, st));
     ts::Geo G;
-    ts_geometry(I, n_pairs, G);
+    ts_geometry(I, n_pairs, ts::Chunk<3>::CH, G);
     rcode = ts_prepare(st, G, (const long long *)mptr);
     if (rcode) return rcode;
     // the COO's chunks: from the shard cursors of the pair kernels, or one range of n_pairs records
     const int n_shards = d_shards ? COO_SHARDS : 1;
     const long long shard_cap = d_shards ? coo_cap / COO_SHARDS : coo_cap;
-    const long long chunk_cap = n_pairs / ts::CH + n_shards + 1;
+    const long long chunk_cap = n_pairs / ts::Chunk<3>::CH + n_shards + 1;
     longlong2 *chunks = nullptr;
     unsigned *n_chunks = nullptr;
     XM_HIP(xm_malloc_async((void **)&chunks, sizeof(longlong2) * (size_t)chunk_cap, st));

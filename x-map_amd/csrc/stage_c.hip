@@ -25,73 +25,21 @@ __global__ __launch_bounds__(256) void k_select_map(int I, int private_flag, con
     choice[s] = c;
 }
 
-// build_alterEgo (generator.py:140-157): one thread per user; profiles are short, the grouping of
-// avoid_duplicate_ratings (generator.py:123-138) is done by re-scanning the profile (first-seen order).
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_alterego(long long U, const long long *ptr, const int *item, const float *rating,
-                                                  const long long *time, const uint8_t *flags, const int *map,
-                                                  int *cnt_t, int *cnt_m, const long long *off_t,
-                                                  const long long *off_m, long long n_t_total, int *out_user,
-                                                  int *out_item, double *out_rating, long long *out_time,
-                                                  unsigned long long *n_prof, int min_len) {
-    long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool in = u < U;
-    if (FILL && !in) return;      // (the count pass keeps the whole wave: it ends in a ballot)
-    long long a = 0, b = 0;
-    if (in) { a = ptr[u]; b = ptr[u + 1]; }
-    if (b - a < min_len) {        // shorter profiles are k_alterego_grp's
-        if (FILL) return;
-        in = false; b = a;
-    }
-    long long ot = FILL ? off_t[u] : 0, om = FILL ? n_t_total + off_m[u] : 0;
-    int ct = 0, cm = 0;
-    for (long long e = a; e < b; e++) {
-        int it = item[e];
-        if (flags[it] & 2) {  // "T:" in iid: pass-through row
-            if (FILL) {
-                out_user[ot] = (int)u; out_item[ot] = it; out_rating[ot] = (double)rating[e]; out_time[ot] = time[e];
-                ot++;
-            }
-            ct++;
-        }
-        int m = map[it];
-        if (m < 0) continue;
-        bool first = true;
-        for (long long f = a; f < e; f++)
-            if (map[item[f]] == m) { first = false; break; }
-        if (!first) continue;
-        if (FILL) {
-            double s = 0.0;
-            int n = 0;
-            for (long long f = e; f < b; f++)
-                if (map[item[f]] == m) { s += (double)rating[f]; n++; }
-            out_user[om] = (int)u; out_item[om] = m; out_rating[om] = s / (double)n;      // np.mean of the group (fp64, generator.py:134)
-            out_time[om] = time[e];
-            om++;
-        }
-        cm++;
-    }
-    if (!FILL) {
-        if (in) { cnt_t[u] = ct; cnt_m[u] = cm; }
-        // users with at least one row: the profiles of the output (one atomic per wave)
-        const unsigned long long any = __ballot(ct + cm > 0);
-        if (n_prof && any && lane_id() == 0) atomicAdd(n_prof, (unsigned long long)__popcll(any));
-    }
-}
+// build_alterEgo (generator.py:140-157), one profile entry per lane: four profiles of up to 16 ratings per wave, one per
+// 16-lane group (90 % of the users at BASELINE configs[1]), longer ones on the whole wave in chunks of 64 -- coalesced
+// loads of the profile; the first-seen grouping of avoid_duplicate_ratings (generator.py:123-138) by broadcasting every
+// entry through its group (sums in profile order, like the reference's list); rows written in runs.  Rounds 1-2 gave every
+// user ONE thread that walked the profile alone and re-scanned it per mapped entry: 1.1 ms for the fill pass, 3 ms under a
+// long run (driver run of round 2), and a tail of users with long profiles.
+// PROF_SHARDS counters for the users with output rows (one word would serialise an atomic per wave).
+constexpr int PROF_SHARDS = 64;
 
-// The same rows for profiles of at most 64 ratings (all but ~0.05 % at BASELINE configs[1]), one entry per lane: four
-// profiles of up to 16 ratings per wave, one per 16-lane group, longer ones on the whole wave -- coalesced loads of the
-// profile, the first-seen grouping of avoid_duplicate_ratings (generator.py:123-138) by broadcasting every entry through
-// its group (sums in profile order, like the reference's list), rows written in runs.  One thread per user -- the form
-// above, kept for profiles beyond a wave -- walked its profile alone with uncoalesced loads and re-scanned it per mapped
-// entry: 1.1 ms for the fill pass, 3 ms on a slow day (driver run of round 2).
-constexpr int AE_WAVE_MAX = 64;
-template <bool FILL, int G>
-__device__ __forceinline__ void alterego_group(bool on, long long u, long long a, int d, int gl, int gbase, const int *item,
-                                               const float *rating, const long long *time, const uint8_t *flags, const int *map,
-                                               int *cnt_t, int *cnt_m, const long long *off_t, const long long *off_m,
-                                               long long n_t_total, int *out_user, int *out_item, double *out_rating,
-                                               long long *out_time, int &any) {
+template <bool FILL>
+__device__ __forceinline__ void alterego_group16(bool on, long long u, long long a, int d, int gl, int gbase, const int *item,
+                                                 const float *rating, const long long *time, const uint8_t *flags,
+                                                 const int *map, int *cnt_t, int *cnt_m, const long long *off_t,
+                                                 const long long *off_m, long long n_t_total, int *out_user, int *out_item,
+                                                 double *out_rating, long long *out_time, int &any) {
     const bool act = on && gl < d;
     int it = -1, m = -1;
     float r = 0.f;
@@ -105,8 +53,7 @@ __device__ __forceinline__ void alterego_group(bool on, long long u, long long a
     bool first = act && m >= 0;
     double s = 0.0;
     int n = 0;
-    const int dmax = G == 64 ? d : 16;
-    for (int t = 0; t < dmax; t++) {          // entry t of the group's profile, broadcast
+    for (int t = 0; t < 16; t++) {            // entry t of the group's profile, broadcast
         const int mt = __shfl(m, gbase + t, 64);
         const float rt = __shfl(r, gbase + t, 64);
         if (act && m >= 0 && mt == m) {
@@ -114,7 +61,7 @@ __device__ __forceinline__ void alterego_group(bool on, long long u, long long a
             s += (double)rt; n++;
         }
     }
-    const unsigned long long gmask = G == 64 ? ~0ull : (0xffffull << gbase);
+    const unsigned long long gmask = 0xffffull << gbase;
     const unsigned long long bt = __ballot(act && is_t) & gmask, bm = __ballot(first) & gmask;
     const unsigned long long lt = lanemask_lt();
     if (!FILL) {
@@ -137,6 +84,67 @@ __device__ __forceinline__ void alterego_group(bool on, long long u, long long a
     }
 }
 
+// a profile of any length on the whole wave, 64 entries at a time; every chunk is compared with all chunks (the earlier
+// ones decide "seen before", all of them add to the mean)
+template <bool FILL>
+__device__ __forceinline__ void alterego_wave(long long u, long long a, int d, int lane, const int *item, const float *rating,
+                                              const long long *time, const uint8_t *flags, const int *map, int *cnt_t,
+                                              int *cnt_m, const long long *off_t, const long long *off_m, long long n_t_total,
+                                              int *out_user, int *out_item, double *out_rating, long long *out_time, int &any) {
+    int ct = 0, cm = 0;
+    for (int cb = 0; cb < d; cb += 64) {
+        const int e = cb + lane;
+        const bool act = e < d;
+        int it = -1, m = -1;
+        float r = 0.f;
+        bool is_t = false;
+        if (act) {
+            it = item[a + e];
+            r = rating[a + e];
+            is_t = (flags[it] & 2) != 0;
+            m = map[it];
+        }
+        bool first = act && m >= 0;
+        double s = 0.0;
+        int n = 0;
+        for (int ob = 0; ob < d; ob += 64) {
+            int om = m;
+            float orr = r;
+            if (ob != cb) {
+                om = -1; orr = 0.f;
+                if (ob + lane < d) { om = map[item[a + ob + lane]]; orr = rating[a + ob + lane]; }
+            }
+            const int lim = min(64, d - ob);
+            for (int t = 0; t < lim; t++) {
+                const int mt = __shfl(om, t, 64);
+                const float rt = __shfl(orr, t, 64);
+                if (act && m >= 0 && mt == m) {
+                    if (ob + t < e) first = false;
+                    s += (double)rt; n++;
+                }
+            }
+        }
+        const unsigned long long bt = __ballot(act && is_t), bm = __ballot(first);
+        const unsigned long long lt = lanemask_lt();
+        if (FILL) {
+            if (act && is_t) {
+                const long long o = off_t[u] + ct + __popcll(bt & lt);
+                out_user[o] = (int)u; out_item[o] = it; out_rating[o] = (double)r; out_time[o] = time[a + e];
+            }
+            if (first) {
+                const long long o = n_t_total + off_m[u] + cm + __popcll(bm & lt);
+                out_user[o] = (int)u; out_item[o] = m; out_rating[o] = s / (double)n;
+                out_time[o] = time[a + e];
+            }
+        }
+        ct += __popcll(bt); cm += __popcll(bm);
+    }
+    if (!FILL && lane == 0) {
+        cnt_t[u] = ct; cnt_m[u] = cm;
+        any = (ct + cm) > 0;
+    }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_alterego_grp(long long U, const long long *ptr, const int *item, const float *rating,
                                                       const long long *time, const uint8_t *flags, const int *map, int *cnt_t,
@@ -151,25 +159,25 @@ __global__ __launch_bounds__(256) void k_alterego_grp(long long U, const long lo
         const int g = lane >> 4;
         const long long u = u0 + g;
         long long a = 0;
-        int d = 0;
-        if (u < U) { a = ptr[u]; d = (int)min(ptr[u + 1] - a, (long long)(AE_WAVE_MAX + 1)); }
-        alterego_group<FILL, 16>(u < U && d <= 16, u, a, d, lane & 15, g << 4, item, rating, time, flags, map, cnt_t, cnt_m, off_t,
-                                 off_m, n_t_total, out_user, out_item, out_rating, out_time, any);
+        int d = 17;
+        if (u < U) { a = ptr[u]; d = (int)min(ptr[u + 1] - a, 17ll); }
+        alterego_group16<FILL>(u < U && d <= 16, u, a, d, lane & 15, g << 4, item, rating, time, flags, map, cnt_t, cnt_m, off_t,
+                               off_m, n_t_total, out_user, out_item, out_rating, out_time, any);
     }
     for (int q = 0; q < 4; q++) {
         const long long u = u0 + q;
         if (u >= U) break;
         const long long a = ptr[u];
         const long long dl = ptr[u + 1] - a;
-        if (dl <= 16 || dl > AE_WAVE_MAX) continue;
+        if (dl <= 16) continue;
         int any1 = 0;
-        alterego_group<FILL, 64>(true, u, a, (int)dl, lane, 0, item, rating, time, flags, map, cnt_t, cnt_m, off_t, off_m, n_t_total,
-                                 out_user, out_item, out_rating, out_time, any1);
+        alterego_wave<FILL>(u, a, (int)dl, lane, item, rating, time, flags, map, cnt_t, cnt_m, off_t, off_m, n_t_total, out_user,
+                            out_item, out_rating, out_time, any1);
         any += any1;        // (lane 0 carries it)
     }
     if (!FILL && n_prof) {
         const int tot = (int)wave_sum_ll((long long)any);
-        if (lane == 0 && tot) atomicAdd(n_prof, (unsigned long long)tot);
+        if (lane == 0 && tot) atomicAdd(&n_prof[blockIdx.x & (PROF_SHARDS - 1)], (unsigned long long)tot);
     }
 }
 
@@ -192,18 +200,13 @@ int xmap_select_map(void *stream, int32_t n_items, int private_flag, const int32
 }
 
 int xmap_alterego_count(void *stream, const xmap_ratings *R, const int32_t *map_src2tgt, int32_t *cnt_t, int32_t *cnt_m,
-                        int64_t *d_profiles /* zeroed by the caller, or NULL */) {
+                        int64_t *d_profiles /* [64] zeroed by the caller, or NULL */) {
     XM_ARG(R && map_src2tgt && cnt_t && cnt_m);
     if (R->n_users == 0) return XMAP_OK;
     k_alterego_grp<false><<<dim3((unsigned)((R->n_users + 15) / 16)), dim3(256), 0, (hipStream_t)stream>>>(
         R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
         R->flags, map_src2tgt, cnt_t, cnt_m, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
         (unsigned long long *)d_profiles);
-    XM_LAUNCH_CHECK();
-    k_alterego<false><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(       // profiles beyond a wave
-        R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
-        R->flags, map_src2tgt, cnt_t, cnt_m, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-        (unsigned long long *)d_profiles, AE_WAVE_MAX + 1);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -217,11 +220,6 @@ int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_s
         R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
         R->flags, map_src2tgt, nullptr, nullptr, (const long long *)off_t, (const long long *)off_m, n_t_total, out_user,
         out_item, out_rating, (long long *)out_time, nullptr);
-    XM_LAUNCH_CHECK();
-    k_alterego<true><<<dim3((unsigned)((R->n_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        R->n_users, (const long long *)R->user_ptr, R->user_item, R->user_rating, (const long long *)R->user_time,
-        R->flags, map_src2tgt, nullptr, nullptr, (const long long *)off_t, (const long long *)off_m, n_t_total, out_user,
-        out_item, out_rating, (long long *)out_time, nullptr, AE_WAVE_MAX + 1);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

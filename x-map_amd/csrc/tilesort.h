@@ -12,9 +12,10 @@
 //   tile of key k      m[k] >> ts_log                  (T tiles, a level-A bucket = 2^NB_LOG consecutive tiles)
 //   large key          count >= tile measure: always the last key of its tile, at most one per tile; its records are
 //                      routed straight to its own position range at level B and converted in slices (k_*_large)
-//   level A / B        a workgroup bins a chunk of CH records: bucket histogram and ranks by LDS atomics, one returning
-//                      global atomic per occupied bucket for the fragment's place in the bucket's range, then the chunk is
-//                      copied out in bucket order (consecutive lanes write consecutive records of a fragment)
+//   level A / B        a workgroup bins a chunk of CH records: the records are loaded whole (coalesced) into registers,
+//                      bucket histogram and ranks by LDS atomics, one returning global atomic per occupied bucket for the
+//                      fragment's place in the bucket's range, the records staged in LDS in bucket order and copied out
+//                      (consecutive lanes write consecutive records of a fragment)
 //   level C            one workgroup per tile: the small keys' records get their rank from LDS cursors, are laid out in
 //                      final order in LDS and leave as whole rows
 //
@@ -26,12 +27,13 @@
 namespace xmap {
 namespace ts {
 
-constexpr int CH = 4096;          // records per workgroup of a binning level
 constexpr int BT = 256;           // threads of a binning workgroup
-constexpr int EPT = CH / BT;
+// records per workgroup of a binning level: the chunk is staged in LDS in bucket order (16-byte records: 64 KB, 24-byte
+// records: 48 KB; two workgroups per CU either way)
+template <int RW> struct Chunk { static constexpr int CH = RW == 2 ? 4096 : 2048; static constexpr int EPT = CH / BT; };
 constexpr int NB_LOG = 7;
 constexpr int NB = 1 << NB_LOG;   // fine tiles per level-A bucket
-constexpr int NA_MAX = 512;       // level-A buckets (LDS histogram)
+constexpr int NA_MAX = 256;       // level-A buckets (LDS histogram; two staged chunks of 16-byte records per CU need the rest)
 constexpr int CAP = 3072;         // records of a tile's small part that are laid out in LDS (more: placed directly)
 constexpr int CT = 512;           // threads of a level-C workgroup
 constexpr int NK_MAX = 520;       // keys of a tile's small part (the host chooses KW so that tile measure / KW + 1 fits)
@@ -42,6 +44,7 @@ struct Geo {
     int K;                        // keys
     long long M;                  // records (= ptr[K])
     int KW, ts_log, T, NA;
+    int ch;                       // records per chunk of the binning levels (Chunk<RW>::CH)
     const long long *ptr;         // [K + 1] first position of every key
     unsigned *tk;                 // [K] tile | large << 31
     int *tile_key0;               // [T + 1] first key of a tile
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void k_ts_chunks(Geo G) {
     if (a >= G.NA) return;
     const int t0 = a << NB_LOG, t1 = min(G.T, (a + 1) << NB_LOG);
     const long long size = G.tile_pos0[t1] - G.tile_pos0[t0];
-    const int nch = (int)((size + CH - 1) / CH);
+    const int nch = (int)((size + G.ch - 1) / G.ch);
     if (nch == 0) return;
     const unsigned base = atomicAdd(&G.counters[0], (unsigned)nch);
     for (int x = 0; x < nch; x++)
@@ -110,37 +113,35 @@ __device__ __forceinline__ void block_scan_2(const unsigned *cnt, unsigned *off,
 }
 
 // records of RW 64-bit words, key = low 32 bits of word 0
-constexpr unsigned NOKEY = 0xffffffffu;
 template <int RW>
 struct RecLoader {
     const unsigned long long *__restrict__ in;
-    static constexpr bool listed = false;                 // level A: chunk c = records [c CH, (c + 1) CH)
+    // level A: chunk c = records [c CH, (c + 1) CH)
     __device__ __forceinline__ bool chunk(long long n_in, long long &i0, long long &i1) const {
-        i0 = (long long)blockIdx.x * CH;
-        i1 = min(n_in, i0 + CH);
+        i0 = (long long)blockIdx.x * Chunk<RW>::CH;
+        i1 = min(n_in, i0 + Chunk<RW>::CH);
         return true;
     }
-    __device__ __forceinline__ unsigned key(long long idx) const { return (unsigned)in[idx * RW]; }
-    __device__ __forceinline__ void get(long long idx, unsigned long long (&w)[RW]) const {
+    __device__ __forceinline__ void load(long long idx, unsigned long long (&w)[RW]) const {
 #pragma unroll
         for (int x = 0; x < RW; x++) w[x] = in[idx * RW + x];
     }
-    __device__ __forceinline__ void extra(long long, long long) const {}
+    // what else the workgroup does with its chunk (w[r] = record i0 + r BT + tid, on[r]: there is one)
+    __device__ __forceinline__ void extra(long long, const unsigned long long (&)[Chunk<RW>::EPT][RW], const bool (&)[Chunk<RW>::EPT]) const {}
 };
 
 // One binning level.  LEVEL_B = false: a chunk of the loader's index space (L.chunk), buckets = level-A buckets.
 // LEVEL_B = true: a listed chunk of a level-A bucket's range in the input (position space), buckets = the bucket's fine
 // tiles (small part) + their large keys.
-// Memory-level parallelism is what the kernel lives on: the EPT keys of a thread are requested together, then their tile
-// words, then the ranks are taken; the copy-out gathers UNC records before it stores them.
 template <int RW, bool LEVEL_B, typename Loader>
 __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, unsigned long long *__restrict__ out) {
+    constexpr int CH = Chunk<RW>::CH, EPT = Chunk<RW>::EPT;
     constexpr int NBK = LEVEL_B ? 2 * NB : NA_MAX;
     __shared__ unsigned hist[NBK];
     __shared__ unsigned off[NBK + 1];
     __shared__ long long gbase[NBK];
     __shared__ unsigned wsum[BT / 64];
-    __shared__ unsigned short perm[CH];
+    __shared__ unsigned long long stage[CH * RW];
     __shared__ unsigned short sbk[CH];
     const int tid = threadIdx.x;
     long long i0, i1;
@@ -158,17 +159,24 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
     const int nbk = LEVEL_B ? 2 * NB : G.NA;
     for (int b = tid; b < nbk; b += BT) hist[b] = 0u;
     __syncthreads();
-    unsigned kk[EPT], br[EPT];       // key, then bucket << 16 | rank (0xffffffff: no record)
+    unsigned long long w[EPT][RW];
+    bool on[EPT];
+    unsigned br[EPT];       // tile word, then bucket << 16 | rank
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
         const long long idx = i0 + r * BT + tid;
-        kk[r] = idx < i1 ? L.key(idx) : NOKEY;
+        on[r] = idx < i1;
+        if (on[r]) L.load(idx, w[r]);
+        else {
+#pragma unroll
+            for (int x = 0; x < RW; x++) w[r][x] = 0ull;
+        }
     }
 #pragma unroll
-    for (int r = 0; r < EPT; r++) br[r] = kk[r] != NOKEY ? G.tk[kk[r]] : 0u;
+    for (int r = 0; r < EPT; r++) br[r] = on[r] ? G.tk[(unsigned)w[r][0]] : 0u;
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
-        if (kk[r] == NOKEY) { br[r] = 0xffffffffu; continue; }
+        if (!on[r]) continue;
         const unsigned tkv = br[r];
         const int t = (int)(tkv & 0x7fffffffu);
         const int b = LEVEL_B ? ((t & (NB - 1)) | ((tkv >> 31) ? NB : 0)) : (t >> NB_LOG);
@@ -193,36 +201,21 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
     }
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
-        if (br[r] == 0xffffffffu) continue;
+        if (!on[r]) continue;
         const unsigned b = br[r] >> 16, s = off[b] + (br[r] & 0xffffu);
-        perm[s] = (unsigned short)(r * BT + tid);
+#pragma unroll
+        for (int x = 0; x < RW; x++) stage[s * RW + x] = w[r][x];
         sbk[s] = (unsigned short)b;
     }
+    L.extra(i0, w, on);
     __syncthreads();
     const int n = (int)off[nbk];
-    constexpr int UNC = 4;
-    for (int s0 = tid; s0 < n; s0 += BT * UNC) {
-        unsigned long long w[UNC][RW];
-        long long dst[UNC];
+    for (int s = tid; s < n; s += BT) {
+        const unsigned b = sbk[s];
+        unsigned long long *o = out + (size_t)(gbase[b] + (long long)(s - off[b])) * RW;
 #pragma unroll
-        for (int u = 0; u < UNC; u++) {
-            const int s = s0 + u * BT;
-            dst[u] = -1;
-            if (s < n) {
-                const unsigned b = sbk[s];
-                dst[u] = gbase[b] + (long long)(s - off[b]);
-                L.get(i0 + perm[s], w[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNC; u++) {
-            if (dst[u] < 0) continue;
-            unsigned long long *o = out + (size_t)dst[u] * RW;
-#pragma unroll
-            for (int x = 0; x < RW; x++) o[x] = w[u][x];
-        }
+        for (int x = 0; x < RW; x++) o[x] = stage[s * RW + x];
     }
-    L.extra(i0, i1);
 }
 
 // what a level-C workgroup knows about its tile

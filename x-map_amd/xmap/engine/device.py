@@ -1138,7 +1138,7 @@ class Engine(object):
         cnt_m = self._empty(max(U, 1), torch.int32)
         if U == 0:
             cnt_t.zero_(); cnt_m.zero_()
-        d_prof = self._zeros(1, torch.int64)
+        d_prof = self._zeros(64, torch.int64)            # sharded counter of the users with output rows
         with self.timed("c_count"):
             check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m), vp(d_prof)))
             off_t = self._empty(U + 1, torch.int64)
@@ -1149,9 +1149,9 @@ class Engine(object):
             h = self._pinned3()
             h[0:1].copy_(off_t[U:U + 1], non_blocking=True)
             h[1:2].copy_(off_m[U:U + 1], non_blocking=True)
-            h[2:3].copy_(d_prof, non_blocking=True)
+            h[2:66].copy_(d_prof, non_blocking=True)
             torch.cuda.current_stream(self.dev).synchronize()
-            nt, nm, n_prof = int(h[0]), int(h[1]), int(h[2])
+            nt, nm, n_prof = int(h[0]), int(h[1]), int(h[2:66].sum())
         n = nt + nm
         G = GenResult()
         G.user = self._empty(max(n, 1), torch.int32)
@@ -1170,7 +1170,7 @@ class Engine(object):
     def _pinned3(self):
         h = getattr(self, "_h3", None)
         if h is None:
-            h = self._h3 = torch.empty(3, dtype=torch.int64, pin_memory=True)
+            h = self._h3 = torch.empty(66, dtype=torch.int64, pin_memory=True)
         return h
 
     def n_profiles(self, G):
