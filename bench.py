@@ -446,6 +446,13 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # The interpreter's cyclic collector is kept out of the timed steps (a full collection over the ~1e6 objects torch and
+    # numpy have created by now is a 30-40 ms host pause that lands inside one HIP-event bracket: one step in twenty showed
+    # a 39 ms "c_fill" around a 0.35 ms kernel, which is what made the driver-run stage C of round 2 read 4.3 ms): collect
+    # now, move the survivors out of the collector's reach, as bench_api does.
+    import gc
+    gc.collect()
+    gc.freeze()
     if dist:
         dist.barrier()
     eng.timers = {}
@@ -489,6 +496,8 @@ def main():
         # (the bracket covers the rows of the heavy set too unless XMAP_SPLIT_PHASES=1: they run on a side stream next to the
         # class launches, and their contributions are then part of the bytes)
         split = "pair_heavy" in tm
+        if res["n_contrib_light"] is None:
+            res["n_contrib_light"] = 2 * (res["S"].layout.half_contrib - eng.heavy_half(res["S"].layout))
         bytes_tri = 8.0 * (res["n_contrib_light"] if split or world > 1 else P) + 16.0 * nnz + 32.0 * I + 12.0 * res["n_kept_local"]
         ach = bytes_tri / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
         # SURVEY.md 8d states the whole-stage figure too: B_A = 8 P + 16 nnz + 32 I + 20 D' over t_A

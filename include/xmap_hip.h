@@ -167,7 +167,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij,
                     double *coo_ls /*NULL, or the RecommenderSim variant (below)*/, int32_t *rowcnt,
                     int32_t *rowcnt_h /*[64][1024] scratch*/, int64_t *d_shards /*[2][4096]*/,
-                    int64_t *d_counters /*[4]*/,
+                    int64_t *d_counters /*[4]; [6] with phases bit 64: [4] / [5] = kept / evaluated unordered pairs, the sums
+                                          of d_shards[0] / [1]*/,
                     int32_t *mircnt /*[I] or NULL.  NULL: rowcnt[i]++ / rowcnt[j]++ as described above.  Else rowcnt counts
                                       the pairs a row computed itself and mircnt those computed in lighter rows (the row layout
                                       of xmap_sim3_mirror)*/);
@@ -198,6 +199,14 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr /*[I
                      uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] x 8 B (16 B)*/, void *srec /*[nnz] x 16 B (24 B) scratch*/,
                      void *bufA /*as srec, scratch*/, void *bufB /*as srec, scratch*/, void *rc /*[nnz] x 16 B*/,
                      uint64_t *Wp /*[I]*/, double *info /*[I][4]*/, double *norms /*[2][I]*/, int32_t *h_ctl /*[2], host*/);
+/* xmap_sim2_plan + xmap_sim2_units with one synchronisation instead of four: the caller sizes the unit arrays from bounds it
+ * knows without asking the device (light units <= contributions / slot_target + n_items with contributions = sum over the
+ * users of d (d - 1) / 2; heavy units <= nnz / ch_min + 1024).  h_out [10], host = {light units, heavy units, first unit of
+ * table class rank 0..4, light units, CH, |H|} (h_out + 2 is the cls_ptr of xmap_sim2_pairs). */
+int xmap_sim3_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int64_t *pre, const int32_t *hid,
+                   const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp, int32_t *Qcat /*[5 I]*/,
+                   int64_t *uq_ptr /*[5 I + 1]*/, int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int32_t *uq_item, int32_t *uq_q,
+                   int32_t *uc_item, int32_t *uc_c, int64_t cap_light, int64_t cap_heavy, int64_t *h_out /*[10], host*/);
 /* The mirror of round 3.  xmap_sim2_pairs was given mircnt: own[i] = pairs row i computed (rowcnt), mir[j] = pairs computed
  * in lighter rows.  Row i of the CSR = [own | mirrored]: row_ptr = exclusive scan of own + mir; the own halves are written
  * in runs straight from the COO, the mirrored halves go through the tile sort keyed by the heavier item (positions mptr =

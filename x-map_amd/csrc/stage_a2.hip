@@ -294,15 +294,16 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
 }
 
 __global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Qcat, const long long *uq_ptr, int *uq_item, int *uq_q,
-                                                     const int *C, const long long *uc_ptr, int *uc_item, int *uc_c) {
+                                                     const int *C, const long long *uc_ptr, int *uc_item, int *uc_c,
+                                                     long long cap_light, long long cap_heavy) {
     const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (long long)N_CLASSES * I) return;
     const int i = (int)(x % I);
     long long b = uq_ptr[x];
-    for (int k = 0; k < Qcat[x]; k++) { uq_item[b + k] = i; uq_q[b + k] = k; }
+    for (int k = 0; k < Qcat[x] && b + k < cap_light; k++) { uq_item[b + k] = i; uq_q[b + k] = k; }
     if (x >= I) return;
     b = uc_ptr[i];
-    for (int k = 0; k < C[i]; k++) { uc_item[b + k] = i; uc_c[b + k] = k; }
+    for (int k = 0; k < C[i] && b + k < cap_heavy; k++) { uc_item[b + k] = i; uc_c[b + k] = k; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,6 +396,16 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begi
         }
         base += __popcll(km);
     }
+}
+
+// sums of the shard cursors (kept pairs) and of the evaluated-pair counters -> counters[4], counters[5]: what the host reads
+// after the pair kernels, in one copy with the overflow flags
+__global__ __launch_bounds__(256) void k_shard_sums(const unsigned long long *shards, unsigned long long *counters) {
+    unsigned long long a = 0ull, b = 0ull;
+    for (int s = threadIdx.x; s < COO_SHARDS; s += 256) { a += shards[s]; b += shards[COO_SHARDS + s]; }
+    a = (unsigned long long)wave_sum_ll((long long)a);
+    b = (unsigned long long)wave_sum_ll((long long)b);
+    if (lane_id() == 0) { atomicAdd(&counters[4], a); atomicAdd(&counters[5], b); }
 }
 
 __global__ __launch_bounds__(256) void k_fold_heavy(int n_heavy, const int *hlist, int *rowcnt_h, int *rowcnt) {
@@ -491,14 +502,18 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     A_STAMP(0);
 
     // walk(body): every co-rating of this unit's raters (those of hash partition q); body(act, j, jw, rj, ri, a, gei)
-    // runs once per lane and inner step.  Wave w takes every NW-th block of 64 raters.
+    // runs once per lane and inner step.  Wave w takes every NW-th block of RB raters.  RB = 64 (one rater record per lane)
+    // when the wave is alone or the row is very long; the rows of the shared 1024 / 512-slot tables have 158 / 33 raters
+    // on average: blocks of 64 gave wave 0 eight steps of 8 raters and left waves 2-3 with half a block or nothing, blocks
+    // of 16 deal the raters out evenly (a unit lives as long as its busiest wave, and holds its table that long).
+    constexpr int RB = (NW == 1 || NW == 16) ? 64 : 16;
     auto walk = [&](auto &&body) {
-        for (int base = p0 + 64 * w; base < p1; base += 64 * NW) {
+        for (int base = p0 + RB * w; base < p1; base += RB * NW) {
             const int p = base + lane;
             int e0 = 0, pw = 0;
             RT r = (RT)0;
             double au = 0.0;
-            if (p < p1) {
+            if (lane < RB && p < p1) {
                 if (LS) {       // fp64 ratings, user average 0 by construction
                     const RaterRecWide rr = ((const RaterRecWide *)A.rc)[p];
                     e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
@@ -508,9 +523,9 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
                     if (ADJ) au = A.u_avg[rr.user];
                 }
             }
-            const int nr = (p1 - base) < 64 ? (p1 - base) : 64;
+            const int nr = (p1 - base) < RB ? (p1 - base) : RB;
 #ifdef A_TRACE
-            if (base == p0 + 64 * w && __shfl(e0, 0, 64) >= 0) A_STAMP(1);
+            if (base == p0 + RB * w && __shfl(e0, 0, 64) >= 0) A_STAMP(1);
 #endif
             // software pipeline: the first 2 GRP entries of the NEXT step's prefixes are loaded before this step is
             // processed (a step waits for the longest of its 8 prefixes; every load inside the loop below is one more
@@ -1712,8 +1727,61 @@ int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const in
     XM_ARG(Qcat && uq_ptr && uq_item && uq_q && C && uc_ptr && uc_item && uc_c);
     if (n_items == 0) return XMAP_OK;
     k_fill_units2<<<dim3((unsigned)(((long long)N_CLASSES * n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        n_items, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c);
+        n_items, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c, 0x7fffffffffffffffLL,
+        0x7fffffffffffffffLL);
     XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+/* xmap_sim2_plan + xmap_sim2_units with ONE synchronisation: the unit arrays are sized by the caller from bounds it knows
+ * without asking the device (light units <= contributions / slot_target + n_items, heavy units <= nnz / ch_min + 1024), the
+ * scans leave their totals on the device, and the counts the launches need come back in one copy together with the heavy
+ * set's {CH, |H|}.  h_out [10] = {light units, heavy units, first unit of table class rank 0..4, light units, CH, |H|}. */
+int xmap_sim3_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int64_t *pre, const int32_t *hid,
+                   const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp, int32_t *Qcat, int64_t *uq_ptr,
+                   int64_t *uc_ptr, int32_t dups, int32_t *uq_item, int32_t *uq_q, int32_t *uc_item, int32_t *uc_c,
+                   int64_t cap_light, int64_t cap_heavy, int64_t *h_out) {
+    XM_SCOPE(stream);
+    XM_ARG(R && Wp && pre && hid && ctl && Q && C && small && Qcat && uq_ptr && uc_ptr && h_out);
+    XM_ARG(uq_item && uq_q && uc_item && uc_c && cap_light >= 0 && cap_heavy >= 0);
+    XM_ARG(slot_target > 0 && slot_target <= T_SLOTS);
+    hipStream_t st = (hipStream_t)stream;
+    const int I = R->n_items;
+    for (int c = 0; c < 10; c++) h_out[c] = 0;
+    XM_HIP(hipMemsetAsync(Qcat, 0, sizeof(int32_t) * (size_t)N_CLASSES * (size_t)(I > 0 ? I : 1), st));
+    if (I > 0) {
+        k_plan2<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(
+            I, (const long long *)R->item_ptr, nullptr, (const long long *)pre, (int)R->n_users + 2, hid, ctl, slot_target, dups, Q, C,
+            small, (unsigned long long *)Wp, Qcat);
+        XM_LAUNCH_CHECK();
+    }
+    int rcode = xmap_exclusive_scan_i32_to_i64(stream, Qcat, uq_ptr, (int64_t)N_CLASSES * I, nullptr);
+    if (rcode) return rcode;
+    rcode = xmap_exclusive_scan_i32_to_i64(stream, C, uc_ptr, I, nullptr);
+    if (rcode) return rcode;
+    if (I > 0) {
+        k_fill_units2<<<dim3((unsigned)(((long long)N_CLASSES * I + 255) / 256)), dim3(256), 0, st>>>(
+            I, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c, cap_light, cap_heavy);
+        XM_LAUNCH_CHECK();
+        // class boundaries uq_ptr[c I], c = 0..5 (the last one is the total), the heavy units' total, {CH, |H|}
+        XM_HIP(hipMemcpy2DAsync(&h_out[2], sizeof(int64_t), uq_ptr, sizeof(int64_t) * (size_t)I, sizeof(int64_t), N_CLASSES + 1,
+                                hipMemcpyDeviceToHost, st));
+        XM_HIP(hipMemcpyAsync(&h_out[1], uc_ptr + I, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
+    int32_t h_ctl[2] = {0, 0};
+    XM_HIP(hipMemcpyAsync(h_ctl, ctl, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    XM_HIP(hipStreamSynchronize(st));
+    h_out[0] = h_out[2 + N_CLASSES];
+    h_out[8] = h_ctl[0]; h_out[9] = h_ctl[1];
+    if (h_ctl[1] > HMAX) {
+        set_error("heavy set larger than %d", HMAX);
+        return XMAP_ERR_OVERFLOW;
+    }
+    if (h_out[0] > cap_light || h_out[1] > cap_heavy) {
+        set_error("unit arrays too small: %lld light / %lld heavy units, room for %lld / %lld", (long long)h_out[0], (long long)h_out[1],
+                  (long long)cap_light, (long long)cap_heavy);
+        return XMAP_ERR_CAPACITY;
+    }
     return XMAP_OK;
 }
 
@@ -1828,6 +1896,11 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     if ((phases & 4) && !heavy_aside && n_heavy_units > 0 && n_heavy > 0) {
         if (method == XMAP_COSINE) k_heavy_merge<XMAP_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, st>>>(A, n_heavy);
         else k_heavy_merge<XMAP_ADJUST_COSINE><<<dim3((unsigned)n_heavy), dim3(256), 0, st>>>(A, n_heavy);
+        XM_LAUNCH_CHECK();
+    }
+    if (phases & 64) {      // d_counters is [6]: [4] = kept pairs, [5] = unordered pairs evaluated (sums over the shards)
+        XM_HIP(hipMemsetAsync(d_counters + 4, 0, 2 * sizeof(int64_t), st));
+        k_shard_sums<<<dim3(1), dim3(256), 0, st>>>((const unsigned long long *)d_shards, (unsigned long long *)d_counters);
         XM_LAUNCH_CHECK();
     }
     if ((phases & 16) && n_heavy > 0) {   // fold the heavy items' count replicas into rowcnt

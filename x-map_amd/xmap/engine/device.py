@@ -37,6 +37,10 @@ class DeviceRatings(object):
         self.n_users = len(user_ptr) - 1
         self.n_items = int(n_items)
         self.nnz = int(user_ptr[-1])
+        # contributions of the "tri" formulation (every unordered pair of a profile once): a property of the profile
+        # lengths, so the engine sizes its pair buffers and unit arrays without asking the device
+        d = np.diff(user_ptr)
+        self.half_contrib = int((d * (d - 1) // 2).sum())
         if self.nnz >= 2 ** 31 - 1:
             raise ValueError("nnz must fit int32")
         if self.nnz and (item.min() < 0 or item.max() >= self.n_items):
@@ -393,6 +397,42 @@ class Engine(object):
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
+    def _tri_plan3(self, L, slot_target):
+        """_tri_plan with one synchronisation (xmap_sim3_plan): unit arrays sized from host-known bounds, the counts the
+        launches need and the heavy set's {CH, |H|} in one copy"""
+        R = self.R
+        st = _stream(self.dev)
+        I = R.n_items
+        L.Q = self._out(max(I, 1), torch.int32, I > 0)
+        L.C = self._out(max(I, 1), torch.int32, I > 0)
+        L.small = self._out(max(I, 1), torch.uint8, I > 0)
+        L.Qcat = self._empty(5 * max(I, 1), torch.int32)
+        L.uq_ptr = self._out(5 * I + 1, torch.int64, I > 0)
+        L.uc_ptr = self._out(I + 1, torch.int64, I > 0)
+        cap_light = L.half_contrib // max(int(slot_target), 1) + I + 1
+        cap_heavy = R.nnz // max(int(L.ch_min), 1) + 1025
+        L.uq_item = self._empty(cap_light, torch.int32)
+        L.uq_q = self._empty(cap_light, torch.int32)
+        L.uc_item = self._empty(cap_heavy, torch.int32)
+        L.uc_c = self._empty(cap_heavy, torch.int32)
+        h = (C.c_int64 * 10)()
+        with self.timed("tri_plan"):
+            check(lib.xmap_sim3_plan(st, C.byref(R.c), i32(slot_target), vp(L.pre), vp(L.hid), vp(L.ctl), vp(L.Q), vp(L.C),
+                                     vp(L.small), vp(L.Wp), vp(L.Qcat), vp(L.uq_ptr), vp(L.uc_ptr),
+                                     i32(1 if getattr(L, "dups", False) else 0), vp(L.uq_item), vp(L.uq_q), vp(L.uc_item),
+                                     vp(L.uc_c), i64(cap_light), i64(cap_heavy), h))
+        L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
+        L.cls_ptr = (C.c_int64 * 6)(*[int(h[2 + c]) for c in range(6)])
+        L.CH, L.n_heavy = int(h[8]), int(h[9])
+        L.slot_target = slot_target
+        L.replan = self._tri_plan3
+
+    def heavy_half(self, L):
+        """contributions of the heavy rows (reporting only: the bench's per-kernel byte counts)"""
+        if getattr(L, "_heavy_half", None) is None:
+            L._heavy_half = int(L.Wp[L.hlist[:L.n_heavy].long()].sum().item()) if L.n_heavy else 0
+        return L._heavy_half
+
     def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
         rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity).
@@ -421,7 +461,7 @@ class Engine(object):
             hp_lo = self._empty(max(nh, 1) * 1024, torch.float64)
             hp_cnt = self._empty(max(nh, 1) * 1024, torch.int32)
             hp_mut = self._empty(max(nh, 1) * 1024, torch.int32)
-            d_cnt = self._zeros(4, torch.int64)
+            d_cnt = self._zeros(6, torch.int64)       # [4], [5]: the shard sums (phases bit 64)
             d_shards = self._empty(2 * 4096, torch.int64)
             rowcnt_h = self._empty(64 * 1024, torch.int32)
 
@@ -442,14 +482,14 @@ class Engine(object):
                     run((4 if do_heavy else 0) | 16)
             else:       # the heavy rows (chunk partials + merge) on a side stream next to the class launches of the light rows
                 with self.timed("pair_tri"):
-                    run(8 | 2 | 16 | (5 if do_heavy else 0) | (32 if raw else 0))
-            h = d_cnt.tolist()
+                    run(8 | 2 | 16 | 64 | (5 if do_heavy else 0) | (32 if raw else 0))
+            h = d_cnt.tolist()          # the one synchronisation of the pair kernels: flags + kept / evaluated pairs
             if h[2]:
                 if L.slot_target <= 32:
                     raise abi.XmapError(abi.ERR_OVERFLOW, "pair-table overflow")
                 if not retry:      # sharded callers re-plan collectively
                     return None, rowcnt, 0, 0, 1
-                self._tri_plan(L, L.slot_target // 2)
+                getattr(L, "replan", self._tri_plan)(L, L.slot_target // 2)
                 continue
             if h[3]:            # a COO shard overflowed: more slack
                 if coo_slack > 64:
@@ -457,8 +497,9 @@ class Engine(object):
                 coo_slack *= 2
                 continue
             break
-        sh = d_shards.view(2, 4096).sum(dim=1).tolist()
-        n, n_unordered = int(sh[0]), int(sh[1])
+        if os.environ.get("XMAP_SPLIT_PHASES") == "1":      # (the split run has no shard-sum phase)
+            h[4:6] = d_shards.view(2, 4096).sum(dim=1).tolist()
+        n, n_unordered = int(h[4]), int(h[5])
         coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if (rec or raw) else ())
         out = (coo, rowcnt, n, n_unordered)
         if split:
@@ -553,7 +594,6 @@ class Engine(object):
         L.wide = bool(wide)
         info = self._out((i1, 4), torch.float64, I > 0)
         self.norms = self._out(2 * i1, torch.float64, I > 0)
-        h_ctl = (C.c_int32 * 2)()
         r64 = None
         if wide:
             r64 = R.user_rating64 if R.user_rating64 is not None else R.user_rating.double()
@@ -561,13 +601,11 @@ class Engine(object):
             check(lib.xmap_sim3_layout(st, C.byref(R.c), vp(R.item_ptr), vp(r64), i32(ch_min), vp(cnt),
                                        vp(u_avg), vp(u_norm), vp(L.hist), vp(L.pre), vp(L.ctl), vp(L.hid), vp(L.hlist),
                                        vp(L.ub_key), vp(L.ub), vp(srec), vp(buf_a), vp(buf_b), vp(L.rc), vp(L.Wp), vp(info),
-                                       vp(self.norms), h_ctl))
+                                       vp(self.norms), None))
         R.csc_ready = False             # item_ptr is current; item_user / item_rating are not built on this path
-        L.CH, L.n_heavy = int(h_ctl[0]), int(h_ctl[1])
-        L.slot_target = slot_target
-        self._tri_plan(L, slot_target)
-        both = torch.stack([L.Wp[:I].sum(), L.Wp[L.hlist[:L.n_heavy].long()].sum()]).tolist() if I else [0, 0]   # one sync
-        L.half_contrib, L.heavy_half = int(both[0]), int(both[1])
+        L.ch_min = int(ch_min)
+        L.half_contrib = R.half_contrib          # = sum of W+ over the items (the host knows it from the profile lengths)
+        self._tri_plan3(L, slot_target)
         return (u_avg, u_norm, info, None, None), L
 
     def tri_mirror(self, coo, own, mir, info, n, shards=None):

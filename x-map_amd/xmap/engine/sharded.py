@@ -170,7 +170,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             n_prof = eng.n_profiles(G)
         L = S.layout
         return dict(n_eval=S.n_eval, n_kept=S.n_kept, n_contrib=S.n_contrib,
-                    n_contrib_light=2 * (L.half_contrib - L.heavy_half), n_kept_local=S.n_kept,
+                    n_contrib_light=None, n_kept_local=S.n_kept,       # (bench: 2 * (half_contrib - eng.heavy_half(L)), on demand)
                     n_paths=E.n_paths, n_out=E.n_out, n_rows=G.n_rows, n_profiles=n_prof,
                     knn_entries=int(E.kcnt.sum().item()), S=S, E=E, G=G, choice=choice, map=mp)
 
