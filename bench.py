@@ -50,6 +50,9 @@ def workloads():
         "c2": dict(gen=lambda: synth.config_c2(), k=50, name="amazon-like two-domain 1M users / 200k+200k items, top-k=50 (BASELINE configs[1])"),
         # BASELINE.json configs[0]: 10k users / 2x5k items (the reference's CPU-runnable case)
         "c1": dict(gen=lambda: synth.config_c1(), k=10, name="10k users / 2x5k items, top-k=10 (BASELINE configs[0])"),
+        # the reference's own large scenario (TechReport_XMap.pdf Table 3/5): 128 402 movies -> 403 234 books, 3 % shared users
+        "s1": dict(gen=lambda: synth.config_s1(), k=50, name="S1 shape of the reference's report: 1.16M users / 128k source + 403k target items, "
+                                                                "3 % shared users, top-k=50"),
     }
 
 
@@ -541,6 +544,7 @@ def main():
                        "parallelism": ("users sharded over %d GPU(s), partial similarities exchanged" if by_users else "items sharded over %d GPU(s)") % world},
             "alterego_profiles_per_s": res["n_profiles"] / (t_b + t_c) if (t_b + t_c) > 0 else 0.0,
             "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
+            "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,       # torch's allocations (the library's arenas: < 0.5 GB more)
             "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},
             "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
             # the dominant kernel of the step (90 % of it): the path enumeration of stage B.  Its compulsory HBM bytes

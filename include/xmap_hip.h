@@ -366,13 +366,14 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
                    const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
                    int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
                    void *dir /*24 B per tile*/, void *midX /*64 B per record*/);
-/* Row-wise construction of the same lists (default when n_nb <= XMAP_MID_ROWS_MAX): one block per x' keeps the tile
- * sizes of its row in LDS, so there is no n_nb x n_nb table and no global atomic:
+/* Row-wise construction of the same lists (default, any n_nb): one block per x' keeps the tile sizes of its row in LDS --
+ * XMAP_MID_ROWS_SPAN columns at a time; a row with more non-bridge items is built in column ranges, one after the
+ * other -- so there is no n_nb x n_nb table and no global atomic:
  *   xmap_mid_rows_count : ng[x'] = non-empty tiles, nrec[x'] = records of x';
  *   (caller: exclusive scans ng -> dir_ptr [n_nb+1], nrec -> rec_ptr [n_nb+1]; allocates dir, midX)
  *   xmap_mid_rows_place : the tile directory (in x order) and the records of every x'.
  * Output identical to xmap_mid_tally / xmap_mid_place up to the order of the records inside a tile. */
-#define XMAP_MID_ROWS_MAX 40000   /* n_nb * 4 B of LDS per block, 160 KB per CU on gfx950 */
+#define XMAP_MID_ROWS_SPAN 40000   /* columns of a row whose counters fit the LDS of a block (4 B each, 160 KB per CU on gfx950) */
 int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                         const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                         const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,

@@ -125,6 +125,36 @@ def test_stage_b_c_full_size(c2, k):
     assert (rt >= 1).all() and (rt <= 5).all()
 
 
+def test_s1_shape_full_size(monkeypatch):
+    """The reference's own large scenario (TechReport Table 3/5: 128 402 movies -> 403 234 books, 3 % shared users) at
+    k = 50 through the default stage-B path: middle lists built row-wise in column ranges (more non-bridge items than one
+    LDS span), column form of the enumeration; against the per-path enumeration bit for bit, and the list invariants."""
+    import torch
+    from xmap.engine import synth, device, hipabi
+    r = synth.config_s1()
+    assert r.n_src_items > 120000 and r.n_items - r.n_src_items > 380000
+    eng = device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs()))
+    I = r.n_items
+    S = eng.item_sim("adjust_cosine", CAP)
+    d = np.diff(r.user_ptr)
+    assert S.n_contrib == int((d * (d - 1)).sum())
+    E1 = eng.extend(S, 50)
+    assert E1.algo == "cols" and E1.mid is not None
+    assert E1.mid.n_nb > hipabi.MID_ROWS_SPAN            # several column ranges per row
+    E2 = eng.extend(S, 50, algo="enum")
+    assert E1.n_paths == E2.n_paths == E1.units.total and E1.n_out == E2.n_out and E1.n_paths > 0
+    assert np.array_equal(E1.n_cand.cpu().numpy(), E2.n_cand.cpu().numpy())
+    assert np.array_equal(E1.top_end.cpu().numpy(), E2.top_end.cpu().numpy())
+    assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
+    del E2
+    _candidate_properties(r, E1, I)
+    n_top, choice, mp = eng.select(E1, True)
+    G = eng.alterego(mp)
+    flags = r.item_attrs()[3]
+    assert G.n_target_rows == int((flags[r.item] & 2).astype(bool).sum()) and G.n_rows >= G.n_target_rows
+    torch.cuda.empty_cache()
+
+
 def test_full_lists_at_full_size(c2):
     """full=True (what iterating the lazy extended_simRDD triggers) at BASELINE configs[1], k = 50: 4.6e9 (start, end)
     pairs in buffers sized exactly from the candidate counts of the first pass -- no capacity retry --, checked through

@@ -325,6 +325,38 @@ def test_keys_larger_than_a_tile(dev, method):
     xo.sim_free(So)
 
 
+def test_middle_lists_in_column_ranges(dev, monkeypatch):
+    """k_mid_rows keeps the tile counters of XMAP_MID_ROWS_SPAN columns in LDS and builds wider rows range by range: with a
+    span of 37 columns (dozens of ranges per row here) the extension equals the one-range build and the oracle, bit for bit."""
+    from oracle import xmap_oracle as xo
+    from xmap.engine import synth
+    r = synth.make_two_domain(17, 3000, 700, 700, overlap=0.15)
+    attrs = r.item_attrs()
+    eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs)
+    S = eng.item_sim("adjust_cosine", CAP)
+    E0 = eng.extend(S, 10, full=True)
+    assert E0.mid is not None and E0.mid.n_nb > 200
+    monkeypatch.setenv("XMAP_MID_ROWS_SPAN", "37")
+    E1 = eng.extend(S, 10, full=True)
+    monkeypatch.delenv("XMAP_MID_ROWS_SPAN")
+    assert E1.mid.n_tiles == E0.mid.n_tiles and E1.mid.n_records == E0.mid.n_records
+    assert np.array_equal(E1.mid.dir_ptr.cpu().numpy(), E0.mid.dir_ptr.cpu().numpy())
+    d0, d1 = E0.mid.dir.cpu().numpy().reshape(-1, 3), E1.mid.dir.cpu().numpy().reshape(-1, 3)
+    assert np.array_equal(d0[:E0.mid.n_tiles], d1[:E1.mid.n_tiles])          # same tiles, same x order, same offsets
+    assert E1.n_paths == E0.n_paths and E1.n_out == E0.n_out
+    a, b = _xsim_lists(E0, r.n_items), _xsim_lists(E1, r.n_items)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
+    So = xo.item_sim(T, "adjust_cosine", CAP, nthreads=8)
+    Xo = xo.extend(T, So, 10)
+    assert E1.n_paths == Xo.n_paths
+    ost, oen = csr_to_pairs(Xo.xs_ptr, Xo.xs_end)
+    assert np.array_equal(b[0], ost) and np.array_equal(b[1], oen) and np.array_equal(b[2], Xo.xs_val)
+    xo.ext_free(Xo)
+    xo.sim_free(So)
+
+
 def test_determinism_and_partitions(dev):
     """two runs give identical bytes; the result does not depend on the table partitioning."""
     from xmap.engine import synth

@@ -401,7 +401,6 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
     int64_t n_nb = 0;
     XM_ALLOC(c->p_ext, nb_list, I); XM_ALLOC(c->p_ext, nb_id, I);
     XM_TRY(xmap_nb_index(c->st, I, cls, nb_list, nb_id, &n_nb));
-    if (n_nb > XMAP_MID_ROWS_MAX) { set_error("more than %d non-bridge records: use the fine-grained entry points", XMAP_MID_ROWS_MAX); return XMAP_ERR_ARG; }
     T.n_nb = (int32_t)n_nb; T.nb_list = nb_list; T.nb_id = nb_id;
     if (n_nb > 0) {
         int32_t *ng;

@@ -819,27 +819,28 @@ __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
     }
 }
 
-// Row-wise construction of the middle lists (default): ONE block per x', the tile sizes of its row in LDS (n_nb
-// counters: the row of the dense table without the table).  PHASE 0 counts the row's records and non-empty tiles;
-// PHASE 1 repeats the tally, turns it into offsets (block scan), writes the row's tile directory in x order and places
-// the records with LDS cursors.  No global atomics (the table form spends 1.6e8 of them per pass, twice, on a 3 GB
-// table) and no n_nb^2 memory.
+// Row-wise construction of the middle lists (default): ONE block per x', the tile sizes of its row in LDS (the row of
+// the dense table without the table).  PHASE 0 counts the row's records and non-empty tiles; PHASE 1 repeats the tally,
+// turns it into offsets (block scan), writes the row's tile directory in x order and places the records with LDS cursors.
+// No global atomics (the table form spends 1.6e8 of them per pass, twice, on a 3 GB table) and no n_nb^2 memory.
+// The LDS holds the counters of `span` columns (<= XMAP_MID_ROWS_SPAN): a row with more non-bridge items than that is
+// built in column ranges [x0, x0 + span), one after the other -- every range walks the row's (t, s, x) again and keeps the
+// x of its range, the directory and the records of the ranges follow each other (x order is kept).  Rounds 1-2 fell back
+// to the dense n_nb x n_nb table beyond 40 000 non-bridge items (120 GB at 1e5) and the coarse ABI refused.
 constexpr int MIDROW_WAVES = 16;
 template <int PHASE>
-__global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int *ng, long long *nrec, const long long *dir_ptr,
+__global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int span, int *ng, long long *nrec, const long long *dir_ptr,
                                                                 const long long *rec_ptr, MidDir *dir) {
-    extern __shared__ int bins[];                      // [n_nb]
+    extern __shared__ int bins[];                      // [span]
     __shared__ unsigned long long s_wave[MIDROW_WAVES];
     const int xpid = blockIdx.x;
     const int xp = A.nb_list[xpid];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int n_nb = A.n_nb;
-    for (int i = threadIdx.x; i < n_nb; i += 64 * MIDROW_WAVES) bins[i] = 0;
-    __syncthreads();
     const int nq = A.kcnt[(size_t)xp * 2];
     // the joint (t,s) of the row are dealt round-robin to the waves (every wave scans the flags, 64 at a time); the
     // lanes of a wave walk attach(s) together (coalesced, distinct x: no two lanes meet on a counter)
-    auto walk = [&](auto &&body) {
+    auto walk = [&](int x0, int x1, auto &&body) {
         int ctr = 0;
         for (int q = 0; q < nq; q++) {
             const size_t o = ((size_t)xp * 2) * A.k + q;
@@ -856,55 +857,64 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int *
                     if ((ctr++ % MIDROW_WAVES) != w) continue;
                     const long long p = base + l;
                     const int s = A.src_idx[p];
-                    for (long long ap = A.att_ptr[s] + lane; ap < A.att_ptr[s + 1]; ap += 64)
-                        body(A.nb_id[A.att_idx[ap]], v2, m2, f2, p, ap);
+                    for (long long ap = A.att_ptr[s] + lane; ap < A.att_ptr[s + 1]; ap += 64) {
+                        const int xid = A.nb_id[A.att_idx[ap]];
+                        if (xid >= x0 && xid < x1) body(xid, v2, m2, f2, p, ap);
+                    }
                 }
             }
         }
     };
-    walk([&](int xid, double, double, double, long long, long long) { atomicAdd(&bins[xid], 1); });
-    __syncthreads();
-    // per thread a run of consecutive bins: (non-empty tiles << 40 | records), block-wide exclusive scan
-    const int per = (n_nb + 64 * MIDROW_WAVES - 1) / (64 * MIDROW_WAVES);
-    const int b0 = threadIdx.x * per, b1 = (b0 + per) < n_nb ? (b0 + per) : n_nb;
-    unsigned long long mine = 0;
-    for (int i = b0; i < b1; i++) { const int c = bins[i]; mine += (unsigned long long)c + (c ? (1ull << 40) : 0ull); }
-    unsigned long long incl = mine;
+    unsigned long long done = 0;                        // (non-empty tiles << 40 | records) of the ranges before this one
+    const long long rbase = PHASE ? rec_ptr[xpid] : 0, dbase = PHASE ? dir_ptr[xpid] : 0;
+    for (int x0 = 0; x0 < n_nb; x0 += span) {
+        const int x1 = (x0 + span) < n_nb ? (x0 + span) : n_nb, nx = x1 - x0;
+        __syncthreads();                                // (the previous range's placement is over)
+        for (int i = threadIdx.x; i < nx; i += 64 * MIDROW_WAVES) bins[i] = 0;
+        __syncthreads();
+        walk(x0, x1, [&](int xid, double, double, double, long long, long long) { atomicAdd(&bins[xid - x0], 1); });
+        __syncthreads();
+        // per thread a run of consecutive bins: (non-empty tiles << 40 | records), block-wide exclusive scan
+        const int per = (nx + 64 * MIDROW_WAVES - 1) / (64 * MIDROW_WAVES);
+        const int b0 = threadIdx.x * per, b1 = (b0 + per) < nx ? (b0 + per) : nx;
+        unsigned long long mine = 0;
+        for (int i = b0; i < b1; i++) { const int c = bins[i]; mine += (unsigned long long)c + (c ? (1ull << 40) : 0ull); }
+        unsigned long long incl = mine;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    if (lane == 63) s_wave[w] = incl;
-    __syncthreads();
-    unsigned long long before = 0, total = 0;
-    for (int o = 0; o < MIDROW_WAVES; o++) { const unsigned long long v = s_wave[o]; if (o < w) before += v; total += v; }
-    if (PHASE == 0) {
-        if (threadIdx.x == 0) { ng[xpid] = (int)(total >> 40); nrec[xpid] = (long long)(total & ((1ull << 40) - 1)); }
-        return;
-    }
-    unsigned long long ex = before + incl - mine;
-    int rank = (int)(ex >> 40);
-    int off = (int)(ex & ((1ull << 40) - 1));
-    const long long rbase = rec_ptr[xpid], dbase = dir_ptr[xpid];
-    for (int i = b0; i < b1; i++) {
-        const int c = bins[i];
-        bins[i] = off;                                  // placement cursor of the tile
-        if (c) {
-            MidDir d;
-            d.x = A.nb_list[i]; d.ne = 1 + A.kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = i; d.off = rbase + off;
-            dir[dbase + rank] = d;
-            rank++;
-            off += c;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        unsigned long long before = 0, total = 0;
+        for (int o = 0; o < MIDROW_WAVES; o++) { const unsigned long long v = s_wave[o]; if (o < w) before += v; total += v; }
+        if (PHASE == 1) {
+            const unsigned long long ex = done + before + incl - mine;
+            int rank = (int)(ex >> 40);
+            long long off = (long long)(ex & ((1ull << 40) - 1));
+            for (int i = b0; i < b1; i++) {
+                const int c = bins[i];
+                bins[i] = (int)off;                         // placement cursor of the tile (records of a row fit 31 bits)
+                if (c) {
+                    MidDir d;
+                    d.x = A.nb_list[x0 + i]; d.ne = 1 + A.kcnt[(size_t)d.x * 2 + 1]; d.cnt = c; d.pad = x0 + i; d.off = rbase + off;
+                    dir[dbase + rank] = d;
+                    rank++;
+                    off += c;
+                }
+            }
+            __syncthreads();
+            walk(x0, x1, [&](int xid, double v2, double m2, double f2, long long p, long long ap) {
+                const long long pos = rbase + atomicAdd(&bins[xid - x0], 1);
+                const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];      // edge (t, s)
+                const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
+                MidX r;
+                r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
+                r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
+                A.midX[pos] = r;
+            });
         }
+        done += total;
     }
-    __syncthreads();
-    walk([&](int xid, double v2, double m2, double f2, long long p, long long ap) {
-        const long long pos = rbase + atomicAdd(&bins[xid], 1);
-        const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];      // edge (t, s)
-        const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
-        MidX r;
-        r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
-        r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
-        A.midX[pos] = r;
-    });
+    if (PHASE == 0 && threadIdx.x == 0) { ng[xpid] = (int)(done >> 40); nrec[xpid] = (long long)(done & ((1ull << 40) - 1)); }
 }
 
 // directory of the non-empty tiles of every x' (row of the dense table): count, then fill
@@ -1963,10 +1973,15 @@ static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const in
     return A;
 }
 
-// row-wise construction (k_mid_rows); the tile counters of a row live in LDS: n_nb <= XMAP_MID_ROWS_MAX
-static int mid_rows_lds(int32_t n_nb, size_t *bytes) {
-    *bytes = sizeof(int32_t) * (size_t)n_nb;
-    if (n_nb > XMAP_MID_ROWS_MAX) { set_error("row-wise middle lists need n_nb <= %d (got %d)", XMAP_MID_ROWS_MAX, n_nb); return XMAP_ERR_ARG; }
+// row-wise construction (k_mid_rows); the tile counters of a column range of the row live in LDS
+static int mid_rows_lds(int32_t n_nb, size_t *bytes, int *span) {
+    int cap = XMAP_MID_ROWS_SPAN;
+    if (const char *e = getenv("XMAP_MID_ROWS_SPAN")) {      // tests: several column ranges on small inputs
+        const int v = atoi(e);
+        if (v >= 1 && v < cap) cap = v;
+    }
+    *span = n_nb < cap ? n_nb : cap;
+    *bytes = sizeof(int32_t) * (size_t)(*span > 0 ? *span : 1);
     return XMAP_OK;
 }
 
@@ -1978,12 +1993,13 @@ int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t 
     XM_ARG(cls && kcnt && kcol && kval && flags && att_ptr && src_ptr && nb_list && nb_id && ng && nrec);
     if (n_nb == 0) return XMAP_OK;
     size_t lds;
-    int rc = mid_rows_lds(n_nb, &lds);
+    int span;
+    int rc = mid_rows_lds(n_nb, &lds, &span);
     if (rc) return rc;
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
                          src_flag, n_nb, nb_list, nb_id);
     XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_mid_rows<0><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, ng, (long long *)nrec, nullptr,
+    k_mid_rows<0><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, span, ng, (long long *)nrec, nullptr,
                                                                                               nullptr, nullptr);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
@@ -1998,14 +2014,15 @@ int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t 
     XM_ARG(dir_ptr && rec_ptr && dir && midX);
     if (n_nb == 0) return XMAP_OK;
     size_t lds;
-    int rc = mid_rows_lds(n_nb, &lds);
+    int span;
+    int rc = mid_rows_lds(n_nb, &lds, &span);
     if (rc) return rc;
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
                          src_flag, n_nb, nb_list, nb_id);
     A.midX = (MidX *)midX;
     XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_mid_rows<1><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(
-        A, nullptr, nullptr, (const long long *)dir_ptr, (const long long *)rec_ptr, (MidDir *)dir);
+        A, span, nullptr, nullptr, (const long long *)dir_ptr, (const long long *)rec_ptr, (MidDir *)dir);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

@@ -801,9 +801,9 @@ class Engine(object):
 
     def mid_lists(self, E, table_budget=24 << 30, rows=None):
         """middle lists of all joint paths, one tile of records per (x', x) (stage_b.hip, second formulation).
-        rows (default: whenever n_nb <= abi.MID_ROWS_MAX): built row-wise, one block per x' with the row's tile sizes in
-        LDS; otherwise through the dense n_nb x n_nb tile table.  Returns None when neither fits (callers fall back to the
-        per-path enumeration)."""
+        rows (default): built row-wise, one block per x' with the row's tile sizes in LDS (abi.MID_ROWS_SPAN columns at a
+        time); rows=False / XMAP_MID_TABLE=1: through the dense n_nb x n_nb tile table (cross-check; None when it does not
+        fit the budget -- callers fall back to the per-path enumeration)."""
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
@@ -814,7 +814,7 @@ class Engine(object):
         n_nb = int(nn.value)
         nb_list = nb_list[:n_nb]
         if rows is None:
-            rows = n_nb <= abi.MID_ROWS_MAX and os.environ.get("XMAP_MID_TABLE") != "1"
+            rows = os.environ.get("XMAP_MID_TABLE") != "1"
         if n_nb == 0 or (not rows and n_nb * n_nb * 12 > table_budget):
             return None
         M = ExtResult()

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("XMAP_HIP_LIB") or os.path.normpath(os.path.join(HERE,
 COSINE, ADJUST_COSINE = 0, 1
 METHODS = {"cosine": COSINE, "adjust_cosine": ADJUST_COSINE}
 TOPC = 10
-MID_ROWS_MAX = 40000      # XMAP_MID_ROWS_MAX
+MID_ROWS_SPAN = 40000     # XMAP_MID_ROWS_SPAN: columns of a middle-list row per LDS pass
 ERR_HIP, ERR_ARG, ERR_OVERFLOW, ERR_CAPACITY = -1, -2, -3, -4     # XMAP_ERR_* of include/xmap_hip.h
 
 

@@ -97,11 +97,12 @@ def _domain_draws(rng, users, n_items, d_min, mu, sigma, zipf):
 
 
 def make_two_domain(seed, n_users, n_src_items, n_tgt_items, overlap=0.25,
-                    d_min=5, mu=0.7, sigma=1.0, zipf=0.8):
+                    d_min=5, mu=0.7, sigma=1.0, zipf=0.8, src_share=0.5):
+    """src_share: fraction of the single-domain users that are source-only (0.5: as many as target-only)"""
     rng = np.random.default_rng(seed)
     r = rng.random(n_users)
     both = r < overlap
-    src_only = (~both) & (r < overlap + (1.0 - overlap) / 2)
+    src_only = (~both) & (r < overlap + (1.0 - overlap) * src_share)
     tgt_only = ~(both | src_only)
     all_u = np.arange(n_users)
     us, its = _domain_draws(rng, all_u[both | src_only], n_src_items,
@@ -168,6 +169,19 @@ def config_c1(seed=1):
 def config_c4(seed=4, n_sources=4):
     """4 source domains -> 1 target, ~5M users in total (BASELINE configs[3]): every source problem has 1.25 M users."""
     return make_multi_domain(seed, 1250000, 200000, 200000, n_sources)
+
+
+def config_s1(seed=3):
+    """The shape of the reference's own large scenario S1 (TechReport_XMap.pdf, Tables 3 and 5): source = movies, 128 402
+    items / 473 764 users; target = books, 403 234 items / 725 846 users; the two catalogues barely share users (rating
+    density of the union 0.0147 %).  Same generator as the other configs (log-normal profile lengths, Zipf popularity), 3 %
+    of the users active in both domains: the bridge set is thin and most items are non-bridge records -- the regime the
+    stage-B middle lists have to survive (n_nb far above one LDS span of columns)."""
+    n_src_users, n_tgt_users, overlap = 473764, 725846, 0.03
+    n_users = int(round((n_src_users + n_tgt_users) / (1.0 + overlap)))
+    both = overlap * n_users
+    src_share = (n_src_users - both) / max(n_users - both, 1.0)
+    return make_two_domain(seed, n_users, 128402, 403234, overlap=overlap, src_share=src_share)
 
 
 def config_c2(seed=2):
