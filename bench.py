@@ -51,8 +51,8 @@ def workloads():
         # BASELINE.json configs[0]: 10k users / 2x5k items (the reference's CPU-runnable case)
         "c1": dict(gen=lambda: synth.config_c1(), k=10, name="10k users / 2x5k items, top-k=10 (BASELINE configs[0])"),
         # the reference's own large scenario (TechReport_XMap.pdf Table 3/5): 128 402 movies -> 403 234 books, 3 % shared users
-        "s1": dict(gen=lambda: synth.config_s1(), k=50, name="S1 shape of the reference's report: 1.16M users / 128k source + 403k target items, "
-                                                                "3 % shared users, top-k=50"),
+        "s1": dict(gen=lambda: synth.config_s1(), k=10, name="S1 shape of the reference's report: 1.16M users / 128k source + 403k target items, "
+                                                                "3 % shared users, top-k=10 (the reference's parameters.yaml)"),
     }
 
 

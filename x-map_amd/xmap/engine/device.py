@@ -834,6 +834,9 @@ class Engine(object):
                 check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(M.ng), vp(M.dir_ptr), i64(n_nb), C.byref(tg)))
                 check(lib.xmap_exclusive_scan_i64(st, vp(nrec), vp(rec_ptr), i64(n_nb), C.byref(tx)))
                 M.n_records, M.n_tiles = int(tx.value), int(tg.value)
+                budget = float(os.environ.get("XMAP_MID_BUDGET_GB", "100")) * 1e9
+                if 64.0 * M.n_records + 24.0 * M.n_tiles > budget:
+                    return None         # the lists do not fit: the caller enumerates path by path
                 M.dir = self._empty(max(M.n_tiles, 1) * 3, torch.int64)
                 M.midX = self._empty(max(M.n_records, 1) * 8, torch.float64)
                 check(lib.xmap_mid_rows_place(st, *common, vp(M.dir_ptr), vp(rec_ptr), vp(M.dir), vp(M.midX)))
@@ -1044,12 +1047,20 @@ class Engine(object):
         I = R.n_items
         st = _stream(self.dev)
         E.algo = algo
+        U = self.path_units(E, start_range, chunk, start_split=start_split)
+        # The path count is the reference's algorithm, not the engine's: every joint (t, s) multiplies the attach lists of
+        # both ends (core/extender.py:142-169), so a thin bridge set with long lists and a long k explode it (the S1 shape
+        # of the reference's report has 2.9e10 paths at its own k = 10 and 5.8e13 at k = 50).  Refuse up front what would
+        # take hours, instead of dying in an allocation.
+        max_paths = float(os.environ.get("XMAP_MAX_PATHS", "5e12"))
+        if U.total > max_paths:
+            raise abi.XmapError(abi.ERR_CAPACITY, "the extension has %.3g paths at top_k = %d (limit XMAP_MAX_PATHS = %.3g): "
+                                "use a shorter list" % (U.total, E.k, max_paths))
         M = getattr(E, "mid", None)
         if M is None:
             M = self.mid_lists(E) if algo in ("mid", "cols") else None
         if algo == "cols" and M is None:
             algo = "enum"           # no non-bridge records (nothing joint) or the lists do not fit: per-path enumeration
-        U = self.path_units(E, start_range, chunk, start_split=start_split)
         E.units = U
         E.mid = M
         if algo == "cols":
