@@ -410,7 +410,9 @@ typedef struct { int32_t n[4]; int len; } Path;
 XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *prefix_cls,
                  const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
                  int do_paths, int32_t s_lo, int32_t s_hi /* source records [s_lo, s_hi): a bounded sample for the CPU
-                 baseline timing; (0, I) = everything */, double max_seconds /* > 0: stop the sample after this long */) {
+                 baseline timing; (0, I) = everything */, double max_seconds /* > 0: stop the sample after this long */,
+                 const uint8_t *want /* NULL, or [I]: only the paths that START at an item with want[item] != 0 are
+                 enumerated -- the complete X-Sim lists of a sample of starts at a size where all paths are out of reach */) {
     int32_t I = S->I, k = top_k;
     XoExt *X = (XoExt *)calloc(1, sizeof(XoExt));
     X->I = I; X->k = k;
@@ -476,6 +478,20 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     size_t p0cap = 1024;
     Path *P0 = (Path *)malloc(p0cap * sizeof(Path));
+    uint8_t *wanty = NULL, *wantt = NULL;      /* wanty[x'] = some y' of NB_NN(x') is a wanted start */
+    if (want) {
+        wanty = (uint8_t *)calloc((size_t)(I ? I : 1), 1);
+        for (int32_t x = 0; x < I; x++) if (X->cls[x] == 2)
+            for (int32_t y = 0; y < X->cnt[(size_t)x * 2 + 1]; y++)
+                if (want[X->col[((size_t)x * 2 + 1) * k + y]]) { wanty[x] = 1; break; }
+        /* wantt[t] = a (t, s) record can produce a wanted start: t itself, an x' of attach(t), or a y' of such an x' */
+        wantt = (uint8_t *)calloc((size_t)(I ? I : 1), 1);
+        for (int32_t t = 0; t < I; t++) {
+            if (want[t]) { wantt[t] = 1; continue; }
+            for (int64_t a = aptr[t]; a < aptr[t + 1]; a++)
+                if (want[ax[a]] || wanty[ax[a]]) { wantt[t] = 1; break; }
+        }
+    }
     /* B5b-B5e: every SRC record ((t,s), attach(s))   extender.py:61-70,174,176 */
     if (s_lo < 0) s_lo = 0;
     if (s_hi > I || s_hi < 0) s_hi = I;
@@ -488,6 +504,7 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
         for (int l = 0; l < 2; l++) for (int32_t q = 0; q < X->cnt[(size_t)s * 2 + l]; q++) {
             int32_t t = X->col[((size_t)s * 2 + l) * k + q];       /* v in knn_BB[s].keys() */
             if (!(flags[t] & 2)) continue;                         /* "T:" in v */
+            if (want && !wantt[t]) continue;                       /* (no wanted start behind this record) */
             /* P0(t,s)  extender.py:134-138 / :154-158 */
             size_t np0 = 0;
             size_t need = 1;
@@ -509,6 +526,8 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
             if (joint) { /* final_joint_extend  extender.py:142-169 */
                 for (int64_t a = aptr[t]; a < aptr[t + 1]; a++) {
                     int32_t xp = ax[a];
+                    if (want && !want[xp] && !wanty[xp]) continue;
+                    if (!want || want[xp])
                     for (size_t p = 0; p < np0; p++) { /* target_path */
                         path[0] = xp; memcpy(path + 1, P0[p].n, (size_t)P0[p].len * sizeof(int32_t));
                         path_value(X, path, P0[p].len + 1, &sp, &cp);
@@ -518,6 +537,7 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
                     for (size_t p = 0; p < np0; p++) /* longest_path */
                         for (int32_t y = 0; y < X->cnt[(size_t)xp * 2 + 1]; y++) {
                             int32_t yp = X->col[((size_t)xp * 2 + 1) * k + y];
+                            if (want && !want[yp]) continue;
                             path[0] = yp; path[1] = xp; memcpy(path + 2, P0[p].n, (size_t)P0[p].len * sizeof(int32_t));
                             path_value(X, path, P0[p].len + 2, &sp, &cp);
                             pmap_add(&M, ((uint64_t)(uint32_t)yp << 32) | (uint32_t)P0[p].n[P0[p].len - 1], sp * cp, cp);
@@ -526,6 +546,7 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
                 }
             }
             /* final_nonjoint_extend on EVERY source record (quirk A.5-5)  extender.py:124-140,:180 */
+            if (!want || want[t])
             for (size_t p = 0; p < np0; p++) {
                 path_value(X, P0[p].n, P0[p].len, &sp, &cp);
                 pmap_add(&M, ((uint64_t)(uint32_t)t << 32) | (uint32_t)P0[p].n[P0[p].len - 1], sp * cp, cp);
@@ -533,7 +554,7 @@ XoExt *xo_extend(const XoSim *S, int top_k, const double *info, const int32_t *p
             }
         }
     }
-    free(P0);
+    free(P0); free(wanty); free(wantt);
     X->n_paths = n_paths;
     clock_gettime(CLOCK_MONOTONIC, &ts1);
     X->path_seconds = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);

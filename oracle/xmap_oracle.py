@@ -141,14 +141,19 @@ class Ext(object):
     pass
 
 
-def extend(T, S, top_k, do_paths=True, s_range=None, max_seconds=0.0):
+def extend(T, S, top_k, do_paths=True, s_range=None, max_seconds=0.0, starts=None):
     """Stage B from the oracle's own stage-A handle.  s_range = (lo, hi): paths of the source records in that item
-    range only (a bounded sample for timing; the X-Sim lists are then partial)."""
+    range only (a bounded sample for timing; the X-Sim lists are then partial).  starts = item indices: only the paths
+    that start there (their X-Sim lists are complete; n_paths counts them alone)."""
     lo, hi = (0, T.I) if s_range is None else (int(s_range[0]), int(s_range[1]))
+    want = None
+    if starts is not None:
+        want = np.zeros(max(T.I, 1), np.uint8)
+        want[np.asarray(starts, np.int64)] = 1
     h = lib().xo_extend(S._h, C.c_int(top_k), _p(S.info, C.c_double), _p(T.prefix_cls, C.c_int32),
                         _p(T.suffix_cls, C.c_int32), _p(T.contains_mask, C.c_uint32),
                         _p(T.flags, C.c_uint8), C.c_int(1 if do_paths else 0), C.c_int32(lo), C.c_int32(hi),
-                        C.c_double(max_seconds))
+                        C.c_double(max_seconds), _p(want, C.c_uint8) if want is not None else None)
     x = h.contents
     I, k = T.I, top_k
     out = Ext()

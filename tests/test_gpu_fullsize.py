@@ -125,6 +125,70 @@ def test_stage_b_c_full_size(c2, k):
     assert (rt >= 1).all() and (rt <= 5).all()
 
 
+def test_stage_b_against_the_oracle_at_full_size(c2):
+    """BASELINE configs[1], k = 50, against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py):
+    bridge flags and the classified top-k lists of EVERY item, the attach lists derived from them, and -- for a sample
+    of starts, whose paths the oracle can enumerate -- the exact path counts, the candidate counts and the ten best
+    candidates with their X-Sim values, bit for bit."""
+    from oracle import xmap_oracle as xo
+    r, eng = c2
+    I, k, method = r.n_items, 50, "adjust_cosine"
+    S = eng.item_sim(method, CAP)
+    E = eng.extend(S, k)
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *r.item_attrs())
+    So = xo.item_sim(T, method, CAP, nthreads=16)
+    assert So.n_eval == S.n_eval and int(So.row_ptr[-1]) == S.n_kept
+    Xo = xo.extend(T, So, k, do_paths=False)
+    # B1-B4: every item
+    assert np.array_equal(E.bb.cpu().numpy()[:I], Xo.bb)
+    cls = E.cls.cpu().numpy()[:I]
+    assert np.array_equal(cls, Xo.cls)
+    kcnt = E.kcnt.cpu().numpy()[:I]
+    assert np.array_equal(kcnt, Xo.cnt)
+    msk = np.arange(k)[None, None, :] < Xo.cnt[:, :, None]
+    kcol = E.kcol.cpu().numpy()[:I]
+    assert np.array_equal(kcol[msk], Xo.col[msk])
+    assert np.array_equal(E.kval.cpu().numpy()[:I][msk], Xo.val[msk])
+    # B5a: attach(b) = the non-bridge records x with b in NB_BB(x), from the oracle's lists
+    nb = np.nonzero(Xo.cls == 2)[0]
+    c0 = Xo.cnt[nb, 0]
+    xs = np.repeat(nb, c0)
+    q = np.arange(int(c0.sum())) - np.repeat(np.cumsum(c0) - c0, c0)
+    b = Xo.col[xs, 0, q].astype(np.int64)
+    o = np.lexsort((xs, b))
+    aptr = np.zeros(I + 1, np.int64)
+    np.cumsum(np.bincount(b, minlength=I), out=aptr[1:])
+    g_ptr, g_idx = E.att[0].cpu().numpy(), E.att[1].cpu().numpy()
+    assert np.array_equal(g_ptr[:I + 1], aptr)
+    rows = np.repeat(np.arange(I, dtype=np.int64), np.diff(aptr))
+    go = np.lexsort((g_idx[:aptr[-1]], rows))
+    assert np.array_equal(g_idx[:aptr[-1]][go], xs[o])
+    # B5b-B6: a sample of starts
+    P = E.units.P.cpu().numpy()[:I]
+    assert int(P.sum()) == E.n_paths
+    rng = np.random.default_rng(11)
+    small = np.nonzero((P > 0) & (P <= 2000000))[0]
+    mid = np.nonzero((P > 2000000) & (P <= 30000000))[0]
+    sample = np.sort(np.concatenate([rng.choice(small, size=min(40, len(small)), replace=False),
+                                     rng.choice(mid, size=min(4, len(mid)), replace=False)]))
+    assert len(sample) >= 20
+    Xs = xo.extend(T, So, k, starts=sample)
+    assert Xs.n_paths == int(P[sample].sum())
+    n_cand = E.n_cand.cpu().numpy()[:I]
+    top_end, top_val = E.top_end.cpu().numpy()[:I], E.top_val.cpu().numpy()[:I]
+    for s in sample:
+        lo, hi = int(Xs.xs_ptr[s]), int(Xs.xs_ptr[s + 1])
+        ends, vals = Xs.xs_end[lo:hi], Xs.xs_val[lo:hi]
+        assert n_cand[s] == hi - lo
+        order = np.lexsort((ends, -np.abs(vals)))[:10]
+        m = len(order)
+        assert np.array_equal(top_end[s, :m], ends[order]) and (top_end[s, m:] == -1).all()
+        assert np.array_equal(top_val[s, :m], vals[order])
+    xo.ext_free(Xs)
+    xo.ext_free(Xo)
+    xo.sim_free(So)
+
+
 def test_s1_shape_full_size(monkeypatch):
     """The reference's own large scenario (TechReport Table 3/5: 128 402 movies -> 403 234 books, 3 % shared users) at the
     reference's own list length (parameters.yaml: extend_among_topk 10) through the default stage-B path: 3.3e5 non-bridge

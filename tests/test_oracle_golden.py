@@ -138,3 +138,32 @@ def test_rec_sim_oracle_matches_reference(key, rows_key):
     info = dict((i, v) for i, v in g[key]["item_info"])
     for i, name in enumerate(iids):
         assert R.norm[i] == pytest.approx(info[name][1], rel=1e-14)
+
+
+def test_oracle_extension_of_a_sample_of_starts():
+    """xo.extend(starts=...) enumerates only the paths that start at the given items: their X-Sim lists equal the ones of the
+    full enumeration (which is pinned against the golden vectors above), the other starts get none, and the path counts of
+    disjoint samples add up to the full count."""
+    from oracle import xmap_oracle as xo
+    from xmap.engine import synth
+    r = synth.make_two_domain(5, 1500, 400, 400, overlap=0.3)
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *r.item_attrs())
+    S = xo.item_sim(T, "adjust_cosine", 50)
+    full = xo.extend(T, S, 5)
+    has = np.nonzero(np.diff(full.xs_ptr))[0]
+    assert len(has) > 50
+    rng = np.random.default_rng(1)
+    sample = np.sort(rng.choice(has, size=40, replace=False))
+    rest = np.setdiff1d(np.arange(r.n_items), sample)
+    a, b = xo.extend(T, S, 5, starts=sample), xo.extend(T, S, 5, starts=rest)
+    assert a.n_paths + b.n_paths == full.n_paths and 0 < a.n_paths < full.n_paths
+    for s in range(r.n_items):
+        lo, hi = full.xs_ptr[s], full.xs_ptr[s + 1]
+        x = a if s in set(sample.tolist()) else b
+        y = b if x is a else a
+        assert x.xs_ptr[s + 1] - x.xs_ptr[s] == hi - lo and y.xs_ptr[s + 1] == y.xs_ptr[s]
+        assert np.array_equal(x.xs_end[x.xs_ptr[s]:x.xs_ptr[s + 1]], full.xs_end[lo:hi])
+        assert np.array_equal(x.xs_val[x.xs_ptr[s]:x.xs_ptr[s + 1]], full.xs_val[lo:hi])
+    for x in (a, b, full):
+        xo.ext_free(x)
+    xo.sim_free(S)

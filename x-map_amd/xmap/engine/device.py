@@ -766,6 +766,7 @@ class Engine(object):
                                      i64(cap_units), vp(U.unit_start), vp(U.unit_c), vp(U.unit_G), vp(U.unit_row),
                                      vp(U.heavy_unit0), h))
         U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = int(h[0]), int(h[1]), int(h[2]), int(h[3]), int(h[4])
+        U.P = P          # exact path count per start (B5d / B5e)
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
