@@ -21,7 +21,7 @@ def per_kernel(path, counter):
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] != counter:
             continue
-        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("xmap::", "").strip()
+        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("xmap::", "").replace("ts::", "").strip()
         acc[name] += float(row["Counter_Value"]) * 1024.0
     return acc
 
@@ -43,7 +43,13 @@ def main(fetch_csv, write_csv, tag, dense_fetch=None, dense_write=None):
            # profiles/rand_rmw_grp.hip under --pmc: README, "FETCH_SIZE correction")
            "k_paths4_fetch_x1": sum(v["FETCH_SIZE_bytes"] + v["WRITE_SIZE_bytes"] for k, v in raw.items() if k.startswith("k_paths4")), "k_paths2": tot(lambda k: k == "k_paths2"), "k_scatter": tot(lambda k: k == "k_scatter"),
            "k_knn_classify": tot(lambda k: k == "k_knn_classify"), "k_sort_profiles": tot(lambda k: k == "k_sort_profiles"),
-           "k_csc_fill": tot(lambda k: k == "k_csc_fill"), "k_dense_topk": tot(lambda k: k.startswith("k_dense_topk")) or None,
+           "k_csc_fill": tot(lambda k: k == "k_csc_fill"),
+           # round 3: the mirror = level A over the COO (+ own halves), level B, tiles, slices of the large keys; the
+           # transposition of the ratings = the two levels over the sort records, tiles, slices
+           "mirror": tot(lambda k: k.startswith("k_ts_bin<3") or k.startswith("k_mir_")),
+           "rater_records": tot(lambda k: k.startswith("k_ts_bin<2") or k.startswith("k_rc_")),
+           "k_count3": tot(lambda k: k == "k_count3"), "k_sort_profiles3": tot(lambda k: k.startswith("k_sort_profiles3")),
+           "k_item_stats3": tot(lambda k: k.startswith("k_item_")), "k_dense_topk": tot(lambda k: k.startswith("k_dense_topk")) or None,
            "raw": raw}
     here = os.path.dirname(os.path.abspath(__file__))
     old = {}
