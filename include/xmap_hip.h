@@ -143,6 +143,8 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
  *            half COO: coo_cap entries cut into 4096 shards with a cursor each (d_shards[0][s]; unused entries keep
  *            coo_i = -1), rowcnt[i]++ / rowcnt[j]++; d_shards[1][s] sums to the unordered pairs evaluated;
  *            d_counters[2] = table overflow, [3] = COO shard overflow.
+ *            bits 16-23 / 8-15 of phases = m / r (m > 1): only the rows of H whose item index % m == r are computed
+ *            (item-sharded ranks deal the heavy rows round-robin; partials and merge of a row stay on one rank).
  *   scatter: after an exclusive scan of rowcnt -> row_ptr, both directions of every valid COO entry (n_coo = coo_cap
  *            entries are scanned) into the CSR. */
 int xmap_sim2_layout(void *stream, const xmap_ratings *R, const double *info, int32_t ch_min, int32_t *hist /*[U+2]*/,
@@ -191,9 +193,14 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
  * rating64 != NULL: the ratings are fp64 (RecommenderSim over AlterEgo means, core/recommenderSim.py:64-133; R->user_rating is
  * ignored), the user averages are zero by construction (u_avg must be zero-filled, u_norm may be NULL), there is no
  * mutuality, and ub / rc use the 16-byte wide forms xmap_sim2_pairs reads when coo_ls != NULL without phases bit 32.
- * h_ctl (host, [2]) = {CH, |H|}; synchronises. */
+ * phases: 1 = everything up to the rater records and W+; 2 = item statistics of the items [stats_lo, stats_hi) (and the flags
+ * of THEIR rater records); 4 = flags of the profile copy, 8 = flags of all rater records -- both from the complete info.
+ * One GPU: 1 | 2 | 4 with all items.  Item-sharded ranks: 1 | 2 with the rank's share, an all-gather of info / norms (the
+ * all-gather of per-item norms), then 4 | 8.
+ * h_ctl (host, [2], may be NULL) = {CH, |H|}; synchronises if given. */
 int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr /*[I+1] = R->item_ptr*/,
-                     const double *rating64 /*[nnz] or NULL*/, int32_t ch_min, int32_t *cnt /*[I] scratch*/,
+                     const double *rating64 /*[nnz] or NULL*/, int32_t ch_min, int32_t phases, int32_t stats_lo, int32_t stats_hi,
+                     int32_t *cnt /*[I] scratch*/,
                      double *u_avg /*[U]*/, double *u_norm /*[U] or NULL with rating64*/, int32_t *hist /*[U+2]*/,
                      int64_t *pre /*[U+3]*/, int32_t *ctl /*[4]*/, int32_t *hid /*[I]*/, int32_t *hlist /*[1024]*/,
                      uint64_t *ub_key /*[nnz] scratch*/, void *ub /*[nnz] x 8 B (16 B)*/, void *srec /*[nnz] x 16 B (24 B) scratch*/,

@@ -330,6 +330,8 @@ struct TriArgs {
                                     // (round-3 mirror: row = [own | mirrored], xmap_sim3_mirror)
     int *rowcnt_h;                  // [HEAVY_SHARDS][HMAX] replicas for the heavy items
     unsigned long long *counters;   // [2] table overflow, [3] COO overflow
+    int heavy_mod, heavy_rem;       // the rows of H this call computes: item index % heavy_mod == heavy_rem (item-sharded ranks
+                                    // deal the heavy rows round-robin; 1, 0: all of them)
     int raw;                        // user-sharded input: emit every pair's partial sums (dot as (value, error) in coo_sim /
                                     // coo_aux, n_ij, mutuality) unfinished and unfiltered -- xmap_sim2_merge finishes them
 };
@@ -722,6 +724,8 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_pair_heavy(TriArgs A) {
     }
     __syncthreads();
     const int i = uniform(A.uc_item[unit]);
+    if (A.heavy_mod > 1 && (i % A.heavy_mod) != A.heavy_rem) return;      // another rank's heavy row (by ITEM index: the dense
+                                                                          // heavy ids are handed out by atomics and differ between ranks)
     const int c = uniform(A.uc_c[unit]);
     const int CH = uniform(*A.CH);
     const int base0 = uniform((int)A.iptr[i]);
@@ -791,6 +795,7 @@ __global__ __launch_bounds__(256) void k_heavy_merge(TriArgs A, int n_heavy) {
     const int h = blockIdx.x;
     if (h >= n_heavy) return;
     const int i = A.hlist[h];
+    if (A.heavy_mod > 1 && (i % A.heavy_mod) != A.heavy_rem) return;
     const int nc = A.C[i];
     const long long u0 = A.uc_ptr[i];
     // four waves per row: the most popular item has ~80 chunks of partials to fold
@@ -1291,19 +1296,19 @@ struct BigList {
 };
 
 template <typename Src>
-__global__ __launch_bounds__(256) void k_item_stats3(int I, const long long *iptr, const Src src, double *info, double *norms,
-                                                     BigList B) {
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (i0 >= I) return;
+__global__ __launch_bounds__(256) void k_item_stats3(int I, int lo, int hi, const long long *iptr, const Src src, double *info,
+                                                     double *norms, BigList B) {
+    const int i0 = lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (i0 >= hi) return;
     const int lane = lane_id();
     {
         const int i = i0 + (lane >> 4);
-        const bool on = i < I && iptr[i + 1] - iptr[i] <= 64;
+        const bool on = i < hi && iptr[i + 1] - iptr[i] <= 64;
         item_stats_group<16, Src, false>(on, i, lane & 15, I, iptr, src, info, norms, nullptr, nullptr);
     }
     for (int t = 0; t < 4; t++) {
         const int i = i0 + t;
-        if (i >= I) break;
+        if (i >= hi) break;
         const long long n = iptr[i + 1] - iptr[i];
         if (n <= 64) continue;
         if (n > STAT_BIG) {
@@ -1398,6 +1403,17 @@ __global__ __launch_bounds__(256) void k_item_big_flags(const long long *iptr, c
         src.load(p, r, u);
         src.set_flag(p, r >= avg);
     }
+}
+
+// the rater records' flags from the complete item info (sharded item statistics: a rank's k_item_stats3 flagged the records
+// of ITS items only; after the all-gather of the item info every record is done here -- idempotent).  A record knows its
+// profile entry (e0 + position), the entry knows its item.
+__global__ __launch_bounds__(256) void k_rc_flags(long long nnz, RaterRec *rc, const int2 *ub, const double *info) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const RaterRec r = rc[p];
+    const int it = ub[(long long)r.e0 + (r.pos_ge & 0x7fffffff)].x & 0x7fffffff;
+    if ((double)r.rating >= info[(size_t)it * 4]) rc[p].pos_ge = (int)((unsigned)r.pos_ge | 0x80000000u);
 }
 
 // the profile copy's flags: rating >= average of the entry's item
@@ -1827,6 +1843,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     A.shard_occ = (unsigned long long *)d_shards + COO_SHARDS; A.coo_i = coo_i; A.coo_j = coo_j; A.coo_sim = coo_sim; A.coo_mutu = coo_mutu; A.coo_nij = coo_nij;
     A.coo_aux = coo_ls;
     A.raw = raw ? 1 : 0;
+    A.heavy_mod = (phases >> 16) & 0xff; A.heavy_rem = (phases >> 8) & 0xff;
+    if (A.heavy_mod < 1) A.heavy_mod = 1;
     A.rowcnt = rowcnt; A.mircnt = mircnt; A.rowcnt_h = rowcnt_h; A.counters = (unsigned long long *)d_counters;
     // phases 1 | 2 | 4 in one call: the heavy rows (chunk partials, then their merge) run on a side stream of their own,
     // next to the class launches of the light rows -- they share nothing but the atomic COO cursors and counters
@@ -2033,8 +2051,8 @@ int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_
 }
 
 /* Round-3 layout of stage A (one transposition per pass): see the declarations in include/xmap_hip.h. */
-int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, const double *rating64, int32_t ch_min, int32_t *cnt,
-                     double *u_avg, double *u_norm, int32_t *hist, int64_t *pre, int32_t *ctl, int32_t *hid, int32_t *hlist,
+int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, const double *rating64, int32_t ch_min, int32_t phases,
+                     int32_t stats_lo, int32_t stats_hi, int32_t *cnt, double *u_avg, double *u_norm, int32_t *hist, int64_t *pre, int32_t *ctl, int32_t *hid, int32_t *hlist,
                      uint64_t *ub_key, void *ub, void *srec, void *bufA, void *bufB, void *rc, uint64_t *Wp, double *info,
                      double *norms, int32_t *h_ctl) {
     XM_SCOPE(stream);
@@ -2042,18 +2060,21 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
     XM_ARG(ub_key && ub && srec && bufA && bufB && rc && Wp && info && norms && ch_min >= 64);
     XM_ARG(R->nnz < 0x7fffffffLL && R->n_users < 0x7ffffff0LL && R->n_items >= 0);
     XM_ARG(rating64 || u_norm);
+    XM_ARG(stats_lo >= 0 && stats_lo <= stats_hi && stats_hi <= R->n_items && (phases & ~15) == 0);
     hipStream_t st = (hipStream_t)stream;
     const int I = R->n_items;
     const long long nnz = R->nnz;
     const bool wide = rating64 != nullptr;
     const size_t In = (size_t)(I > 0 ? I : 1);
+    int rcode = XMAP_OK;
+    if (phases & 1) {
     // raters per item -> item_ptr
     XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * In, st));
     if (nnz > 0) {
         k_count3<<<dim3((unsigned)((nnz + CNT_CHUNK - 1) / CNT_CHUNK)), dim3(256), 0, st>>>(nnz, R->user_item, cnt);
         XM_LAUNCH_CHECK();
     }
-    int rcode = xmap_exclusive_scan_i32_to_i64(stream, cnt, item_ptr, I, nullptr);
+    rcode = xmap_exclusive_scan_i32_to_i64(stream, cnt, item_ptr, I, nullptr);
     if (rcode) return rcode;
     if (!wide) {
         rcode = xmap_user_stats(stream, R, u_avg, u_norm);
@@ -2123,8 +2144,9 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
             XM_LAUNCH_CHECK();
         }
     }
-    // item statistics from the rater records (+ their mutuality flags), big items in chunks; then the profile copy's flags
-    if (I > 0) {
+    }   // phases & 1
+    // item statistics of [stats_lo, stats_hi) from the rater records (+ those records' mutuality flags), big items in chunks
+    if ((phases & 2) && stats_hi > stats_lo) {
         BigList B;
         B.chunk_cap = nnz / STAT_CHK + nnz / STAT_BIG + 2;
         B.item_cap = nnz / STAT_BIG + 2;
@@ -2133,10 +2155,10 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
         XM_HIP(xm_malloc_async((void **)&B.items, sizeof(int4) * (size_t)B.item_cap, st));
         XM_HIP(xm_malloc_async((void **)&B.part, sizeof(double) * 5 * (size_t)B.chunk_cap, st));
         XM_HIP(hipMemsetAsync(B.counters, 0, 2 * sizeof(unsigned), st));
-        const dim3 grid((unsigned)((I + 15) / 16)), gridC((unsigned)((B.chunk_cap + 3) / 4)), gridI((unsigned)((B.item_cap + 63) / 64));
+        const dim3 grid((unsigned)((stats_hi - stats_lo + 15) / 16)), gridC((unsigned)((B.chunk_cap + 3) / 4)), gridI((unsigned)((B.item_cap + 63) / 64));
         if (wide) {
             const RcWideSrc src{(const RaterRecWide *)rc};
-            k_item_stats3<RcWideSrc><<<grid, dim3(256), 0, st>>>(I, (const long long *)item_ptr, src, info, norms, B);
+            k_item_stats3<RcWideSrc><<<grid, dim3(256), 0, st>>>(I, stats_lo, stats_hi, (const long long *)item_ptr, src, info, norms, B);
             XM_LAUNCH_CHECK();
             k_item_chunks<RcWideSrc><<<gridC, dim3(256), 0, st>>>((const long long *)item_ptr, src, B);
             XM_LAUNCH_CHECK();
@@ -2144,7 +2166,7 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
             XM_LAUNCH_CHECK();
         } else {
             const RcSrc src{(RaterRec *)rc, u_avg};
-            k_item_stats3<RcSrc><<<grid, dim3(256), 0, st>>>(I, (const long long *)item_ptr, src, info, norms, B);
+            k_item_stats3<RcSrc><<<grid, dim3(256), 0, st>>>(I, stats_lo, stats_hi, (const long long *)item_ptr, src, info, norms, B);
             XM_LAUNCH_CHECK();
             k_item_chunks<RcSrc><<<gridC, dim3(256), 0, st>>>((const long long *)item_ptr, src, B);
             XM_LAUNCH_CHECK();
@@ -2152,10 +2174,18 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
             XM_LAUNCH_CHECK();
             k_item_big_flags<RcSrc><<<gridC, dim3(256), 0, st>>>((const long long *)item_ptr, src, B, info);
             XM_LAUNCH_CHECK();
-            if (nnz > 0) {
-                k_ub_flags<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st>>>(nnz, (int2 *)ub, info);
-                XM_LAUNCH_CHECK();
-            }
+        }
+    }
+    // mutuality flags from the COMPLETE item info: the profile copy's (4), the rater records' of the items another rank's
+    // statistics covered (8)
+    if (!wide && nnz > 0 && I > 0) {
+        if (phases & 8) {
+            k_rc_flags<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st>>>(nnz, (RaterRec *)rc, (const int2 *)ub, info);
+            XM_LAUNCH_CHECK();
+        }
+        if (phases & 4) {
+            k_ub_flags<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st>>>(nnz, (int2 *)ub, info);
+            XM_LAUNCH_CHECK();
         }
     }
     if (h_ctl) {

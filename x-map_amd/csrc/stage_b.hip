@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
 // x of its range, the directory and the records of the ranges follow each other (x order is kept).  Rounds 1-2 fell back
 // to the dense n_nb x n_nb table beyond 40 000 non-bridge items (120 GB at 1e5) and the coarse ABI refused.
 constexpr int MIDROW_WAVES = 16;
-template <int PHASE>
+template <int PHASE, bool ONE_RANGE>
 __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int span, int *ng, long long *nrec, const long long *dir_ptr,
                                                                 const long long *rec_ptr, MidDir *dir) {
     extern __shared__ int bins[];                      // [span]
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
                     const int s = A.src_idx[p];
                     for (long long ap = A.att_ptr[s] + lane; ap < A.att_ptr[s + 1]; ap += 64) {
                         const int xid = A.nb_id[A.att_idx[ap]];
-                        if (xid >= x0 && xid < x1) body(xid, v2, m2, f2, p, ap);
+                        if (ONE_RANGE || (xid >= x0 && xid < x1)) body(xid, v2, m2, f2, p, ap);
                     }
                 }
             }
@@ -867,9 +867,9 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
     };
     unsigned long long done = 0;                        // (non-empty tiles << 40 | records) of the ranges before this one
     const long long rbase = PHASE ? rec_ptr[xpid] : 0, dbase = PHASE ? dir_ptr[xpid] : 0;
-    for (int x0 = 0; x0 < n_nb; x0 += span) {
-        const int x1 = (x0 + span) < n_nb ? (x0 + span) : n_nb, nx = x1 - x0;
-        __syncthreads();                                // (the previous range's placement is over)
+    for (int x0 = 0; x0 < n_nb; x0 += ONE_RANGE ? n_nb : span) {
+        const int x1 = (ONE_RANGE || (x0 + span) >= n_nb) ? n_nb : (x0 + span), nx = x1 - x0;
+        if (!ONE_RANGE) __syncthreads();                // (the previous range's placement is over)
         for (int i = threadIdx.x; i < nx; i += 64 * MIDROW_WAVES) bins[i] = 0;
         __syncthreads();
         walk(x0, x1, [&](int xid, double, double, double, long long, long long) { atomicAdd(&bins[xid - x0], 1); });
@@ -1998,9 +1998,15 @@ int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t 
     if (rc) return rc;
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
                          src_flag, n_nb, nb_list, nb_id);
-    XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_mid_rows<0><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, span, ng, (long long *)nrec, nullptr,
-                                                                                              nullptr, nullptr);
+    if (span >= n_nb) {
+        XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_mid_rows<0, true><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, span, ng, (long long *)nrec,
+                                                                                                       nullptr, nullptr, nullptr);
+    } else {
+        XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_mid_rows<0, false><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, span, ng, (long long *)nrec,
+                                                                                                        nullptr, nullptr, nullptr);
+    }
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -2020,9 +2026,15 @@ int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t 
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
                          src_flag, n_nb, nb_list, nb_id);
     A.midX = (MidX *)midX;
-    XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_mid_rows<1><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(
-        A, span, nullptr, nullptr, (const long long *)dir_ptr, (const long long *)rec_ptr, (MidDir *)dir);
+    if (span >= n_nb) {
+        XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_mid_rows<1, true><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(
+            A, span, nullptr, nullptr, (const long long *)dir_ptr, (const long long *)rec_ptr, (MidDir *)dir);
+    } else {
+        XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_mid_rows<1, false><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(
+            A, span, nullptr, nullptr, (const long long *)dir_ptr, (const long long *)rec_ptr, (MidDir *)dir);
+    }
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }

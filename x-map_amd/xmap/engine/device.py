@@ -433,11 +433,13 @@ class Engine(object):
             L._heavy_half = int(L.Wp[L.hlist[:L.n_heavy].long()].sum().item()) if L.n_heavy else 0
         return L._heavy_half
 
-    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False):
+    def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False,
+                  heavy_deal=None):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
         rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity).
         split: count a row's own pairs (rowcnt) and the pairs lighter rows computed for it (a 5th return value) apart --
-        what tri_mirror takes."""
+        what tri_mirror takes.  heavy_deal = (rank, world): of the heavy rows only those with item index % world == rank
+        (item-sharded ranks deal them round-robin; chunk partials and merge of a row stay on one rank)."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -465,7 +467,10 @@ class Engine(object):
             d_shards = self._empty(2 * 4096, torch.int64)
             rowcnt_h = self._empty(64 * 1024, torch.int32)
 
+            deal = 0 if heavy_deal is None else ((int(heavy_deal[1]) & 0xff) << 16) | ((int(heavy_deal[0]) & 0xff) << 8)
+
             def run(phases):
+                phases |= deal
                 check(lib.xmap_sim2_pairs(
                     st, C.byref(R.c), m, int(cap), vp(u_avg), vp(self.norms), vp(L.rc), vp(L.ub), vp(L.Q), vp(L.small),
                     vp(L.uq_item),
@@ -488,7 +493,7 @@ class Engine(object):
                 if L.slot_target <= 32:
                     raise abi.XmapError(abi.ERR_OVERFLOW, "pair-table overflow")
                 if not retry:      # sharded callers re-plan collectively
-                    return None, rowcnt, 0, 0, 1
+                    return (None, rowcnt, 0, 0) + ((None, None) if split else ()) + (1,)
                 getattr(L, "replan", self._tri_plan)(L, L.slot_target // 2)
                 continue
             if h[3]:            # a COO shard overflowed: more slack
@@ -503,7 +508,7 @@ class Engine(object):
         coo = (coo_i, coo_j, coo_sim, coo_mutu, coo_nij) + ((coo_ls,) if (rec or raw) else ())
         out = (coo, rowcnt, n, n_unordered)
         if split:
-            return out + (mircnt, d_shards)
+            return out + (mircnt, d_shards) + (() if retry else (0,))
         return out if retry else out + (0,)
 
     def tri_scatter(self, coo, rowcnt, info, n=None, L=None):
@@ -564,11 +569,13 @@ class Engine(object):
                                       vp(col), vp(sim), vp(ls)))
         return cnt[:I], col[:I], sim[:I], ls[:I]
 
-    def layout3(self, slot_target=640, ch_min=1024, wide=False):
+    def layout3(self, slot_target=640, ch_min=1024, wide=False, item_range=None):
         """Round-3 layout of the "tri" formulation, one transposition per pass (xmap_sim3_layout): item counts, user and
         item info, weight-sorted profiles, rater records through the tile sort, heavy set, work units.  Returns (stats, L)
         like stats() + tri_layout().  wide: fp64 ratings (R.user_rating64) with zero user averages -- the RecommenderSim
-        variant."""
+        variant.  item_range (item-sharded ranks): the item statistics of that share of the items only; the caller then
+        completes stats[2] (info) and self.norms on every rank -- the all-gather of per-item norms -- and calls L.finish(),
+        which sets the mutuality flags from them and plans the work units."""
         R = self.R
         st = _stream(self.dev)
         I, U, nnz = R.n_items, R.n_users, R.nnz
@@ -597,15 +604,27 @@ class Engine(object):
         r64 = None
         if wide:
             r64 = R.user_rating64 if R.user_rating64 is not None else R.user_rating.double()
-        with self.timed("layout3"):
-            check(lib.xmap_sim3_layout(st, C.byref(R.c), vp(R.item_ptr), vp(r64), i32(ch_min), vp(cnt),
+        def call(phases, lo, hi):
+            check(lib.xmap_sim3_layout(st, C.byref(R.c), vp(R.item_ptr), vp(r64), i32(ch_min), i32(phases), i32(lo), i32(hi), vp(cnt),
                                        vp(u_avg), vp(u_norm), vp(L.hist), vp(L.pre), vp(L.ctl), vp(L.hid), vp(L.hlist),
                                        vp(L.ub_key), vp(L.ub), vp(srec), vp(buf_a), vp(buf_b), vp(L.rc), vp(L.Wp), vp(info),
                                        vp(self.norms), None))
         R.csc_ready = False             # item_ptr is current; item_user / item_rating are not built on this path
         L.ch_min = int(ch_min)
         L.half_contrib = R.half_contrib          # = sum of W+ over the items (the host knows it from the profile lengths)
-        self._tri_plan3(L, slot_target)
+        if item_range is None:
+            with self.timed("layout3"):
+                call(1 | 2 | 4, 0, I)
+            self._tri_plan3(L, slot_target)
+        else:
+            with self.timed("layout3"):
+                call(1 | 2, int(item_range[0]), int(item_range[1]))
+
+            def finish():
+                with self.timed("layout3_flags"):
+                    call(4 | 8, 0, I)
+                self._tri_plan3(L, slot_target)
+            L.finish = finish
         return (u_avg, u_norm, info, None, None), L
 
     def tri_mirror(self, coo, own, mir, info, n, shards=None):

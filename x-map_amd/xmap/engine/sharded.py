@@ -1,10 +1,11 @@
 """One pass of the hot path, optionally item-sharded over the ranks of one node.
 
-Sharding: inputs (CSR + CSC) are replicated in every GPU's HBM; the work is sharded by
-item.  Stage A: the per-item statistics are computed for a share of the items and all-gathered (32 B x I: the all-gather of
-item norms); the work units (item, partition) of the pair kernel are split into contiguous ranges of
-equal rater-steps; each rank appends the kept pairs of its units to a half COO (every unordered pair is
-owned by exactly one unit, so there are no cross-GPU partials) and mirrors them into a CSR of its own:
+Sharding: the ratings (CSR by user) are replicated in every GPU's HBM; the work is sharded by
+item.  Stage A: every rank lays the ratings out (one transposition: 1.6 ms, replicated), the per-item statistics are
+computed for a share of the items and all-gathered (32 B x I: the all-gather of item norms) before the mutuality flags are
+set from them; the work units (item, partition) of the pair kernel are split into contiguous ranges of
+equal rater-steps and the heavy rows dealt round-robin; each rank appends the kept pairs of its units to a half COO (every
+unordered pair is owned by exactly one unit, so there are no cross-GPU partials) and mirrors them into a CSR of its own:
 that is the rank's partition of item2item_simRDD (both directions of its pairs), and where stage A ends.  Stage B starts with the exchange its input needs (the reference
 broadcasts the knn tables, utils/assist.py:88-101): the per-item row counts are all-reduced, the COO parts
 all-gathered (S4/S6 of SURVEY 2.3) and every rank mirrors the full COO into the CSR; then
@@ -176,34 +177,48 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
 
     comm = Comm(dist, group)
     dev = eng.dev
-    # ---- stage A: every rank lays out the (replicated) ratings, computes the pairs of its share of the
-    # work units into a half COO, the COO parts are all-gathered and mirrored into the full CSR everywhere
+    # ---- stage A: every rank lays out the (replicated) ratings -- one transposition, rater records through the tile sort --,
+    # the item statistics are computed for a share of the items and all-gathered; every rank computes the pairs of its share
+    # of the work units (+ its share of the heavy rows) into a half COO and mirrors them into a CSR of its own
     with eng.timed("stage_a"):
-        # per-item statistics of a share of the items, then ONE all-gather of the 32-byte item records and the two dense
-        # norm columns (S3 of SURVEY 2.3: the reference collects and broadcasts item_info, utils/assist.py:71-73)
         ilo, ihi = I * rank // world, I * (rank + 1) // world
-        stats = eng.stats(item_range=(ilo, ihi))
-        with eng.timed("stats_gather"):
-            info = stats[2]
-            info[:I] = comm.all_gather_var(info[ilo:ihi].reshape(-1)).view(I, 4)
-            nI = max(I, 1)
-            for c0 in (0, nI):
-                eng.norms[c0:c0 + I] = comm.all_gather_var(eng.norms[c0 + ilo:c0 + ihi].contiguous())
-        L = eng.tri_layout(stats)
+        nI = max(I, 1)
+
+        def gather(info, norms):
+            # ONE exchange of the 32-byte item records and the two dense norm columns (S3 of SURVEY 2.3: the reference
+            # collects and broadcasts item_info, utils/assist.py:71-73) -- the all-gather of per-item norms
+            with eng.timed("stats_gather"):
+                info[:I] = comm.all_gather_var(info[ilo:ihi].reshape(-1)).view(I, 4)
+                for c0 in (0, nI):
+                    norms[c0:c0 + I] = comm.all_gather_var(norms[c0 + ilo:c0 + ihi].contiguous())
+        # (no collective between a possible raise and the agree() that follows it)
+        err, stats, L = None, None, None
+        try:
+            stats, L = eng.layout3(item_range=(ilo, ihi))
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage A (layout)")
+        gather(stats[2], eng.norms)
+        err = None
+        try:
+            L.finish()
+        except Exception as e:
+            err = e
+        comm.agree(err, "stage A (flags + plan)")
         while True:
             # contiguous unit ranges of equal rater-steps: prefix sum and cut points on the device (the units are listed
-            # by table class, every rank gets a slice of every class boundary it spans)
+            # by table class, every rank gets a slice of every class boundary it spans); the heavy rows are dealt
+            # round-robin by item index, so every rank carries about 1 / world of their rater visits
             lo, hi = 0, 0
             if L.n_light:
                 n_i = (eng.R.item_ptr[1:] - eng.R.item_ptr[:-1])
                 c = torch.cumsum(n_i[L.uq_item[:L.n_light].long()].double(), 0)
-                w_heavy = n_i[L.hlist[:L.n_heavy].long()].sum().double() if L.n_heavy else None
-                cuts = unit_cuts(c, w_heavy, world)
+                cuts = unit_cuts(c, None, world)
                 lo, hi = int(cuts[rank]), int(cuts[rank + 1])
             err, ovf = None, 0
             try:
-                coo, rowcnt, n, n_unordered, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi),
-                                                                 do_heavy=(rank == 0), retry=False)
+                coo, own, n, n_unordered, mir, shards, ovf = eng.tri_pairs(method, cap, stats, L, unit_range=(lo, hi), retry=False,
+                                                                           split=True, heavy_deal=(rank, world))
             except Exception as e:          # e.g. half-COO overflow on this rank only
                 err = e
             comm.agree(err, "stage A (pair kernels)")
@@ -211,15 +226,15 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             comm.all_reduce(flag, "max")
             if int(flag.item()) == 0:
                 break
-            eng._tri_plan(L, L.slot_target // 2)      # every rank re-plans identically
+            L.replan(L, L.slot_target // 2)      # every rank re-plans identically
         # the rank's partition of item2item_simRDD: both directions of ITS kept pairs, CSR by first item (the same
         # mirror step a single GPU does for all pairs)
-        S_part = eng.tri_scatter(coo, rowcnt, stats[2], n, L)
+        S_part = eng.tri_mirror(coo, own, mir, stats[2], n, shards)
         tot = torch.tensor([n_unordered, n], dtype=torch.int64, device=dev)
         comm.all_reduce(tot)
         it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
         light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
-    S, E, pt = _stage_b(eng, comm, coo, rowcnt, stats[2], L, k, rank, world, n)
+    S, E, pt = _stage_b(eng, comm, coo, (own, mir), stats[2], L, k, rank, world, n)
     # ---- stage C: replicated (a few ms)
     with eng.timed("stage_c"):
         n_top, choice, mp = eng.select(E, private)
@@ -322,16 +337,19 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
         # utils/assist.py:88-101): the ranks' COO parts are exchanged here -- per-item row counts all-reduced, the
         # compacted parts (one index list for the five columns) sent as ONE variable-length all-gather of 24-byte
         # records (i | j << 32, sim bits, mutu | n_ij << 32) -- and every rank mirrors the full COO into the CSR.
+        split = isinstance(rowcnt, tuple)          # (own, mirrored) counts of the round-3 mirror, or one combined array
         with eng.timed("exchange"):
-            comm.all_reduce(rowcnt)
+            for c_ in (rowcnt if split else (rowcnt,)):
+                comm.all_reduce(c_)
             rec = eng.pack_pairs(coo, n_local)                                  # library kernels, no torch arithmetic
             rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
+            n_all = int(rec.shape[0])
             coo = eng.unpack_pairs(rec)
         # No collective sits between a possible raise and the agree() that follows it: the local phases run in try blocks,
         # the all-gathers of the knn tables (ext_gather) run outside any of them.
         err, S, E = None, None, None
         try:
-            S = eng.tri_scatter(coo, rowcnt, info, None, L)
+            S = eng.tri_mirror(coo, rowcnt[0], rowcnt[1], info, n_all) if split else eng.tri_scatter(coo, rowcnt, info, None, L)
             E = eng.ext_knn(S, k, comm)
         except Exception as e:
             err = e
