@@ -98,7 +98,7 @@ static int reverse_list(xmap_ctx *c, int mode, const uint8_t *bb, const int64_t 
     XM_ALLOCZ(c->p_ext, rcnt, I);
     XM_ALLOCZ(c->p_ext, ptr, I + 1);
     XM_TRY(xmap_reverse_count(c->st, &c->S, mode, k, bb, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->R.suffix_cls,
-                              c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, rcnt));
+                              c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, rcnt, 0, I));
     int64_t n = 0;
     XM_TRY(xmap_exclusive_scan_i32_to_i64(c->st, rcnt, ptr, I, &n));
     int32_t *idx;
@@ -108,7 +108,7 @@ static int reverse_list(xmap_ctx *c, int mode, const uint8_t *bb, const int64_t 
     XM_ALLOC(c->p_ext, val, 3 * (size_t)(n ? n : 1));
     XM_ALLOCZ(c->p_ext, flag, n);
     XM_TRY(xmap_reverse_fill(c->st, &c->S, mode, k, bb, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->R.suffix_cls,
-                             c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, ptr, idx, val, flag));
+                             c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, ptr, idx, val, flag, 0, I));
     *rptr = ptr; *ridx = idx; *rval = val; *rflag = flag;
     return XMAP_OK;
 }

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void k_knn_thresholds(int I, int k, const int 
 
 struct RevArgs {
     int I, k, mode;
+    int row_lo, row_hi;          // the rows (= targets of the reverse lists) of this call: a rank's share, or [0, I)
     const KnnThr *thr;
     const int *long_rows;        // [0] = count, then the rows with more than rev_long entries (or NULL)
     int rev_long;
@@ -377,8 +378,8 @@ constexpr int REV_LONG = 4096;      // default of RevArgs::rev_long (XMAP_REV_LO
 constexpr int REV_WAVES = 16;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
-    int a = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (a >= A.I) return;
+    int a = A.row_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= A.row_hi) return;
     int lane = lane_id();
     long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
     if (A.long_rows && hi - lo > A.rev_long) return;
@@ -400,9 +401,10 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     if (!FILL && lane == 0) A.rcnt[a] = total;
 }
 
-__global__ __launch_bounds__(256) void k_rev_long_rows(int I, const long long *row_ptr, int rev_long, int *long_rows /*[0] = count*/) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < I && row_ptr[a + 1] - row_ptr[a] > rev_long) long_rows[1 + atomicAdd(&long_rows[0], 1)] = a;
+__global__ __launch_bounds__(256) void k_rev_long_rows(int row_lo, int row_hi, const long long *row_ptr, int rev_long,
+                                                       int *long_rows /*[0] = count*/) {
+    const int a = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < row_hi && row_ptr[a + 1] - row_ptr[a] > rev_long) long_rows[1 + atomicAdd(&long_rows[0], 1)] = a;
 }
 
 template <bool FILL>
@@ -1777,13 +1779,15 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
                           const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
                           const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
                           const int64_t *attach_ptr, const void *thr, int32_t *long_rows, int32_t *rcnt, const int64_t *rptr,
-                          int32_t *ridx, double *rval, uint8_t *rflag) {
+                          int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo, int32_t row_hi) {
     XM_ARG(S && bb && cls && kcnt && kcol && kval && suffix_cls && contains_mask && flags);
     XM_ARG(mode >= 0 && mode <= 2);
     XM_ARG(mode != 1 || attach_ptr);
-    if (S->n_items == 0) return XMAP_OK;
+    XM_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= S->n_items);
+    if (row_hi == row_lo) return XMAP_OK;
     RevArgs A;
     A.I = S->n_items; A.k = top_k; A.mode = mode; A.thr = (const KnnThr *)thr; A.long_rows = long_rows;
+    A.row_lo = row_lo; A.row_hi = row_hi;
     const char *rl = getenv("XMAP_REV_LONG");
     A.rev_long = (rl && atoi(rl) > 0) ? atoi(rl) : REV_LONG;
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
@@ -1791,12 +1795,13 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
     A.attach_ptr = (const long long *)attach_ptr;
     A.rcnt = rcnt; A.rptr = (const long long *)rptr; A.ridx = ridx; A.rval = rval; A.rflag = rflag;
-    dim3 grid((unsigned)((S->n_items + 3) / 4)), block(256);
+    const int n_rows = row_hi - row_lo;
+    dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (long_rows && !fill) {     // the count pass lists the long rows, the fill pass that follows reuses the list
         XM_HIP(hipMemsetAsync(long_rows, 0, sizeof(int32_t), st));
-        k_rev_long_rows<<<dim3((unsigned)((S->n_items + 255) / 256)), dim3(256), 0, st>>>(S->n_items, (const long long *)S->row_ptr,
-                                                                                      A.rev_long, long_rows);
+        k_rev_long_rows<<<dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st>>>(row_lo, row_hi, (const long long *)S->row_ptr,
+                                                                                  A.rev_long, long_rows);
         XM_LAUNCH_CHECK();
     }
     if (fill) k_reverse<true><<<grid, block, 0, st>>>(A);
@@ -1823,19 +1828,20 @@ int xmap_knn_thresholds(void *stream, int32_t n_items, int top_k, const int32_t 
 int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                        const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                        const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, const void *thr,
-                       int32_t *long_rows, int32_t *rcnt) {
+                       int32_t *long_rows, int32_t *rcnt, int32_t row_lo, int32_t row_hi) {
     XM_ARG(rcnt);
     return reverse_common(stream, false, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
-                          attach_ptr, thr, long_rows, rcnt, nullptr, nullptr, nullptr, nullptr);
+                          attach_ptr, thr, long_rows, rcnt, nullptr, nullptr, nullptr, nullptr, row_lo, row_hi);
 }
 
 int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, const void *thr,
-                      int32_t *long_rows, const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag) {
+                      int32_t *long_rows, const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo,
+                      int32_t row_hi) {
     XM_ARG(rptr && ridx && rval);
     return reverse_common(stream, true, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
-                          attach_ptr, thr, long_rows, nullptr, rptr, ridx, rval, rflag);
+                          attach_ptr, thr, long_rows, nullptr, rptr, ridx, rval, rflag, row_lo, row_hi);
 }
 
 int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end, const double *xs_val,

@@ -732,23 +732,59 @@ class Engine(object):
         return E
 
     def _reverse(self, S, E, mode, attach_ptr):
+        """one reverse adjacency (mode 0 attach, 1 src, 2 rnn), all rows on this device"""
+        st8 = self.reverse_count(S, E, mode, attach_ptr, None)
+        self.reverse_fill(st8)
+        return st8.out
+
+    def reverse_count(self, S, E, mode, attach_ptr, rows):
+        """count pass of one reverse adjacency over the rows [lo, hi) (None: all).  The list of a row is built from that row
+        of the similarity matrix alone (the matrix is symmetric: "b lists a" is tested on a's own entry for b), so a rank's
+        share of the rows is a contiguous share of the lists -- item-sharded ranks all-gather the pieces (reverse_gather_*)."""
         R = self.R
-        st = _stream(self.dev)
         I = R.n_items
-        rcnt = self._zeros(max(I, 1), torch.int32)
-        args = (C.byref(S.c), mode, E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval),
-                vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(attach_ptr), vp(getattr(E, "thr", None)),
-                vp(getattr(E, "long_rows", None)))
-        check(lib.xmap_reverse_count(st, *args, vp(rcnt)))
+        st8 = ExtResult()
+        st8.S, st8.E, st8.mode = S, E, mode
+        st8.rows = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
+        st8.rcnt = self._zeros(max(I, 1), torch.int32)
+        st8.args = (C.byref(S.c), mode, E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval),
+                    vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(attach_ptr), vp(getattr(E, "thr", None)),
+                    vp(getattr(E, "long_rows", None)))
+        st8.keep = attach_ptr
+        check(lib.xmap_reverse_count(_stream(self.dev), *st8.args, vp(st8.rcnt), i32(st8.rows[0]), i32(st8.rows[1])))
+        return st8
+
+    def reverse_gather_counts(self, st8, comm):
+        """collective: every rank's counts of its rows -> the counts of all rows"""
+        I = self.R.n_items
+        lo, hi = st8.rows
+        st8.rcnt[:I] = comm.all_gather_var(st8.rcnt[lo:hi].contiguous())
+
+    def reverse_fill(self, st8):
+        """offsets of all rows (scan of the complete counts), then the entries of this device's rows"""
+        I = self.R.n_items
+        st = _stream(self.dev)
         rptr = self._zeros(I + 1, torch.int64)
         tot = C.c_int64(0)
-        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(rcnt), vp(rptr), i64(I), C.byref(tot)))
+        check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(st8.rcnt), vp(rptr), i64(I), C.byref(tot)))
         n = int(tot.value)
         ridx = self._empty(max(n, 1), torch.int32)
         rval = self._empty((max(n, 1), 3), torch.float64)
         rflag = self._zeros(max(n, 1), torch.uint8)
-        check(lib.xmap_reverse_fill(st, *args, vp(rptr), vp(ridx), vp(rval), vp(rflag)))
-        return rptr, ridx, rval, rflag, n
+        check(lib.xmap_reverse_fill(st, *st8.args, vp(rptr), vp(ridx), vp(rval), vp(rflag), i32(st8.rows[0]), i32(st8.rows[1])))
+        st8.out = (rptr, ridx, rval, rflag, n)
+
+    def reverse_gather(self, st8, comm):
+        """collective: the ranks' pieces of the lists, in rank (= row) order"""
+        rptr, ridx, rval, rflag, n = st8.out
+        lo, hi = st8.rows
+        ends = rptr[[lo, hi]].tolist()
+        a, b = int(ends[0]), int(ends[1])
+        if n:
+            ridx[:n] = comm.all_gather_var(ridx[a:b].contiguous())
+            rval[:n] = comm.all_gather_var(rval[a:b].reshape(-1)).view(n, 3)
+            rflag[:n] = comm.all_gather_var(rflag[a:b].contiguous())
+        return st8.out
 
     def path_units(self, E, start_range=None, chunk=None, row_budget=48 << 30, start_split=None):
         """Work units of the path enumeration from the exact per-start path counts: starts with more than
@@ -949,6 +985,7 @@ class Engine(object):
             rows = (int(cuts[comm.rank]), int(cuts[comm.rank + 1]))
         E = self.knn(S, top_k, rows=rows)
         E.rows = rows
+        E.row_share = rows          # (kept for the reverse lists of a sharded step)
         ok = C.c_int32(1)
         check(lib.xmap_edge_ranges(_stream(self.dev), C.byref(S.c), C.byref(ok)))
         E.fast_div = int(ok.value)       # the bare division sequence of k_paths4 is the division for these edge values
@@ -970,14 +1007,17 @@ class Engine(object):
         E.rows = None
         return E
 
-    def ext_reverse(self, S, E):
-        """local part: list thresholds and the three reverse adjacencies from the complete knn tables"""
+    def ext_thresholds(self, E):
         I = self.R.n_items
-        st = _stream(self.dev)
+        E.thr = self._empty(max(I, 1) * 4, torch.float64)      # last entry of every list, 16 B each
+        check(lib.xmap_knn_thresholds(_stream(self.dev), i32(I), E.k, vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(E.thr)))
+        E.long_rows = self._empty(max(I, 1) + 1, torch.int32)
+
+    def ext_reverse(self, S, E):
+        """local part: list thresholds and the three reverse adjacencies from the complete knn tables (item-sharded ranks
+        run the three in row shares: xmap.engine.sharded._stage_b)"""
         with self.timed("reverse"):
-            E.thr = self._empty(max(I, 1) * 4, torch.float64)      # last entry of every list, 16 B each
-            check(lib.xmap_knn_thresholds(st, i32(I), E.k, vp(E.kcnt), vp(E.kcol), vp(E.kval), vp(E.thr)))
-            E.long_rows = self._empty(max(I, 1) + 1, torch.int32)
+            self.ext_thresholds(E)
             E.att = self._reverse(S, E, 0, None)
             E.src = self._reverse(S, E, 1, E.att[0])
             E.rnn = self._reverse(S, E, 2, None)

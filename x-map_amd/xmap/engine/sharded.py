@@ -355,9 +355,34 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
             err = e
         comm.agree(err, "stage B (mirror + knn tables)")
         eng.ext_gather(E, comm)
+        # the three reverse adjacencies (attach / src / rnn) in row shares: the list of a row comes from that row alone, so
+        # the ranks' pieces are contiguous -- counts all-gathered, entries all-gathered (S8 / S9 of SURVEY 2.3)
+        rows = getattr(E, "row_share", None)
+        with eng.timed("reverse"):
+            err = None
+            try:
+                eng.ext_thresholds(E)
+            except Exception as e:
+                err = e
+            comm.agree(err, "stage B (list thresholds)")
+            for mode, name in ((0, "att"), (1, "src"), (2, "rnn")):
+                err, st8 = None, None
+                try:
+                    st8 = eng.reverse_count(S, E, mode, E.att[0] if mode == 1 else None, rows)
+                except Exception as e:
+                    err = e
+                comm.agree(err, "stage B (reverse lists: count)")
+                if rows is not None:
+                    eng.reverse_gather_counts(st8, comm)
+                err = None
+                try:
+                    eng.reverse_fill(st8)
+                except Exception as e:
+                    err = e
+                comm.agree(err, "stage B (reverse lists: fill)")
+                setattr(E, name, eng.reverse_gather(st8, comm) if rows is not None else st8.out)
         err = None
         try:
-            eng.ext_reverse(S, E)
             E = eng.extend_tables(E, False, None, start_split=(rank, world))
         except Exception as e:
             err = e
