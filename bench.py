@@ -325,17 +325,52 @@ def bench_api(args, rank, world, local, dist):
     k = args.k or wl["k"]
     t0 = time.time()
     r = wl["gen"]()
-    recs = r.train_records()
-    t_rec = time.time() - t0
     sc = SparkContext(conf=SparkConf().setAppName("bench"))
     sqlContext = SQLContext(sc)
-    trainRDD = sc.parallelize(recs, 8).cache()
+    setup = {}
+    if args.feed:
+        # the native feeder (csrc/feeder.hip): the workload as two Amazon-format text files' worth of bytes (written by the
+        # library's formatting utility: test infrastructure, timed apart), parsed + cleaned + indexed in C++, merged into the
+        # train set; no Python object per rating anywhere
+        import ctypes as C
+        from xmap.engine import feeder, hipabi
+        os.environ["TZ"] = "UTC"            # the clean stage filters by LOCAL-time year (baselinerClean.py:36,48); the synthetic
+        time.tzset()                        # timestamps lie in 2012-2013 UTC
+        numbers = np.concatenate([r.src_numbers, r.tgt_numbers]).astype(np.int64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+        def text_of(lo, hi, fmt):
+            n = C.c_int64(0)
+            args_ = (C.c_int64(r.n_users), p(r.user_ptr), p(r.item), p(r.rating), p(r.time), b"A%013lld", fmt, p(numbers),
+                     C.c_int32(lo), C.c_int32(hi))
+            hipabi.check(hipabi.lib.xmap_feed_format(*args_, None, C.c_int64(0), C.byref(n)))
+            buf = C.create_string_buffer(int(n.value))
+            hipabi.check(hipabi.lib.xmap_feed_format(*args_, buf, C.c_int64(int(n.value)), C.byref(n)))
+            return buf.raw[:int(n.value)]
+        t1 = time.time()
+        src_text, tgt_text = text_of(0, r.n_src_items, b"%010lld"), text_of(r.n_src_items, r.n_items, b"B0%08lld")
+        setup["text_written_s"] = time.time() - t1
+        setup["text_bytes"] = len(src_text) + len(tgt_text)
+        t1 = time.time()
+        fm = feeder.Feed.from_texts([(src_text, "S:"), (tgt_text, "T:")], 2012, 2013, 1)
+        setup["feeder_parse_clean_index_merge_s"] = time.time() - t1
+        assert fm.nnz == r.nnz and fm.n_items == r.n_items and fm.n_users == r.n_users
+        del src_text, tgt_text
+        trainRDD = feeder.FeedRDD(fm, sc)
+        n_recs = fm.n_users
+    else:
+        recs = r.train_records()
+        setup["python_records_s"] = time.time() - t0
+        trainRDD = sc.parallelize(recs, 8).cache()
+        n_recs = len(recs)
+    t_rec = time.time() - t0
     sim_tool, ext_tool, gen_tool = BaselinerSim(args.method, CAP), ExtendSim(k), Generator(1, 0.6, args.method, 0.1)
     t0 = time.time()
     sim = baseliner_calculate_sim_pipeline(sc, sim_tool, trainRDD)
     torch.cuda.synchronize()
     t_setup = time.time() - t0
-    log("api: %d records built in %.1f s; first baseliner call (id dictionary + CSR + upload + stage A) %.1f s" % (len(recs), t_rec, t_setup))
+    setup["first_call_id_tables_upload_stage_a_s"] = t_setup
+    log("api: %d records ready in %.1f s; first baseliner call (id tables + upload + stage A) %.1f s" % (n_recs, t_rec, t_setup))
     # the 1.2e7 Python objects of the record list are static from here on: keep the cyclic collector from walking them
     # in the middle of a timed call (a full collection over them is ~0.1 s; a Spark driver would not hold the records)
     import gc
@@ -377,7 +412,7 @@ def bench_api(args, rank, world, local, dist):
           "alterego_profiles_per_s": n_prof / (t_b + t_c), "alterego_rows": G.n_rows, "profiles": n_prof,
           "stage_ms": {"A_item_sim": t_a * 1e3, "B_extend": t_b * 1e3, "C_generate": t_c * 1e3},
           "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
-          "setup_s": {"python_records": t_rec, "first_call_id_dictionary_csr_upload_stage_a": t_setup}})
+          "setup_s": setup})
 
 
 def main():
@@ -392,6 +427,7 @@ def main():
     ap.add_argument("--layout", default="items", choices=["items", "users"])   # N > 1: replicated ratings + item-sharded work
     #                                             (default), or user-sharded ratings + exchange of the partial similarities
     ap.add_argument("--api", action="store_true")        # configs[1] through the pipeline API of the drop-in package (one GPU)
+    ap.add_argument("--feed", action="store_true")       # --api: the train set through the native feeder (text -> CSR in C++)
     ap.add_argument("--no-extra", action="store_true")   # default c2 run at N = 1: skip the short recsim / dense lines
     args = ap.parse_args()
 

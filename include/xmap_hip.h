@@ -541,6 +541,35 @@ int xmap_alterego_fill(void *stream, const xmap_ratings *R, const int32_t *map_s
  *   xmap_ctx_gen_download   : AlterEgo rows (user, item, rating fp64, time), pass-through target rows first
  * Errors: negative return code, text in xmap_last_error(). */
 typedef struct xmap_ctx xmap_ctx;
+
+/* ---- native feeder (csrc/feeder.hip; host code, no GPU): raw lines `uid iid rating unix_ts` (reference README.md:41-42) ->
+ * id tables + CSR + predicate arrays, with the reference's clean stage in between (core/baselinerClean.py:40-101: fields =
+ * re.split(r"\s+"), local-time year in [year_from, year_to], item id = field + label, the latest rating of an item wins in
+ * place, users with fewer than min_ratings ratings dropped; users in first-seen order, items in lexicographic id order).
+ *   xmap_feed_text   : one domain's text                       xmap_feed_merge : source + target feed of one problem
+ *   xmap_feed_texts  : the domains of one problem in one call (= the merge of their feeds, without building them)
+ *   xmap_feed_sizes  : {users, items, ratings, bytes of the user ids, bytes of the item ids, lines read, lines in the period}
+ *   xmap_feed_arrays : copies into caller buffers (any but user_ptr may be NULL); when = the timestamps as doubles
+ *   xmap_feed_ids    : the id strings back to back + offsets [n + 1] (which = 0 users, 1 items; bytes may be NULL); which | 2:
+ *                      a newline behind every id (bytes + n in all; offsets may then be NULL)
+ *   xmap_ctx_upload_feed : the coarse ABI's upload straight from a feed (xmap_ctx_upload_ratings on its arrays)
+ *   xmap_feed_format : test / bench utility, the inverse for one domain (items [item_lo, item_hi) of a CSR -> text) */
+typedef struct xmap_feed xmap_feed;
+int xmap_feed_text(const char *text, int64_t len, int32_t year_from, int32_t year_to, const char *label, int32_t min_ratings,
+                   xmap_feed **out);
+int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *lens, const char *const *labels, int32_t year_from,
+                    int32_t year_to, int32_t min_ratings, xmap_feed **out);
+int xmap_feed_merge(const xmap_feed *a, const xmap_feed *b, xmap_feed **out);
+int xmap_feed_sizes(const xmap_feed *f, int64_t *sizes /*[7]*/);
+int xmap_feed_arrays(const xmap_feed *f, int64_t *user_ptr, int32_t *item, double *rating, double *when, int32_t *prefix_cls,
+                     int32_t *suffix_cls, uint32_t *contains_mask, uint8_t *flags);
+int xmap_feed_ids(const xmap_feed *f, int32_t which, char *bytes, int64_t *offsets);
+void xmap_feed_free(xmap_feed *f);
+int xmap_ctx_upload_feed(xmap_ctx *ctx, const xmap_feed *f);
+int xmap_feed_format(int64_t n_users, const int64_t *user_ptr, const int32_t *item, const float *rating, const int64_t *when,
+                     const char *uid_fmt, const char *iid_fmt, const int64_t *item_number, int32_t item_lo, int32_t item_hi,
+                     char *out, int64_t cap, int64_t *written);
+
 int xmap_ctx_create(int device, xmap_ctx **out);
 void xmap_ctx_destroy(xmap_ctx *ctx);
 int xmap_ctx_upload_ratings(xmap_ctx *ctx, int64_t n_users, int32_t n_items, const int64_t *user_ptr, const int32_t *item,

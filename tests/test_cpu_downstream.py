@@ -43,6 +43,63 @@ def test_clean_matches_reference(gold, tmp_path):
     assert [u for u, _ in debug] == g["partial"] and len(debug) <= g["params"][1]
 
 
+def test_native_feeder_matches_reference(gold, tmp_path, monkeypatch):
+    """csrc/feeder.hip (text -> id tables + CSR + predicate arrays in C++) against the reference's own cleaned output: the
+    same users in the same order, the same (item, rating, time) entries; then the engine's conventions on top of it (items in
+    lexicographic order, the four predicate arrays of xmap.engine.ids); and the pipeline switch XMAP_NATIVE_FEED=1."""
+    from xmap.core.baselinerClean import BaselinerClean
+    from xmap.engine import feeder, ids
+    from xmap.utils.assist import baseliner_clean_data_pipeline
+    g = gold["clean"]
+    text = "\n".join(g["lines"]) + "\n"
+    want = [(u, [(i, r, dt(t)) for (i, r, t) in prof]) for u, prof in g["cleaned"]]
+    f = feeder.Feed.from_text(text, g["params"][2], g["params"][3], g["params"][4], g["params"][0])
+    assert f.n_lines == len(g["lines"]) and f.records() == want
+    ptr, item, rating, when, attrs = f.arrays()
+    iids = f.ids(1)
+    assert iids == sorted({i for _, prof in want for (i, _, _) in prof}) and f.ids(0) == [u for u, _ in want]
+    assert [iids[k] for k in item] == [i for _, prof in want for (i, _, _) in prof]
+    for a, b in zip(attrs, ids.item_attrs(iids)):
+        assert np.array_equal(a, b)
+    # lines with leading / trailing blanks and CRs split like re.split(r"\s+"); short lines are errors like the IndexError
+    messy = text.replace("\t", "  \t ").replace("\n", " \r\n")
+    assert feeder.Feed.from_text(messy, *g["params"][2:5], g["params"][0]).records() == want
+    with pytest.raises(Exception):
+        feeder.Feed.from_text("u1 i1 5.0\n", 2012, 2013, "S:", 1)
+    # two domains merged: users of the first, then the rest; items stay sorted; predicates of the union
+    f2 = feeder.Feed.from_text(text, g["params"][2], g["params"][3], "T:", g["params"][0])
+    m = f.merge(f2)
+    assert m.n_users == f.n_users and m.n_items == 2 * f.n_items and m.nnz == 2 * f.nnz
+    mi = m.ids(1)
+    assert mi == sorted(mi)
+    for a, b in zip(m.arrays()[4], ids.item_attrs(mi)):
+        assert np.array_equal(a, b)
+    rec = m.records()
+    assert [(i, r, w) for (i, r, w) in rec[0][1][:len(want[0][1])]] == want[0][1]
+    # ... and the same feed from both texts in one call (users that reappear in the second text: the grouping by user is a
+    # stable counting sort there), also with the lines of the first text shuffled (nothing grouped by user at all)
+    m2 = feeder.Feed.from_texts([(text, g["params"][4]), (text, "T:")], g["params"][2], g["params"][3], g["params"][0])
+    assert m2.records() == rec and m2.ids(1) == mi
+    for a, b in zip(m2.arrays(), m.arrays()):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) if isinstance(a, tuple) else np.array_equal(a, b)
+    rng = np.random.default_rng(0)
+    lines = list(g["lines"])
+    perm = rng.permutation(len(lines))
+    shuffled = "\n".join(lines[k] for k in perm) + "\n"
+    tool = BaselinerClean(*g["params"])
+    sc0 = SparkContext(conf=SparkConf())
+    ref = tool.clean_data(tool.filter_data(tool.parse_data(sc0.parallelize([lines[k] for k in perm], 1)))).collect()
+    assert feeder.Feed.from_text(shuffled, *g["params"][2:5], g["params"][0]).records() == ref
+    # the pipeline switch
+    p = tmp_path / "raw.txt"
+    p.write_text(text)
+    monkeypatch.setenv("XMAP_NATIVE_FEED", "1")
+    sc = SparkContext(conf=SparkConf())
+    rdd = baseliner_clean_data_pipeline(sc, BaselinerClean(*g["params"]), "file:" + str(p), False, 30)
+    assert isinstance(rdd, feeder.FeedRDD) and rdd._items is None
+    assert rdd.collect() == want
+
+
 def test_split_protocol():
     from xmap.core.baselinerSplit import BaselinerSplit
     from xmap.utils.assist import baseliner_split_data_pipeline

@@ -71,8 +71,14 @@ def train_state(trainRDD):
         if ref is None and fp == _fingerprint(records_of(trainRDD)):
             return st
         _engines.pop(key, None)
-    recs = records_of(trainRDD)
-    st = TrainState(recs)
+    feed = getattr(trainRDD, "feed", None)
+    if feed is not None and getattr(trainRDD, "_items", None) is None:
+        from . import feeder                       # native records (xmap.engine.feeder.FeedRDD): no Python loop over them
+        recs = None
+        st = feeder.train_state_from_feed(feed)
+    else:
+        recs = records_of(trainRDD)
+        st = TrainState(recs)
     try:
         ref = weakref.ref(trainRDD, lambda _r, k=key: _engines.pop(k, None))
         fp = None

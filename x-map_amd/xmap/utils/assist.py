@@ -12,7 +12,15 @@ import yaml
 
 
 def baseliner_clean_data_pipeline(sc, clean_tool, path_rawdata, is_debug, num_partition):
-    """parse -> filter -> clean (-> debug subset).  reference utils/assist.py:9-21 (host-side ETL)"""
+    """parse -> filter -> clean (-> debug subset).  reference utils/assist.py:9-21 (host-side ETL).
+    With XMAP_NATIVE_FEED=1 the three steps run in the library's native feeder (csrc/feeder.hip, same semantics) and the
+    result is an RDD whose records exist natively: Python tuples only if somebody iterates it."""
+    import os
+    if os.environ.get("XMAP_NATIVE_FEED") == "1" and not is_debug:
+        from xmap.engine import feeder
+        period = clean_tool.period
+        feed = feeder.Feed.from_file(path_rawdata, period[0], period[-1], clean_tool.label, clean_tool.num_atleast_rating)
+        return feeder.FeedRDD(feed, sc)
     dataRDD = sc.textFile(path_rawdata, 30)
     cleanedRDD = clean_tool.clean_data(clean_tool.filter_data(clean_tool.parse_data(dataRDD))).cache()
     if is_debug:
