@@ -39,6 +39,7 @@ struct xmap_ctx {
     xmap_sim S;
     double *u_avg = nullptr, *u_norm = nullptr, *info = nullptr;
     int64_t n_kept = 0, n_eval = 0, n_contrib = 0;
+    int64_t half_contrib = 0;       // sum over the users of d (d - 1) / 2: sizes the pair buffers (known from user_ptr)
     // stage B
     bool have_ext = false;
     int top_k = 0;
@@ -199,6 +200,8 @@ int xmap_ctx_upload_ratings(xmap_ctx *c, int64_t n_users, int32_t n_items, const
     xmap_ratings &R = c->R;
     memset(&R, 0, sizeof(R));
     R.n_users = n_users; R.n_items = n_items; R.nnz = nnz;
+    c->half_contrib = 0;
+    for (int64_t u = 0; u < n_users; u++) { const int64_t d = user_ptr[u + 1] - user_ptr[u]; c->half_contrib += d * (d - 1) / 2; }
     int64_t *d_ptr, *d_time, *d_iptr;
     int32_t *d_item, *d_iuser, *d_pre, *d_suf;
     float *d_rating, *d_irating;
@@ -235,33 +238,25 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     struct Guard { Pool &p; ~Guard() { p.release(); } } guard{tmp};
 #define T_ALLOC(ptr, n) XM_TRY(dalloc(tmp, &(ptr), (size_t)(n), c->st))
 #define T_ALLOCZ(ptr, n) XM_TRY(dalloc(tmp, &(ptr), (size_t)(n), c->st, true))
-    // A2 / A3
+    // A2 / A3 + layout of the "tri" formulation: one transposition (xmap_sim3_layout); the CSC arrays stay unbuilt
     int32_t *cnt;
     T_ALLOC(cnt, I);
-    XM_TRY(xmap_build_csc(c->st, U, I, nnz, R.user_ptr, R.user_item, R.user_rating, cnt, (int64_t *)R.item_ptr, (int32_t *)R.item_user,
-                          (float *)R.item_rating));
     double *norms;
     XM_ALLOC(c->p_sim, c->u_avg, U);
     XM_ALLOC(c->p_sim, c->u_norm, U);
     XM_ALLOCZ(c->p_sim, c->info, (size_t)I * 4);
     T_ALLOCZ(norms, (size_t)2 * I);
-    XM_TRY(xmap_user_stats(c->st, &R, c->u_avg, c->u_norm));
-    XM_TRY(xmap_item_stats(c->st, &R, c->u_avg, c->info, norms, nullptr, nullptr, 0, I));
-    // layout of the "tri" formulation
     int32_t *hist, *ctl, *hid, *hlist;
     int64_t *pre;
-    uint64_t *ub_key, *ub, *rcrec, *Wp;
+    uint64_t *ub_key, *ub, *rcrec, *Wp, *srec, *buf_a, *buf_b;
+    const size_t n1 = (size_t)(nnz ? nnz : 1);
     T_ALLOC(hist, U + 2); T_ALLOC(pre, U + 3); T_ALLOC(ctl, 4); T_ALLOC(hid, I); T_ALLOCZ(hlist, 1024);
-    T_ALLOC(ub_key, nnz); T_ALLOC(ub, nnz); T_ALLOC(rcrec, (size_t)2 * (nnz ? nnz : 1)); T_ALLOC(Wp, I);
-    int32_t h_ctl[2] = {0, 0};
-    XM_TRY(xmap_sim2_layout(c->st, &R, c->info, 1024, hist, pre, ctl, hid, hlist, ub_key, ub, rcrec, Wp, 0, h_ctl));
-    const int n_heavy = h_ctl[1];
-    int64_t half_contrib = 0;
-    {
-        int64_t *scan;
-        T_ALLOC(scan, I + 1);
-        XM_TRY(xmap_exclusive_scan_i64(c->st, (const int64_t *)Wp, scan, I, &half_contrib));
-    }
+    T_ALLOC(ub_key, n1); T_ALLOC(ub, n1); T_ALLOC(rcrec, 2 * n1); T_ALLOC(Wp, I);
+    T_ALLOC(srec, 2 * n1); T_ALLOC(buf_a, 2 * n1); T_ALLOC(buf_b, 2 * n1);
+    const int ch_min = 1024;
+    XM_TRY(xmap_sim3_layout(c->st, &R, (int64_t *)R.item_ptr, nullptr, ch_min, 1 | 2 | 4, 0, I, cnt, c->u_avg, c->u_norm, hist, pre, ctl,
+                            hid, hlist, ub_key, ub, srec, buf_a, buf_b, rcrec, Wp, c->info, norms, nullptr));
+    const int64_t half_contrib = c->half_contrib;
     int32_t *Q, *Cc, *Qcat, *uq_item = nullptr, *uq_q = nullptr, *uc_item = nullptr, *uc_c = nullptr;
     uint8_t *small;
     int64_t *uq_ptr, *uc_ptr;
@@ -269,35 +264,39 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     T_ALLOCZ(uc_ptr, I + 1);
     int slot_target = 640;
     double coo_slack = 1.0;
-    int64_t hc[8];
+    int64_t hc[10];
     int64_t n_light = 0, n_hu = 0;
+    int n_heavy = 0;
     auto plan = [&](int target) -> int {
-        XM_TRY(xmap_sim2_plan(c->st, &R, target, rcrec, pre, hid, ctl, Q, Cc, small, Wp, Qcat, uq_ptr, uc_ptr, 0, hc));
-        n_light = hc[0]; n_hu = hc[1];
-        T_ALLOC(uq_item, n_light); T_ALLOC(uq_q, n_light); T_ALLOC(uc_item, n_hu); T_ALLOC(uc_c, n_hu);
-        XM_TRY(xmap_sim2_units(c->st, I, Qcat, uq_ptr, uq_item, uq_q, Cc, uc_ptr, uc_item, uc_c));
+        const int64_t cap_light = half_contrib / target + I + 1, cap_heavy = nnz / ch_min + 1025;
+        T_ALLOC(uq_item, cap_light); T_ALLOC(uq_q, cap_light); T_ALLOC(uc_item, cap_heavy); T_ALLOC(uc_c, cap_heavy);
+        XM_TRY(xmap_sim3_plan(c->st, &R, target, pre, hid, ctl, Q, Cc, small, Wp, Qcat, uq_ptr, uc_ptr, 0, uq_item, uq_q, uc_item, uc_c,
+                              cap_light, cap_heavy, hc));
+        n_light = hc[0]; n_hu = hc[1]; n_heavy = (int)hc[9];
         return XMAP_OK;
     };
     XM_TRY(plan(slot_target));
-    int32_t *coo_i = nullptr, *coo_j = nullptr, *coo_mutu = nullptr, *coo_nij = nullptr, *rowcnt = nullptr;
+    int32_t *coo_i = nullptr, *coo_j = nullptr, *coo_mutu = nullptr, *coo_nij = nullptr, *own = nullptr, *mir = nullptr;
     double *coo_sim = nullptr;
+    int64_t *d_shards = nullptr;
     int64_t cap_coo = 0, n = 0, n_unordered = 0;
     for (;;) {
         cap_coo = ((int64_t)((double)(half_contrib > 0 ? half_contrib : 1) * coo_slack) / 4096 + 1100) * 4096;
         double *hp_hi, *hp_lo;
         int32_t *hp_cnt, *hp_mut, *rowcnt_h;
-        int64_t *d_cnt, *d_shards;
+        int64_t *d_cnt;
         T_ALLOC(coo_i, cap_coo); T_ALLOC(coo_j, cap_coo); T_ALLOC(coo_sim, cap_coo); T_ALLOC(coo_mutu, cap_coo); T_ALLOC(coo_nij, cap_coo);
-        T_ALLOC(rowcnt, I);
+        T_ALLOC(own, I); T_ALLOC(mir, I);
         const size_t hp = (size_t)(n_hu ? n_hu : 1) * 1024;
         T_ALLOC(hp_hi, hp); T_ALLOC(hp_lo, hp); T_ALLOC(hp_cnt, hp); T_ALLOC(hp_mut, hp);
-        T_ALLOCZ(d_cnt, 4); T_ALLOC(d_shards, 2 * 4096); T_ALLOC(rowcnt_h, 64 * 1024);
-        // all phases in one call: the heavy rows run on a side stream next to the class launches of the light rows
+        T_ALLOCZ(d_cnt, 6); T_ALLOC(d_shards, 2 * 4096); T_ALLOC(rowcnt_h, 64 * 1024);
+        // all phases in one call: the heavy rows run on a side stream next to the class launches of the light rows; own and
+        // mirrored row counts apart (mir), kept / evaluated pairs summed on the device (phase 64)
         XM_TRY(xmap_sim2_pairs(c->st, &R, method, cap, c->u_avg, norms, rcrec, ub, Q, small, uq_item, uq_q, hc + 2, 0, n_light, hid, hlist,
-                               ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, 8 | 1 | 2 | 4 | 16, hp_hi, hp_lo, hp_cnt, hp_mut,
-                               cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, rowcnt, rowcnt_h, d_shards, d_cnt, nullptr));
-        int64_t h_cnt[4];
-        XM_TRY(d2h(h_cnt, d_cnt, 4, c->st));
+                               ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, 8 | 1 | 2 | 4 | 16 | 64, hp_hi, hp_lo, hp_cnt,
+                               hp_mut, cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, own, rowcnt_h, d_shards, d_cnt, mir));
+        int64_t h_cnt[6];
+        XM_TRY(d2h(h_cnt, d_cnt, 6, c->st));
         XM_HIP(hipStreamSynchronize(c->st));
         if (h_cnt[2]) {                 // an LDS pair table overflowed: smaller partitions
             if (slot_target <= 32) { set_error("pair-table overflow"); return XMAP_ERR_OVERFLOW; }
@@ -310,24 +309,21 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
             coo_slack *= 2;
             continue;
         }
-        std::vector<int64_t> sh(2 * 4096);
-        XM_TRY(d2h(sh.data(), d_shards, sh.size(), c->st));
-        XM_HIP(hipStreamSynchronize(c->st));
-        n = 0; n_unordered = 0;
-        for (int s = 0; s < 4096; s++) { n += sh[s]; n_unordered += sh[4096 + s]; }
+        n = h_cnt[4]; n_unordered = h_cnt[5];
         break;
     }
-    // mirror the half COO into the CSR
-    int64_t *row_ptr;
+    // mirror the half COO into the CSR (row = [own | mirrored], tile sort by the heavier item)
+    int64_t *row_ptr, *mptr;
     XM_ALLOCZ(c->p_sim, row_ptr, I + 1);
-    XM_TRY(xmap_exclusive_scan_i32_to_i64(c->st, rowcnt, row_ptr, I, nullptr));
+    T_ALLOCZ(mptr, I + 1);
     const int64_t kept = 2 * n;
-    int32_t *col, *mutu, *nij, *fill;
+    int32_t *col, *mutu, *nij, *fill, *tot;
     double *sim;
+    uint64_t *mir_a, *mir_b;
     XM_ALLOC(c->p_sim, col, kept); XM_ALLOC(c->p_sim, sim, kept); XM_ALLOC(c->p_sim, mutu, kept); XM_ALLOC(c->p_sim, nij, kept);
-    T_ALLOC(fill, I);
-    if (n) XM_TRY(xmap_sim2_scatter(c->st, I, cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, row_ptr, fill, hid, hlist, col, sim,
-                                    mutu, nij, nullptr));
+    T_ALLOC(fill, I); T_ALLOC(tot, I); T_ALLOC(mir_a, (size_t)3 * (n ? n : 1)); T_ALLOC(mir_b, (size_t)3 * (n ? n : 1));
+    XM_TRY(xmap_sim3_mirror(c->st, I, cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, d_shards, n, own, mir, tot, row_ptr, mptr, fill,
+                            mir_a, mir_b, col, sim, mutu, nij));
     XM_HIP(hipStreamSynchronize(c->st));
     c->S.n_items = I; c->S.row_ptr = row_ptr; c->S.col = col; c->S.sim = sim; c->S.mutu = mutu; c->S.nij = nij; c->S.info = c->info;
     c->S.frac = nullptr;

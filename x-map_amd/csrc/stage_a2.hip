@@ -339,7 +339,11 @@ struct TriArgs {
 // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207) for one accumulated pair
 template <int METHOD>
 __device__ __forceinline__ bool finish_pair(const TriArgs &A, int i, int j, int n, int m, double dot, double &simv) {
+#ifdef EXP_NONRM      // attribution builds (profiles/tools/a_variants.sh), never shipped
+    const double np = A.nrm[i] * A.nrm[i];
+#else
     const double np = A.nrm[i] * A.nrm[j];
+#endif
     const double cs = (np != 0.0) ? 1.0 * dot / np : 0.0;
     const int mn = n < A.cap ? n : A.cap;
     simv = 1.0 * cs * (double)mn / (double)A.cap;
@@ -389,9 +393,16 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begi
         unsigned long long km = __ballot(keep);
         if (keep) {
             long long p = (long long)base + __popcll(km & lanemask_lt());
-            A.coo_i[p] = i; A.coo_j[p] = j; A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
+            A.coo_i[p] = i; A.coo_j[p] = j;
+#ifndef EXP_NOCOO     // (indices still written: the mirror reads them)
+            A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
             if (A.coo_aux) A.coo_aux[p] = aux(s0 + lane);
+#endif
+#ifdef EXP_NOHID
+            const int hj = -1;
+#else
             const int hj = A.hid[j];
+#endif
             if (j == i) {}   // a row paired with itself (RecommenderSim) has no mirror entry
             else if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
             else atomicAdd(&(A.mircnt ? A.mircnt : A.rowcnt)[j], 1);
@@ -522,7 +533,9 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
                 } else {
                     const RaterRec rr = A.rc[p];
                     e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
+#ifndef EXP_NOUAVG
                     if (ADJ) au = A.u_avg[rr.user];
+#endif
                 }
             }
             const int nr = (p1 - base) < RB ? (p1 - base) : RB;
