@@ -157,8 +157,11 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
                    const int32_t *hid, const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small /*[I]*/,
                    uint64_t *Wp /*[I] as left by xmap_sim2_layout*/, int32_t *Qcat /*[5 I]*/, int64_t *uq_ptr /*[5 I + 1]*/,
                    int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int64_t *h_counts /*[8], host*/);
-int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const int64_t *uq_ptr, int32_t *uq_item,
-                    int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c);
+/* light unit u: uq_item[u] and the 16-byte record uq_q[4 u ..] = (hash partition, first rater, end of raters, partitions of
+ * the row): what a pair kernel needs to start, in one round trip */
+int xmap_sim2_units(void *stream, int32_t n_items, const int64_t *item_ptr, const int32_t *Qcat, const int64_t *uq_ptr,
+                    int32_t *uq_item, int32_t *uq_q /*[4 light units]*/, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item,
+                    int32_t *uc_c);
 int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, const double *u_avg, const double *norms,
                     const void *rc, const void *ub, const int32_t *Q,
                     const uint8_t *small, const int32_t *uq_item, const int32_t *uq_q, const int64_t *cls_ptr /*[6], host*/,
@@ -212,7 +215,7 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr /*[I
  * table class rank 0..4, light units, CH, |H|} (h_out + 2 is the cls_ptr of xmap_sim2_pairs). */
 int xmap_sim3_plan(void *stream, const xmap_ratings *R, int32_t slot_target, const int64_t *pre, const int32_t *hid,
                    const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp, int32_t *Qcat /*[5 I]*/,
-                   int64_t *uq_ptr /*[5 I + 1]*/, int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int32_t *uq_item, int32_t *uq_q,
+                   int64_t *uq_ptr /*[5 I + 1]*/, int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int32_t *uq_item, int32_t *uq_q /*[4 cap_light]*/,
                    int32_t *uc_item, int32_t *uc_c, int64_t cap_light, int64_t cap_heavy, int64_t *h_out /*[10], host*/);
 /* The mirror of round 3.  xmap_sim2_pairs was given mircnt: own[i] = pairs row i computed (rowcnt), mir[j] = pairs computed
  * in lighter rows.  Row i of the CSR = [own | mirrored]: row_ptr = exclusive scan of own + mir; the own halves are written

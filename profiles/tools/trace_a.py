@@ -4,7 +4,7 @@
          _build/stage_b.o _build/stage_c.o _build/stage_d.o _build/stage_e.o
 then on the GPU box, from the repo root: python profiles/tools/trace_a.py"""
 import sys, os, ctypes as C, numpy as np, torch
-os.environ["XMAP_HIP_LIB"] = "scratch/libxmap_ATRACE.so"
+os.environ["XMAP_HIP_LIB"] = "x-map_amd/_variants/libxmap_ATRACE.so"   # profiles/tools/a_variants.sh build ATRACE... (-DA_TRACE)
 sys.path.insert(0, '.'); sys.path.insert(0, 'x-map_amd')
 from xmap.engine import synth, device as dev
 from xmap.engine.hipabi import lib
@@ -50,3 +50,9 @@ for c in range(5):
     if hi <= lo: continue
     x = st[lo:hi].astype(np.float64) / 100.0
     print("class %d stamps us (median): unit read %.1f, first rater step %.1f, walk done %.1f, end %.1f" % (c, np.median(x[:, 0]), np.median(x[:, 1]), np.median(x[:, 2]), np.median(dur[lo:hi])))
+    rr = ni[item[lo:hi]].astype(np.float64)
+    walk = x[:, 2] - x[:, 1]
+    A = np.stack([rr, np.ones_like(rr)], 1)
+    coef = np.linalg.lstsq(A, walk, rcond=None)[0]
+    print("    walk us ~ %.3f per rater of the row + %.1f; finalise + append (end - walk done) median %.1f us; mean stamps %s, mean dur %.1f" % (
+        coef[0], coef[1], np.median(dur[lo:hi] - x[:, 2]), x[:, :3].mean(0).round(1), dur[lo:hi].mean()))

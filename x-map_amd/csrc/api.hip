@@ -269,7 +269,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     int n_heavy = 0;
     auto plan = [&](int target) -> int {
         const int64_t cap_light = half_contrib / target + I + 1, cap_heavy = nnz / ch_min + 1025;
-        T_ALLOC(uq_item, cap_light); T_ALLOC(uq_q, cap_light); T_ALLOC(uc_item, cap_heavy); T_ALLOC(uc_c, cap_heavy);
+        T_ALLOC(uq_item, cap_light); T_ALLOC(uq_q, 4 * cap_light); T_ALLOC(uc_item, cap_heavy); T_ALLOC(uc_c, cap_heavy);
         XM_TRY(xmap_sim3_plan(c->st, &R, target, pre, hid, ctl, Q, Cc, small, Wp, Qcat, uq_ptr, uc_ptr, 0, uq_item, uq_q, uc_item, uc_c,
                               cap_light, cap_heavy, hc));
         n_light = hc[0]; n_hu = hc[1]; n_heavy = (int)hc[9];

@@ -293,14 +293,23 @@ __global__ __launch_bounds__(256) void k_plan2(int I, const long long *iptr, con
     plan_item(i, (long long)Wp[i], I, iptr, pre, HB, hid, CH, target, dups, Q, C, small, Wp, Qcat);
 }
 
-__global__ __launch_bounds__(256) void k_fill_units2(int I, const int *Qcat, const long long *uq_ptr, int *uq_item, int *uq_q,
-                                                     const int *C, const long long *uc_ptr, int *uc_item, int *uc_c,
-                                                     long long cap_light, long long cap_heavy) {
+// light unit u: uq_item[u] and the record uq_q[4 u ..] = (partition, first rater, end of raters, partitions of the row) --
+// what k_pair_tri needs to start, in one round trip
+__global__ __launch_bounds__(256) void k_fill_units2(int I, const long long *iptr, const int *Qcat, const long long *uq_ptr,
+                                                     int *uq_item, int *uq_q, const int *C, const long long *uc_ptr, int *uc_item,
+                                                     int *uc_c, long long cap_light, long long cap_heavy) {
     const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (long long)N_CLASSES * I) return;
     const int i = (int)(x % I);
     long long b = uq_ptr[x];
-    for (int k = 0; k < Qcat[x] && b + k < cap_light; k++) { uq_item[b + k] = i; uq_q[b + k] = k; }
+    const int nq = Qcat[x];
+    if (nq > 0) {
+        const int p0 = (int)iptr[i], p1 = (int)iptr[i + 1];
+        for (int k = 0; k < nq && b + k < cap_light; k++) {
+            uq_item[b + k] = i;
+            ((int4 *)uq_q)[b + k] = make_int4(k, p0, p1, nq);
+        }
+    }
     if (x >= I) return;
     b = uc_ptr[i];
     for (int k = 0; k < C[i] && b + k < cap_heavy; k++) { uc_item[b + k] = i; uc_c[b + k] = k; }
@@ -429,14 +438,11 @@ __global__ __launch_bounds__(256) void k_fold_heavy(int n_heavy, const int *hlis
     if (t) atomicAdd(&rowcnt[hlist[h]], t);
 }
 
-// Light rows.  Eight raters are processed per wave and step (8 lanes each): profile prefixes are short (half a
-// profile on average), so one rater per step would leave most lanes idle and only one dependent load in
-// flight.  Lanes of different raters may meet on one partner: the counters use LDS atomics, the fp64 sum is
-// either an LDS atomic add (cosine: integer-exact, order irrelevant) or, for the double-double sum of
-// adjusted cosine, serialised per slot (conflicts are rare): through a claim word inside one wave, through a lock
-// word when several waves share the table.
-constexpr int GRP = 8;                  // lanes per rater
-constexpr int NGRP = 64 / GRP;          // raters per wave and step
+// Light rows.  The co-ratings of a block of raters are walked as one flat list, one per lane (k_pair_tri: walk).  Lanes
+// of different raters may meet on one partner: the counters use LDS atomics, the fp64 sum is either an LDS atomic add
+// (cosine: integer-exact, order irrelevant) or, for the double-double sum of adjusted cosine, serialised per slot
+// (conflicts are rare): through a claim word inside one wave, through a lock bit in the slot's key when several waves
+// share the table.
 
 // The table size is a template parameter: rows whose partner bound is <= SMALL_BOUND (the vast majority: items
 // with a handful of raters) run with 128 slots (3.5 KB of LDS, full occupancy, 8x cheaper init/finalise), rows up
@@ -472,16 +478,23 @@ struct ATraceEnd { long long u; long long t0;
 #define A_STAMP(k) do {} while (0)
 #endif
 template <int METHOD, int LOG_SLOTS, int NW, bool LS>
-__global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
+__global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pair_tri(TriArgs A) {   // (128 slots: 8 waves per SIMD fit, keep the SGPRs below the limit for that)
     constexpr int SLOTS_ = 1 << LOG_SLOTS;
     constexpr bool ADJ = METHOD == XMAP_ADJUST_COSINE;
     using RT = typename std::conditional<LS, double, float>::type;      // rating type of the profile copy and the rater records
+    // one slot = key 4 B (item; bit 31 = the slot's lock while several waves share the table) + counters + sum: 24 B (adjusted
+    // cosine: (value, error) sum) for the rows below WIDE_MIN raters -- n_ij and the mutuality count in 16 bits each -- so six
+    // 1024-slot tables fit one CU (round 2: 32 KB + 8 B each with 64-bit counters and a lock word: four)
+    // (profiles hold an item once there: n_ij <= n_i < WIDE_MIN; the AlterEgo rows of LS may repeat items: 32-bit halves)
+    using CM = typename std::conditional<NW == 16 || LS, unsigned long long, unsigned>::type;
+    constexpr int MSH = (NW == 16 || LS) ? 32 : 16;
+    constexpr CM NMASK = (CM)(((CM)1 << MSH) - 1);
+    constexpr uint32_t LOCKBIT = 0x80000000u;
     __shared__ uint32_t key[SLOTS_];
-    __shared__ unsigned long long cm[SLOTS_];     // n_ij (low 32) | mutuality (high 32)
+    __shared__ CM cm[SLOTS_];                     // n_ij (low half) | mutuality (high half)
     __shared__ double dot[SLOTS_];
     __shared__ double dlo[ADJ ? SLOTS_ : 1];
-    __shared__ unsigned short claim[ADJ && NW == 1 ? SLOTS_ : 1];   // (lane ids; NW > 1 uses lockw)
-    __shared__ unsigned lockw[ADJ && NW > 1 ? SLOTS_ : 1];
+    __shared__ unsigned short claim[ADJ && NW == 1 ? SLOTS_ : 1];   // (lane ids; NW > 1 locks the key word)
     __shared__ double s_ny[LS ? SLOTS_ : 1];              // LS: norm of the partner
     __shared__ unsigned long long s_ls[LS ? SLOTS_ : 1];  // LS: running maximum (ls_key)
     __shared__ int s_ovf;
@@ -493,92 +506,99 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
 #ifdef A_TRACE
     ATraceEnd tr_{unit, (long long)wall_clock64()};
 #endif
+    // the unit's record in one round trip: item; (partition, first rater, end of raters, partitions of the row)
     const int i = uniform(A.uq_item[unit]);
-    const int tcls = A.small[i];   // 1: 128 slots, 3: 256, 2: 512, 0: 1024, 4: 1024 shared by 16 waves
-    if (tcls != (LOG_SLOTS == 7 ? 1 : (LOG_SLOTS == 8 ? 3 : (LOG_SLOTS == 9 ? 2 : (NW == 16 ? 4 : 0))))) return;   // not reached: class-major units
+    const int4 ud = ((const int4 *)A.uq_q)[unit];
+    const int q = uniform(ud.x), p0 = uniform(ud.y), p1 = uniform(ud.z), Qi = uniform(ud.w);
     const int w = threadIdx.x >> 6;
     for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
-        key[s] = T_EMPTY; cm[s] = 0ull; dot[s] = 0.0;
+        key[s] = T_EMPTY; cm[s] = (CM)0; dot[s] = 0.0;
         if (ADJ) dlo[s] = 0.0;
-        if (ADJ && NW > 1) lockw[s] = 0u;
     }
     if (NW > 1) {
         if (threadIdx.x == 0) s_ovf = 0;
         __syncthreads();
     }
-    const int q = uniform(A.uq_q[unit]);
-    const int Qi = uniform(A.Q[i]);
-    const int p0 = uniform((int)A.iptr[i]);
-    const int p1 = uniform((int)A.iptr[i + 1]);
-    const int g = lane / GRP, sub = lane % GRP;
+    const double nx = A.nrm[i];     // (for the finalisation: in flight during the walk)
     int ovf = 0;
     A_STAMP(0);
 
     // walk(body): every co-rating of this unit's raters (those of hash partition q); body(act, j, jw, rj, ri, a, gei)
-    // runs once per lane and inner step.  Wave w takes every NW-th block of RB raters.  RB = 64 (one rater record per lane)
-    // when the wave is alone or the row is very long; the rows of the shared 1024 / 512-slot tables have 158 / 33 raters
-    // on average: blocks of 64 gave wave 0 eight steps of 8 raters and left waves 2-3 with half a block or nothing, blocks
-    // of 16 deal the raters out evenly (a unit lives as long as its busiest wave, and holds its table that long).
+    // runs once per lane and 64 co-ratings.  Wave w takes every NW-th block of RB raters, one rater record per lane
+    // (RB = 64 when the wave is alone or the row is very long; the rows of the shared 1024 / 512-slot tables have 158 / 33
+    // raters on average: blocks of 16 deal them out evenly -- a unit lives as long as its busiest wave, and holds its table
+    // that long).  The prefixes of a block are walked as ONE flat list (round 2 gave each rater 8 lanes: half of the
+    // lanes idle, one dependent load per 8 entries of the longest of eight prefixes, 10-18 us per unit of which the
+    // table work was a fraction -- profiles/tools/trace_a.py): an inclusive scan of the prefix lengths over the lanes, then
+    // lane l of round t takes co-rating 64 t + l, finds its rater by binary search over the scan (log2 RB permutes) and loads
+    // its entry; all loads of WU rounds are in flight together and every lane of every round but the last is busy.
     constexpr int RB = (NW == 1 || NW == 16) ? 64 : 16;
+    constexpr int WU = 2;
+    auto rater = [&](int p, int &e0, int &pw, RT &r, int &usr) {
+        e0 = 0; pw = 0; r = (RT)0; usr = -1;
+        if (lane < RB && p < p1) {
+            if (LS) {       // fp64 ratings, user average 0 by construction
+                const RaterRecWide rr = ((const RaterRecWide *)A.rc)[p];
+                e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
+            } else {
+                const RaterRec rr = A.rc[p];
+                e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating; usr = rr.user;
+            }
+        }
+    };
+    auto entry = [&](int e, int &jw_, RT &rj_) {        // one entry of a sorted profile
+        if (LS) { const UbWide v = ((const UbWide *)A.ub)[e]; jw_ = v.item_ge; rj_ = (RT)v.rating; }
+        else { const int2 v = A.ub[e]; jw_ = v.x; rj_ = (RT)__int_as_float(v.y); }
+    };
     auto walk = [&](auto &&body) {
-        for (int base = p0 + RB * w; base < p1; base += RB * NW) {
-            const int p = base + lane;
-            int e0 = 0, pw = 0;
-            RT r = (RT)0;
+        int base = p0 + RB * w;
+        if (base >= p1) return;
+        int e0, pw, usr, ne0 = 0, npw = 0, nusr = -1;
+        RT r, nr_ = (RT)0;
+        rater(base + lane, e0, pw, r, usr);
+        for (; base < p1; base += RB * NW) {
+            const bool more = base + RB * NW < p1;            // this wave's next block: its records are loaded now
+            if (more) rater(base + RB * NW + lane, ne0, npw, nr_, nusr);
             double au = 0.0;
-            if (lane < RB && p < p1) {
-                if (LS) {       // fp64 ratings, user average 0 by construction
-                    const RaterRecWide rr = ((const RaterRecWide *)A.rc)[p];
-                    e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
-                } else {
-                    const RaterRec rr = A.rc[p];
-                    e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
 #ifndef EXP_NOUAVG
-                    if (ADJ) au = A.u_avg[rr.user];
+            if (ADJ && !LS && usr >= 0) au = A.u_avg[usr];
 #endif
-                }
-            }
-            const int nr = (p1 - base) < RB ? (p1 - base) : RB;
+            const int len = pw & 0x7fffffff;                  // the rater's prefix: entries [e0, e0 + len) of its profile
+            int end = len;
+#pragma unroll
+            for (int d = 1; d < RB; d <<= 1) { const int v = __shfl_up(end, d, 64); if (lane >= d) end += v; }
+            const int total = rl32(end, RB - 1);
+            const int start = end - len;
 #ifdef A_TRACE
-            if (base == p0 + RB * w && __shfl(e0, 0, 64) >= 0) A_STAMP(1);
+            if (base == p0 + RB * w) A_STAMP(1);
 #endif
-            // software pipeline: the first 2 GRP entries of the NEXT step's prefixes are loaded before this step is
-            // processed (a step waits for the longest of its 8 prefixes; every load inside the loop below is one more
-            // dependent round trip while the unit holds its table: 16 entries cover nearly all prefixes)
-            int nb0 = 0, nb1 = 0, npw = 0, njw = 0, njw2 = 0;
-            RT nrj = (RT)0, nrj2 = (RT)0;
-            auto entry = [&](int e, int &jw_, RT &rj_) {        // one entry of a sorted profile
-                if (LS) { const UbWide v = ((const UbWide *)A.ub)[e]; jw_ = v.item_ge; rj_ = (RT)v.rating; }
-                else { const int2 v = A.ub[e]; jw_ = v.x; rj_ = (RT)__int_as_float(v.y); }
-            };
-            auto prefetch = [&](int t) {
-                nb0 = __shfl(e0, t, 64); npw = __shfl(pw, t, 64);
-                nb1 = (t < nr) ? nb0 + (npw & 0x7fffffff) : nb0;
-                if (nb0 + sub < nb1) entry(nb0 + sub, njw, nrj);
-                if (nb0 + GRP + sub < nb1) entry(nb0 + GRP + sub, njw2, nrj2);
-            };
-            prefetch(g);
-            for (int t0 = 0; t0 < nr; t0 += NGRP) {
-                const int t = t0 + g;                    // this lane group's rater
-                const int b0 = nb0, b1 = nb1, pwt = npw;
-                int jw = njw;
-                RT rj = nrj;
-                const int jw2 = njw2;
-                const RT rj2 = nrj2;
-                if (t0 + NGRP < nr) prefetch(t + NGRP);
-                const double ri = (double)__shfl(r, t, 64);
-                const double a = ADJ ? __shfl(au, t, 64) : 0.0;
-                const unsigned gei = ((unsigned)pwt) >> 31;
-                int it = 0;
-                for (int e = b0 + sub; __ballot(e < b1); e += GRP, it++) {
-                    bool act = e < b1;
-                    if (it == 1) { jw = jw2; rj = rj2; }
-                    else if (act && it >= 2) entry(e, jw, rj);
-                    const int j = jw & 0x7fffffff;
-                    if (act && Qi > 1) act = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
-                    body(act, j, jw, rj, ri, a, gei);
+            for (int f0 = 0; f0 < total; f0 += 64 * WU) {
+                int jw[WU]; RT rj[WU]; bool act[WU]; double ri[WU], a[WU]; unsigned gei[WU];
+#pragma unroll
+                for (int u = 0; u < WU; u++) {
+                    jw[u] = 0; rj[u] = (RT)0; act[u] = false; ri[u] = 0.0; a[u] = 0.0; gei[u] = 0u;
+                    if (u && f0 + u * 64 >= total) continue;  // (uniform)
+                    const int f = f0 + u * 64 + lane;
+                    act[u] = f < total;
+                    int t = 0;                                // the rater of co-rating f: #{k : end[k] <= f}
+#pragma unroll
+                    for (int step = RB / 2; step >= 1; step >>= 1) { const int v = __shfl(end, t + step - 1, 64); if (v <= f) t += step; }
+                    const int eb = __shfl(e0, t, 64), sb = __shfl(start, t, 64), pwt = __shfl(pw, t, 64);
+                    if (act[u]) entry(eb + (f - sb), jw[u], rj[u]);
+                    ri[u] = (double)__shfl(r, t, 64);
+                    if (ADJ) a[u] = __shfl(au, t, 64);
+                    gei[u] = ((unsigned)pwt) >> 31;
+                }
+#pragma unroll
+                for (int u = 0; u < WU; u++) {
+                    if (u && f0 + u * 64 >= total) continue;
+                    const int j = jw[u] & 0x7fffffff;
+                    bool ac = act[u];
+                    if (ac && Qi > 1) ac = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
+                    body(ac, j, jw[u], rj[u], ri[u], a[u], gei[u]);
                 }
             }
+            e0 = ne0; pw = npw; r = nr_; usr = nusr;
         }
     };
 
@@ -590,13 +610,13 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             int probes = 0;
             for (;;) {
                 uint32_t prev = atomicCAS(&key[h], T_EMPTY, (uint32_t)j);
-                if (prev == T_EMPTY || prev == (uint32_t)j) break;
+                if (prev == T_EMPTY || (prev & ~LOCKBIT) == (uint32_t)j) break;
                 h = (h + 1) & (SLOTS_ - 1);
                 if (++probes >= SLOTS_) { act = false; ovf = 1; break; }
             }
         }
         if (act) {
-            const unsigned long long inc = 1ull | (((((unsigned)jw) >> 31) == gei) ? (1ull << 32) : 0ull);
+            const CM inc = (CM)1 | (((((unsigned)jw) >> 31) == gei) ? ((CM)1 << MSH) : (CM)0);
             atomicAdd(&cm[h], inc);
             if (METHOD == XMAP_COSINE) atomicAdd(&dot[h], (1.0 * ri) * (double)rj);   // integer-exact
         }
@@ -618,13 +638,13 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
                     }
                 }
             } else {
-                while (__ballot(pending)) {       // a lock per slot: the holder releases in the same pass
-                    if (pending && atomicCAS(&lockw[h], 0u, 1u) == 0u) {
+                while (__ballot(pending)) {       // a lock per slot (bit 31 of its key): the holder releases in the same pass
+                    if (pending && !(atomicOr(&key[h], LOCKBIT) & LOCKBIT)) {
                         double hi = vhi[h], lo = vlo[h];
                         dd_add(hi, lo, term);
                         vhi[h] = hi; vlo[h] = lo;
                         __threadfence_block();
-                        atomicExch(&lockw[h], 0u);
+                        atomicAnd(&key[h], ~LOCKBIT);
                         pending = false;
                     }
                 }
@@ -634,7 +654,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
     A_STAMP(2);
     if (NW > 1) {
         if (ovf) s_ovf = 1;
-        __syncthreads();          // all raters are in the table
+        __syncthreads();          // all raters are in the table (and every lock bit is clear again)
         ovf = s_ovf;
     }
     if (__ballot(ovf)) {
@@ -648,12 +668,12 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
         for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
             const uint32_t kj = key[s];
             if (kj == T_EMPTY) continue;
-            int n = (int)(cm[s] & 0xffffffffull);
+            int n = (int)(cm[s] & NMASK);
             double inner = dot[s];
             if ((int)kj == i) { n *= 2; inner *= 2.0; }
             const double ny = A.nrm[kj];
             const double np = nx * ny;
-            cm[s] = (unsigned long long)(unsigned)n;
+            cm[s] = (CM)(unsigned)n;
             dot[s] = inner;
             dlo[s] = weighted((np != 0.0) ? 1.0 * inner / np : 0.0, n, A.cap);   // NaN != 0: divides, like the reference
             s_ny[s] = ny;
@@ -695,27 +715,81 @@ __global__ __launch_bounds__(64 * NW) void k_pair_tri(TriArgs A) {
             [&](int s) { return __longlong_as_double((long long)s_ls[s]); });
         return;
     }
-    append_pairs(A, i, w * (SLOTS_ / NW), (w + 1) * (SLOTS_ / NW),
-        [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
-            uint32_t kj = key[s];
-            o = kj != T_EMPTY;
-            if (!o) return false;
-            unsigned long long c = cm[s];
-            j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32);
-            if (A.raw) { sv = dot[s]; return true; }
-            return finish_pair<METHOD>(A, i, j, n, m, dot[s], sv);
-        },
-        [&](int s, bool o, bool keep, double sv) {      // park: weighted sim in dot[], dropped slots emptied
-            if (o) { if (keep) dot[s] = sv; else key[s] = T_EMPTY; }
-        },
-        [&](int s, int &j, int &n, int &m, double &sv) {
-            uint32_t kj = key[s];
-            if (kj == T_EMPTY) return false;
-            unsigned long long c = cm[s];
-            j = (int)kj; n = (int)(c & 0xffffffffull); m = (int)(c >> 32); sv = dot[s];
-            return true;
-        },
-        [&](int s) { return (ADJ && A.raw) ? dlo[s] : 0.0; });
+    // finalisation: this wave's share of the slots stays in registers (NIT rounds of 64); the norm and the heavy id of
+    // every partner are gathered in one go (round 2: norm gather -> cursor atomic -> heavy-id gather, three dependent round
+    // trips and the slots read twice from LDS), then one returning atomic on the shard cursor, then the stores
+    constexpr int NIT = SLOTS_ / NW / 64;
+    const int sb0 = w * (SLOTS_ / NW);
+    int fj[NIT], fn[NIT], fm[NIT], fh[NIT];
+    double fs[NIT], fy[NIT], fa[NIT];
+    bool fo[NIT], fk[NIT];
+#pragma unroll
+    for (int t = 0; t < NIT; t++) {
+        const int sl = sb0 + t * 64 + lane;
+        const uint32_t kj = key[sl];
+        fo[t] = kj != T_EMPTY;
+        fj[t] = (int)kj;
+        const CM c = cm[sl];
+        fn[t] = (int)(c & NMASK); fm[t] = (int)(c >> MSH);
+        fs[t] = dot[sl];
+        fa[t] = (ADJ && A.raw) ? dlo[sl] : 0.0;
+        fy[t] = 0.0; fh[t] = -1;
+        if (fo[t]) {
+#ifdef EXP_NONRM
+            fy[t] = nx;
+#else
+            if (!A.raw) fy[t] = A.nrm[kj];
+#endif
+#ifndef EXP_NOHID
+            fh[t] = A.hid[kj];
+#endif
+        }
+    }
+    int kept = 0, occ = 0;
+#pragma unroll
+    for (int t = 0; t < NIT; t++) {
+        bool keep = fo[t];
+        if (keep && !A.raw) {          // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207): finish_pair
+            const double np = nx * fy[t];
+            const double cs = (np != 0.0) ? 1.0 * fs[t] / np : 0.0;
+            const int mn = fn[t] < A.cap ? fn[t] : A.cap;
+            fs[t] = 1.0 * cs * (double)mn / (double)A.cap;
+            keep = (fs[t] != 0.0) && (fm[t] != 0);
+        }
+        fk[t] = keep;
+        kept += __popcll(__ballot(keep));
+        occ += __popcll(__ballot(fo[t]));
+    }
+    const int shard = (blockIdx.x * NW + w) & (COO_SHARDS - 1);
+    if (lane == 0 && occ) atomicAdd(&A.shard_occ[shard], (unsigned long long)occ);
+    if (!kept) return;
+    unsigned long long cbase = 0;
+    if (lane == 0) {
+        cbase = atomicAdd(&A.shard_cur[shard], (unsigned long long)kept);
+        atomicAdd(&A.rowcnt[i], kept);
+    }
+    cbase = ((unsigned long long)(unsigned)rl32((int)(cbase >> 32), 0) << 32) | (unsigned)rl32((int)(cbase & 0xffffffffull), 0);
+    if ((long long)(cbase + kept) > A.shard_cap) {
+        if (lane == 0) atomicOr(&A.counters[3], 1ull);
+        return;
+    }
+    cbase += (unsigned long long)shard * (unsigned long long)A.shard_cap;
+#pragma unroll
+    for (int t = 0; t < NIT; t++) {
+        const unsigned long long km = __ballot(fk[t]);
+        if (fk[t]) {
+            const long long pp = (long long)cbase + __popcll(km & lanemask_lt());
+            const int j = fj[t];
+            A.coo_i[pp] = i; A.coo_j[pp] = j;
+#ifndef EXP_NOCOO
+            A.coo_sim[pp] = fs[t]; A.coo_mutu[pp] = fm[t]; A.coo_nij[pp] = fn[t];
+            if (A.coo_aux) A.coo_aux[pp] = fa[t];
+#endif
+            if (fh[t] >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + fh[t]], 1);
+            else atomicAdd(&(A.mircnt ? A.mircnt : A.rowcnt)[j], 1);
+        }
+        cbase += __popcll(km);
+    }
 }
 
 // rows of H: chunk c of the raters, dense table over H (partners of a heavy row are heavier, hence in H)
@@ -1751,12 +1825,12 @@ int xmap_sim2_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
     return XMAP_OK;
 }
 
-int xmap_sim2_units(void *stream, int32_t n_items, const int32_t *Qcat, const int64_t *uq_ptr, int32_t *uq_item,
-                    int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c) {
-    XM_ARG(Qcat && uq_ptr && uq_item && uq_q && C && uc_ptr && uc_item && uc_c);
+int xmap_sim2_units(void *stream, int32_t n_items, const int64_t *item_ptr, const int32_t *Qcat, const int64_t *uq_ptr,
+                    int32_t *uq_item, int32_t *uq_q, const int32_t *C, const int64_t *uc_ptr, int32_t *uc_item, int32_t *uc_c) {
+    XM_ARG(item_ptr && Qcat && uq_ptr && uq_item && uq_q && C && uc_ptr && uc_item && uc_c);
     if (n_items == 0) return XMAP_OK;
     k_fill_units2<<<dim3((unsigned)(((long long)N_CLASSES * n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        n_items, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c, 0x7fffffffffffffffLL,
+        n_items, (const long long *)item_ptr, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c, 0x7fffffffffffffffLL,
         0x7fffffffffffffffLL);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
@@ -1790,7 +1864,8 @@ int xmap_sim3_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
     if (rcode) return rcode;
     if (I > 0) {
         k_fill_units2<<<dim3((unsigned)(((long long)N_CLASSES * I + 255) / 256)), dim3(256), 0, st>>>(
-            I, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c, cap_light, cap_heavy);
+            I, (const long long *)R->item_ptr, Qcat, (const long long *)uq_ptr, uq_item, uq_q, C, (const long long *)uc_ptr, uc_item, uc_c,
+            cap_light, cap_heavy);
         XM_LAUNCH_CHECK();
         // class boundaries uq_ptr[c I], c = 0..5 (the last one is the total), the heavy units' total, {CH, |H|}
         XM_HIP(hipMemcpy2DAsync(&h_out[2], sizeof(int64_t), uq_ptr, sizeof(int64_t) * (size_t)I, sizeof(int64_t), N_CLASSES + 1,

@@ -390,10 +390,10 @@ class Engine(object):
             L.n_light, L.n_heavy_units = int(h[0]), int(h[1])
             L.cls_ptr = (C.c_int64 * 6)(*[int(h[2 + c]) for c in range(6)])
             L.uq_item = self._empty(max(L.n_light, 1), torch.int32)
-            L.uq_q = self._empty(max(L.n_light, 1), torch.int32)
+            L.uq_q = self._empty(4 * max(L.n_light, 1), torch.int32)
             L.uc_item = self._empty(max(L.n_heavy_units, 1), torch.int32)
             L.uc_c = self._empty(max(L.n_heavy_units, 1), torch.int32)
-            check(lib.xmap_sim2_units(st, i32(I), vp(L.Qcat), vp(L.uq_ptr), vp(L.uq_item), vp(L.uq_q),
+            check(lib.xmap_sim2_units(st, i32(I), vp(R.item_ptr), vp(L.Qcat), vp(L.uq_ptr), vp(L.uq_item), vp(L.uq_q),
                                       vp(L.C), vp(L.uc_ptr), vp(L.uc_item), vp(L.uc_c)))
         L.slot_target = slot_target
 
@@ -412,7 +412,7 @@ class Engine(object):
         cap_light = L.half_contrib // max(int(slot_target), 1) + I + 1
         cap_heavy = R.nnz // max(int(L.ch_min), 1) + 1025
         L.uq_item = self._empty(cap_light, torch.int32)
-        L.uq_q = self._empty(cap_light, torch.int32)
+        L.uq_q = self._empty(4 * cap_light, torch.int32)
         L.uc_item = self._empty(cap_heavy, torch.int32)
         L.uc_c = self._empty(cap_heavy, torch.int32)
         h = (C.c_int64 * 10)()
