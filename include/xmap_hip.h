@@ -292,7 +292,8 @@ int xmap_bridge_flags(void *stream, const xmap_sim *S, const int32_t *prefix_cls
 
 /* ExtendSim.find_knn_items (core/extender.py:16-44) + extract_siminfo (utils/assist.py:105-133):
  * per item the two top-k lists by (|sim| desc, col asc): list 0 = BB_BB | NB_BB, list 1 = BB_NB | NB_NN.
- * cls[i] = 0 none, 1 bridge record, 2 non-bridge record. kval = (sim, mutu, frac_mutu) fp64. */
+ * cls[i] = 0 none, 1 bridge record, 2 non-bridge record. kval = (sim, mutu, frac_mutu) fp64.  Every entry of the rows
+ * [row_lo, row_hi) is written (the unused tail of a list with zeros): the tables may come uninitialised. */
 int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, uint8_t *cls, int32_t *kcnt /*[I][2]*/,
                       int32_t *kcol /*[I][2][k]*/, double *kval /*[I][2][k][3]*/,

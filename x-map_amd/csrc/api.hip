@@ -371,8 +371,8 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
     uint8_t *bb, *cls;
     int32_t *kcnt, *kcol;
     double *kval;
-    XM_ALLOCZ(c->p_ext, bb, I); XM_ALLOCZ(c->p_ext, cls, I); XM_ALLOCZ(c->p_ext, kcnt, (size_t)I * 2);
-    XM_ALLOCZ(c->p_ext, kcol, (size_t)I * 2 * k); XM_ALLOCZ(c->p_ext, kval, (size_t)I * 2 * k * 3);
+    XM_ALLOCZ(c->p_ext, bb, I); XM_ALLOC(c->p_ext, cls, I); XM_ALLOC(c->p_ext, kcnt, (size_t)I * 2);       // (xmap_knn_classify writes
+    XM_ALLOC(c->p_ext, kcol, (size_t)I * 2 * k); XM_ALLOC(c->p_ext, kval, (size_t)I * 2 * k * 3);          //  every entry of its rows)
     XM_TRY(xmap_bridge_flags(c->st, &c->S, c->R.prefix_cls, bb));
     XM_TRY(xmap_knn_classify(c->st, &c->S, k, bb, c->R.suffix_cls, c->R.contains_mask, cls, kcnt, kcol, kval, 0, I));
     T.cls = cls; T.kcnt = kcnt; T.kcol = kcol; T.kval = kval;

@@ -94,12 +94,23 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
     const long long lo = A.row_ptr[i];
     const int n = (int)(A.row_ptr[i + 1] - lo);
     const int k = A.k;
+    // the unused tail of a list is zero (the tables come uninitialised: a fill of the ~1 GB they take at k = 50 cost
+    // more than the lists of the few short rows)
+    auto zero_tail = [&](int nA, int nB) {
+        for (int e = tid; e < 2 * k; e += K_THREADS) {
+            const int l = e >= k, r = e - l * k;
+            if (r < (l ? nB : nA)) continue;
+            const size_t o = ((size_t)i * 2 + l) * k + r;
+            A.kcol[o] = 0; A.kval[o * 3] = 0.0; A.kval[o * 3 + 1] = 0.0; A.kval[o * 3 + 2] = 0.0;
+        }
+    };
     if (n == 0) {
         if (tid == 0) {
             A.cls[i] = 0;
             A.kcnt[(size_t)i * 2] = 0;
             A.kcnt[(size_t)i * 2 + 1] = 0;
         }
+        zero_tail(0, 0);
         return;
     }
     const bool isbb = A.bb[i] != 0;
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
                 A.kcnt[(size_t)i * 2] = c ? nA : 0;
                 A.kcnt[(size_t)i * 2 + 1] = c ? nB : 0;
             }
+            zero_tail(totA < k ? totA : k, totB < k ? totB : k);
             return;
         }
         // carry the selected <= 2k entries to the front (sorted order kept), then take the next chunk

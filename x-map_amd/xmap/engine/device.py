@@ -721,10 +721,11 @@ class Engine(object):
         else:
             E.bb = self._zeros(max(I, 1), torch.uint8)
             check(lib.xmap_bridge_flags(st, C.byref(S.c), vp(R.prefix_cls), vp(E.bb)))
-        E.cls = self._zeros(max(I, 1), torch.uint8)
-        E.kcnt = self._zeros((max(I, 1), 2), torch.int32)
-        E.kcol = self._zeros((max(I, 1), 2, k), torch.int32)
-        E.kval = self._zeros((max(I, 1), 2, k, 3), torch.float64)
+        alloc = self._empty if I > 0 else self._zeros      # xmap_knn_classify writes every entry of the rows it is given
+        E.cls = alloc(max(I, 1), torch.uint8)                # (item-sharded ranks all-gather the other rows: ext_gather)
+        E.kcnt = alloc((max(I, 1), 2), torch.int32)
+        E.kcol = alloc((max(I, 1), 2, k), torch.int32)
+        E.kval = alloc((max(I, 1), 2, k, 3), torch.float64)
         with self.timed("knn_classify"):
             lo, hi = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
             check(lib.xmap_knn_classify(st, C.byref(S.c), k, vp(E.bb), vp(R.suffix_cls), vp(R.contains_mask),
