@@ -220,15 +220,17 @@ int xmap_sim3_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
 /* The mirror of round 3.  xmap_sim2_pairs was given mircnt: own[i] = pairs row i computed (rowcnt), mir[j] = pairs computed
  * in lighter rows.  Row i of the CSR = [own | mirrored]: row_ptr = exclusive scan of own + mir; the own halves are written
  * in runs straight from the COO, the mirrored halves go through the tile sort keyed by the heavier item (positions mptr =
- * exclusive scan of mir).  n_pairs = valid COO entries (no entry may pair a row with itself). */
+ * exclusive scan of mir).  n_pairs = valid COO entries.  coo_aux / aux (both or neither; RecommenderSim): a sixth column --
+ * the pair's local sensitivity -- travels along (32-byte records), and a row may pair with itself: such an entry is an own
+ * entry only (xmap_sim2_pairs counted it that way), so the CSR has row_ptr[I] <= 2 n_pairs entries. */
 int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij,
                      const int64_t *d_shards /*[4096] fill of the COO's shards as left by xmap_sim2_pairs (coo_cap / 4096
                                                slots each), or NULL: the COO is one range of n_pairs records*/,
                      int64_t n_pairs, const int32_t *own /*[I]*/, const int32_t *mir /*[I]*/, int32_t *tot /*[I] scratch*/,
                      int64_t *row_ptr /*[I+1] out*/, int64_t *mptr /*[I+1] scratch*/, int32_t *fill /*[I] scratch*/,
-                     void *bufA /*[n_pairs] x 24 B scratch*/, void *bufB /*[n_pairs] x 24 B scratch*/, int32_t *col,
-                     double *sim, int32_t *mutu, int32_t *nij);
+                     void *bufA /*[n_pairs] x 24 B (32 B with aux) scratch*/, void *bufB /*as bufA*/, int32_t *col,
+                     double *sim, int32_t *mutu, int32_t *nij, const double *coo_aux /*or NULL*/, double *aux /*or NULL*/);
 
 /* User-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard partial similarities"): a rank
  * holds the complete profiles of a share of the USERS.  Per item its share of get_universal_item_info's sums

@@ -1522,26 +1522,34 @@ __global__ __launch_bounds__(256) void k_row_totals(int I, const int *own, const
 // keyed by the heavier item; its chunks are listed from the shard cursors (k_coo_chunks), so every slot of a chunk is a
 // record.  The same workgroup writes the OWN half of its chunk (extra): the records of one unit are contiguous in the
 // COO and share the lighter item i -- one cursor bump per run, coalesced writes, the chunk still in the caches.
-struct CooLoader {
+// AUX: a sixth COO column travels along (RecommenderSim: the pair's local sensitivity; 32-byte records), and a row may pair
+// with itself -- such a record has an own entry and no mirrored one (k_ts_bin does not route it)
+template <bool AUX>
+struct CooLoaderT {
+    static constexpr int RW = AUX ? 4 : 3;
     const int *__restrict__ coo_i; const int *__restrict__ coo_j; const double *__restrict__ coo_sim;
-    const int *__restrict__ coo_mutu; const int *__restrict__ coo_nij;
+    const int *__restrict__ coo_mutu; const int *__restrict__ coo_nij; const double *__restrict__ coo_aux;
     const longlong2 *chunks; const unsigned *n_chunks;
-    const long long *row_ptr; int *fill; int *col; double *sim; int *mutu; int *nij;
+    const long long *row_ptr; int *fill; int *col; double *sim; int *mutu; int *nij; double *aux;
     __device__ __forceinline__ bool chunk(long long, long long &i0, long long &i1) const {
         if (blockIdx.x >= *n_chunks) return false;
         const longlong2 c = chunks[blockIdx.x];
         i0 = c.x; i1 = c.x + c.y;
         return true;
     }
-    __device__ __forceinline__ void load(long long idx, unsigned long long (&w)[3]) const {
+    __device__ __forceinline__ void load(long long idx, unsigned long long (&w)[RW]) const {
         w[0] = (unsigned long long)(unsigned)coo_j[idx] | ((unsigned long long)(unsigned)coo_i[idx] << 32);
         w[1] = (unsigned long long)__double_as_longlong(coo_sim[idx]);
         w[2] = (unsigned long long)(unsigned)coo_mutu[idx] | ((unsigned long long)(unsigned)coo_nij[idx] << 32);
+        if (AUX) w[RW - 1] = (unsigned long long)__double_as_longlong(coo_aux[idx]);
+    }
+    __device__ __forceinline__ bool keep(const unsigned long long (&w)[RW]) const {
+        return !AUX || (unsigned)w[0] != (unsigned)(w[0] >> 32);
     }
     // own half of the chunk: for a fixed r the lanes of a wave hold consecutive COO slots
-    __device__ __forceinline__ void extra(long long, const unsigned long long (&w)[ts::Chunk<3>::EPT][3],
-                                          const bool (&on)[ts::Chunk<3>::EPT]) const {
-        constexpr int E = ts::Chunk<3>::EPT;
+    __device__ __forceinline__ void extra(long long, const unsigned long long (&w)[ts::Chunk<RW>::EPT][RW],
+                                          const bool (&on)[ts::Chunk<RW>::EPT]) const {
+        constexpr int E = ts::Chunk<RW>::EPT;
         const int lane = lane_id();
         int lead[E], base[E];
         long long rp[E];
@@ -1566,6 +1574,7 @@ struct CooLoader {
                 const long long a = rp[r] + bs + (lane - lead[r]);
                 col[a] = (int)(unsigned)w[r][0]; sim[a] = __longlong_as_double((long long)w[r][1]);
                 mutu[a] = (int)(unsigned)w[r][2]; nij[a] = (int)(w[r][2] >> 32);
+                if (AUX) aux[a] = __longlong_as_double((long long)w[r][RW - 1]);
             }
         }
     }
@@ -1593,13 +1602,17 @@ __global__ __launch_bounds__(256) void k_coo_chunks(int n_shards, long long shar
 }
 
 // level C of the mirror: the small keys of a tile, laid out as CSR columns in LDS, leave as whole row segments
+template <bool AUX>
 __global__ __launch_bounds__(ts::CT) void k_mir_tiles(ts::Geo G, const unsigned long long *bufB, const long long *row_ptr,
-                                                      const int *own, int *col, double *sim, int *mutu, int *nij) {
+                                                      const int *own, int *col, double *sim, int *mutu, int *nij, double *aux) {
+    constexpr int RW = AUX ? 4 : 3;
+    constexpr int CAPX = AUX ? 2048 : ts::CAP;      // (with the sixth column: 68 KB of LDS, two workgroups per CU still)
     __shared__ unsigned cur[ts::NK_MAX], kst[ts::NK_MAX];
     __shared__ long long gsh[ts::NK_MAX];
-    __shared__ double lsim[ts::CAP];
-    __shared__ int lcol[ts::CAP], lmutu[ts::CAP], lnij[ts::CAP];
-    __shared__ unsigned short lkk[ts::CAP];
+    __shared__ double lsim[CAPX];
+    __shared__ double laux[AUX ? CAPX : 1];
+    __shared__ int lcol[CAPX], lmutu[CAPX], lnij[CAPX];
+    __shared__ unsigned short lkk[CAPX];
     const ts::TileHead h = ts::tile_head(G, blockIdx.x);
     if (h.nk <= 0 || h.n <= 0) return;
     for (int x = threadIdx.x; x < h.nk; x += ts::CT) {
@@ -1609,17 +1622,18 @@ __global__ __launch_bounds__(ts::CT) void k_mir_tiles(ts::Geo G, const unsigned 
         gsh[x] = row_ptr[k] + own[k] - G.ptr[k];        // mirrored position -> CSR position of key k
     }
     __syncthreads();
-    const bool in_lds = h.n <= ts::CAP;
+    const bool in_lds = h.n <= CAPX;
     constexpr int UN = 4;
     for (int base = 0; base < h.n; base += ts::CT * UN) {
-        unsigned long long w[UN][3];
+        unsigned long long w[UN][RW];
         bool on[UN];
 #pragma unroll
         for (int t = 0; t < UN; t++) {
             const int idx = base + t * ts::CT + threadIdx.x;
             on[t] = idx < h.n;
-            const size_t o = (size_t)(h.pos0 + (on[t] ? idx : 0)) * 3;
-            w[t][0] = bufB[o]; w[t][1] = bufB[o + 1]; w[t][2] = bufB[o + 2];
+            const size_t o = (size_t)(h.pos0 + (on[t] ? idx : 0)) * RW;
+#pragma unroll
+            for (int x = 0; x < RW; x++) w[t][x] = bufB[o + x];
         }
 #pragma unroll
         for (int t = 0; t < UN; t++) {
@@ -1628,8 +1642,15 @@ __global__ __launch_bounds__(ts::CT) void k_mir_tiles(ts::Geo G, const unsigned 
             const unsigned q = kst[kk] + atomicAdd(&cur[kk], 1u);
             const int ci = (int)(w[t][0] >> 32), cm = (int)(unsigned)w[t][2], cn = (int)(w[t][2] >> 32);
             const double cs = __longlong_as_double((long long)w[t][1]);
-            if (in_lds) { lcol[q] = ci; lsim[q] = cs; lmutu[q] = cm; lnij[q] = cn; lkk[q] = (unsigned short)kk; }
-            else { const long long P = h.pos0 + q + gsh[kk]; col[P] = ci; sim[P] = cs; mutu[P] = cm; nij[P] = cn; }
+            const double ca = AUX ? __longlong_as_double((long long)w[t][RW - 1]) : 0.0;
+            if (in_lds) {
+                lcol[q] = ci; lsim[q] = cs; lmutu[q] = cm; lnij[q] = cn; lkk[q] = (unsigned short)kk;
+                if (AUX) laux[q] = ca;
+            } else {
+                const long long P = h.pos0 + q + gsh[kk];
+                col[P] = ci; sim[P] = cs; mutu[P] = cm; nij[P] = cn;
+                if (AUX) aux[P] = ca;
+            }
         }
     }
     if (!in_lds) return;
@@ -1637,11 +1658,14 @@ __global__ __launch_bounds__(ts::CT) void k_mir_tiles(ts::Geo G, const unsigned 
     for (int q = threadIdx.x; q < h.n; q += ts::CT) {
         const long long P = h.pos0 + q + gsh[lkk[q]];
         col[P] = lcol[q]; sim[P] = lsim[q]; mutu[P] = lmutu[q]; nij[P] = lnij[q];
+        if (AUX) aux[P] = laux[q];
     }
 }
 
+template <bool AUX>
 __global__ __launch_bounds__(ts::LT) void k_mir_large(ts::Geo G, const unsigned long long *bufB, const long long *row_ptr,
-                                                      const int *own, int *col, double *sim, int *mutu, int *nij) {
+                                                      const int *own, int *col, double *sim, int *mutu, int *nij, double *aux) {
+    constexpr int RW = AUX ? 4 : 3;
     if (blockIdx.x >= G.counters[1]) return;
     const int2 sl = G.slist[blockIdx.x];
     const int k = sl.x;
@@ -1649,10 +1673,11 @@ __global__ __launch_bounds__(ts::LT) void k_mir_large(ts::Geo G, const unsigned 
     const long long hi = min(G.ptr[k + 1], lo + ts::SL);
     const long long sh = row_ptr[k] + own[k] - G.ptr[k];
     for (long long p = lo + threadIdx.x; p < hi; p += ts::LT) {
-        const unsigned long long w0 = bufB[(size_t)p * 3], w1 = bufB[(size_t)p * 3 + 1], w2 = bufB[(size_t)p * 3 + 2];
+        const unsigned long long w0 = bufB[(size_t)p * RW], w1 = bufB[(size_t)p * RW + 1], w2 = bufB[(size_t)p * RW + 2];
         const long long P = p + sh;
         col[P] = (int)(w0 >> 32); sim[P] = __longlong_as_double((long long)w1);
         mutu[P] = (int)(unsigned)w2; nij[P] = (int)(w2 >> 32);
+        if (AUX) aux[P] = __longlong_as_double((long long)bufB[(size_t)p * RW + 3]);
     }
 }
 
@@ -1725,6 +1750,30 @@ int ts_prepare(hipStream_t st, ts::Geo &G, const long long *ptr) {
     ts::k_ts_plan<<<dim3((unsigned)((G.K + 255) / 256)), dim3(256), 0, st>>>(G);
     XM_LAUNCH_CHECK();
     ts::k_ts_chunks<<<dim3((unsigned)((G.NA + 255) / 256)), dim3(256), 0, st>>>(G);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+}  // namespace
+
+namespace {
+template <bool AUX>
+int mirror_levels(hipStream_t st, const ts::Geo &G, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
+                  const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_aux, const longlong2 *chunks, const unsigned *n_chunks,
+                  long long chunk_cap, int64_t n_pairs, const int32_t *own, const int64_t *row_ptr, int32_t *fill, void *bufA, void *bufB,
+                  int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *aux) {
+    constexpr int RW = AUX ? 4 : 3;
+    CooLoaderT<AUX> LA{coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, (const long long *)row_ptr, fill,
+                       col, sim, mutu, nij, aux};
+    ts::RecLoader<RW> LB{(const unsigned long long *)bufA};
+    ts::k_ts_bin<RW, false, CooLoaderT<AUX>><<<dim3((unsigned)chunk_cap), dim3(ts::BT), 0, st>>>(G, LA, coo_cap, (unsigned long long *)bufA);
+    XM_LAUNCH_CHECK();
+    ts::k_ts_bin<RW, true, ts::RecLoader<RW>><<<dim3((unsigned)G.clist_cap), dim3(ts::BT), 0, st>>>(G, LB, n_pairs, (unsigned long long *)bufB);
+    XM_LAUNCH_CHECK();
+    k_mir_tiles<AUX><<<dim3((unsigned)G.T), dim3(ts::CT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)row_ptr, own, col,
+                                                                   sim, mutu, nij, aux);
+    XM_LAUNCH_CHECK();
+    k_mir_large<AUX><<<dim3((unsigned)G.slist_cap), dim3(ts::LT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)row_ptr, own,
+                                                                            col, sim, mutu, nij, aux);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -2290,11 +2339,12 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
 int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *d_shards, int64_t n_pairs,
                      const int32_t *own, const int32_t *mir, int32_t *tot, int64_t *row_ptr, int64_t *mptr, int32_t *fill,
-                     void *bufA, void *bufB, int32_t *col, double *sim, int32_t *mutu, int32_t *nij) {
+                     void *bufA, void *bufB, int32_t *col, double *sim, int32_t *mutu, int32_t *nij, const double *coo_aux, double *aux) {
     XM_SCOPE(stream);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && own && mir && tot && row_ptr && mptr && fill && bufA && bufB);
     XM_ARG(col && sim && mutu && nij && n_items >= 0 && coo_cap >= 0 && n_pairs >= 0 && n_pairs < 0x7fffffffLL);
     XM_ARG(d_shards ? (coo_cap >= COO_SHARDS) : (n_pairs <= coo_cap));
+    XM_ARG((coo_aux != nullptr) == (aux != nullptr));
     hipStream_t st = (hipStream_t)stream;
     const int I = n_items;
     if (I > 0) {
@@ -2308,10 +2358,11 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
     if (n_pairs == 0 || I == 0 || coo_cap == 0) return XMAP_OK;
     XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)I, st));
     ts::Geo G;
-    ts_geometry(I, n_pairs, ts::Chunk<3>::CH, G);
+    ts_geometry(I, n_pairs, ts::Chunk<3>::CH, G);      // (n_pairs bounds the mirrored records: a self pair has none)
     rcode = ts_prepare(st, G, (const long long *)mptr);
     if (rcode) return rcode;
     // the COO's chunks: from the shard cursors of the pair kernels, or one range of n_pairs records
+    static_assert(ts::Chunk<3>::CH == ts::Chunk<4>::CH, "one chunk list for both record widths");
     const int n_shards = d_shards ? COO_SHARDS : 1;
     const long long shard_cap = d_shards ? coo_cap / COO_SHARDS : coo_cap;
     const long long chunk_cap = n_pairs / ts::Chunk<3>::CH + n_shards + 1;
@@ -2323,18 +2374,10 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
     k_coo_chunks<<<dim3((unsigned)((n_shards + 255) / 256)), dim3(256), 0, st>>>(n_shards, shard_cap, (const unsigned long long *)d_shards,
                                                                                  n_pairs, chunks, n_chunks, chunk_cap);
     XM_LAUNCH_CHECK();
-    CooLoader LA{coo_i, coo_j, coo_sim, coo_mutu, coo_nij, chunks, n_chunks, (const long long *)row_ptr, fill, col, sim, mutu, nij};
-    ts::RecLoader<3> LB{(const unsigned long long *)bufA};
-    ts::k_ts_bin<3, false, CooLoader><<<dim3((unsigned)chunk_cap), dim3(ts::BT), 0, st>>>(G, LA, coo_cap, (unsigned long long *)bufA);
-    XM_LAUNCH_CHECK();
-    ts::k_ts_bin<3, true, ts::RecLoader<3>><<<dim3((unsigned)G.clist_cap), dim3(ts::BT), 0, st>>>(G, LB, n_pairs, (unsigned long long *)bufB);
-    XM_LAUNCH_CHECK();
-    k_mir_tiles<<<dim3((unsigned)G.T), dim3(ts::CT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)row_ptr, own, col, sim,
-                                                              mutu, nij);
-    XM_LAUNCH_CHECK();
-    k_mir_large<<<dim3((unsigned)G.slist_cap), dim3(ts::LT), 0, st>>>(G, (const unsigned long long *)bufB, (const long long *)row_ptr, own, col,
-                                                                       sim, mutu, nij);
-    XM_LAUNCH_CHECK();
-    return XMAP_OK;
+    if (coo_aux)
+        return mirror_levels<true>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, chunk_cap, n_pairs, own,
+                                   row_ptr, fill, bufA, bufB, col, sim, mutu, nij, aux);
+    return mirror_levels<false>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, chunks, n_chunks, chunk_cap, n_pairs, own,
+                                row_ptr, fill, bufA, bufB, col, sim, mutu, nij, nullptr);
 }
 }

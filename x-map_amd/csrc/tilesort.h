@@ -29,7 +29,7 @@ namespace ts {
 
 constexpr int BT = 256;           // threads of a binning workgroup
 // records per workgroup of a binning level: the chunk is staged in LDS in bucket order (16-byte records: 64 KB, 24-byte
-// records: 48 KB; two workgroups per CU either way)
+// records: 48 KB, 32-byte records: 64 KB; two workgroups per CU either way)
 template <int RW> struct Chunk { static constexpr int CH = RW == 2 ? 4096 : 2048; static constexpr int EPT = CH / BT; };
 constexpr int NB_LOG = 7;
 constexpr int NB = 1 << NB_LOG;   // fine tiles per level-A bucket
@@ -126,6 +126,8 @@ struct RecLoader {
 #pragma unroll
         for (int x = 0; x < RW; x++) w[x] = in[idx * RW + x];
     }
+    // a record the level does not route (it still reaches extra): none here
+    __device__ __forceinline__ bool keep(const unsigned long long (&)[RW]) const { return true; }
     // what else the workgroup does with its chunk (w[r] = record i0 + r BT + tid, on[r]: there is one)
     __device__ __forceinline__ void extra(long long, const unsigned long long (&)[Chunk<RW>::EPT][RW], const bool (&)[Chunk<RW>::EPT]) const {}
 };
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
     for (int b = tid; b < nbk; b += BT) hist[b] = 0u;
     __syncthreads();
     unsigned long long w[EPT][RW];
-    bool on[EPT];
+    bool on[EPT], rt[EPT];  // there is a record; it is routed
     unsigned br[EPT];       // tile word, then bucket << 16 | rank
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
@@ -171,12 +173,13 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
 #pragma unroll
             for (int x = 0; x < RW; x++) w[r][x] = 0ull;
         }
+        rt[r] = on[r] && L.keep(w[r]);
     }
 #pragma unroll
-    for (int r = 0; r < EPT; r++) br[r] = on[r] ? G.tk[(unsigned)w[r][0]] : 0u;
+    for (int r = 0; r < EPT; r++) br[r] = rt[r] ? G.tk[(unsigned)w[r][0]] : 0u;
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
-        if (!on[r]) continue;
+        if (!rt[r]) continue;
         const unsigned tkv = br[r];
         const int t = (int)(tkv & 0x7fffffffu);
         const int b = LEVEL_B ? ((t & (NB - 1)) | ((tkv >> 31) ? NB : 0)) : (t >> NB_LOG);
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(BT) void k_ts_bin(Geo G, Loader L, long long n_in, 
     }
 #pragma unroll
     for (int r = 0; r < EPT; r++) {
-        if (!on[r]) continue;
+        if (!rt[r]) continue;
         const unsigned b = br[r] >> 16, s = off[b] + (br[r] & 0xffffu);
 #pragma unroll
         for (int x = 0; x < RW; x++) stage[s * RW + x] = w[r][x];

@@ -549,8 +549,12 @@ class Engine(object):
         with self.timed("rec_stats"):
             stats, L = self.layout3(slot_target, ch_min=max(64, R.n_users + 2), wide=True)      # no heavy set
         info = stats[2]
-        coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
-        S = self.tri_scatter(coo, rowcnt, info, n, L)
+        if os.environ.get("XMAP_A_V2") == "1":        # round-2 mirror (cursor atomics), kept as a cross-check
+            coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
+            S = self.tri_scatter(coo, rowcnt, info, n, L)
+        else:
+            coo, own, n, n_unordered, mir, shards = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True, split=True)
+            S = self.tri_mirror(coo, own, mir, info, n, shards)
         S.cap, S.n_unordered, S.layout = int(cap), n_unordered, L
         S.norm = self.norms[R.n_items:2 * R.n_items]
         return S
@@ -635,23 +639,30 @@ class Engine(object):
         st = _stream(self.dev)
         I = R.n_items
         coo_i, coo_j, coo_sim, coo_mutu, coo_nij = [x.contiguous() for x in coo[:5]]
+        coo_ls = coo[5].contiguous() if len(coo) > 5 else None       # RecommenderSim: local sensitivities, self pairs
         cap = int(coo_i.numel())
-        kept = 2 * int(n)
+        kept = 2 * int(n)                                            # (an upper bound with self pairs: one entry each)
+        rw = 4 if coo_ls is not None else 3
         row_ptr = self._out(I + 1, torch.int64, I > 0)
         mptr = self._empty(I + 1, torch.int64)
         tot = self._empty(max(I, 1), torch.int32)
         fill = self._empty(max(I, 1), torch.int32)
-        buf_a = self._empty(max(int(n), 1) * 3, torch.int64)
-        buf_b = self._empty(max(int(n), 1) * 3, torch.int64)
+        buf_a = self._empty(max(int(n), 1) * rw, torch.int64)
+        buf_b = self._empty(max(int(n), 1) * rw, torch.int64)
         col = self._empty(max(kept, 1), torch.int32)
         sim = self._empty(max(kept, 1), torch.float64)
         mutu = self._empty(max(kept, 1), torch.int32)
         nij = self._empty(max(kept, 1), torch.int32)
+        ls = self._empty(max(kept, 1), torch.float64) if coo_ls is not None else None
         with self.timed("scatter"):
             check(lib.xmap_sim3_mirror(st, i32(I), i64(cap), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu), vp(coo_nij), vp(shards), i64(n),
                                        vp(own), vp(mir), vp(tot), vp(row_ptr), vp(mptr), vp(fill), vp(buf_a), vp(buf_b), vp(col),
-                                       vp(sim), vp(mutu), vp(nij)))
-        return self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
+                                       vp(sim), vp(mutu), vp(nij), vp(coo_ls), vp(ls)))
+        if coo_ls is not None:
+            kept = int(row_ptr[I].item()) if I > 0 else 0
+        S = self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
+        S.ls = ls[:kept] if ls is not None else None
+        return S
 
     def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
         """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU).  XMAP_A_V2=1: the round-2 sequence
