@@ -230,7 +230,9 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
                      int64_t n_pairs, const int32_t *own /*[I]*/, const int32_t *mir /*[I]*/, int32_t *tot /*[I] scratch*/,
                      int64_t *row_ptr /*[I+1] out*/, int64_t *mptr /*[I+1] scratch*/, int32_t *fill /*[I] scratch*/,
                      void *bufA /*[n_pairs] x 24 B (32 B with aux) scratch*/, void *bufB /*as bufA*/, int32_t *col,
-                     double *sim, int32_t *mutu, int32_t *nij, const double *coo_aux /*or NULL*/, double *aux /*or NULL*/);
+                     double *sim, int32_t *mutu, int32_t *nij, const double *coo_aux /*or NULL*/, double *aux /*or NULL*/,
+                     int32_t row_lo, int32_t row_hi /*the rows to build: 0, n_items = all.  An item-sharded rank builds its share of
+                     the rows from the complete COO: own / mir must be zero outside [row_lo, row_hi), entries of other rows are skipped*/);
 
 /* User-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard partial similarities"): a rank
  * holds the complete profiles of a share of the USERS.  Per item its share of get_universal_item_info's sums

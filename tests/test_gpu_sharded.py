@@ -55,13 +55,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world2_equals_world1():
+@pytest.mark.parametrize("world", [2, 3])
+def test_world2_equals_world1(world):
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
     from xmap.engine import sharded
     ref = _summary(sharded.run_step(_engine(), "adjust_cosine", 50, 5, True))
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -74,9 +75,22 @@ def test_world2_equals_world1():
     assert ref["n_kept"] > 0 and ref["n_paths"] > 0 and ref["n_rows"] > 0
     for rank, out in got:
         for key, v in ref.items():
+            if key in ("row_ptr", "col", "sim"):
+                continue
             assert np.array_equal(out[key], v), (rank, key)
-    # the two partitions are disjoint and together are the whole matrix
+    # stage B builds the matrix in row shares (a rank mirrors its rows only): contiguous, disjoint, together the whole matrix
     I = len(ref["row_ptr"]) - 1
+    lens = np.stack([np.diff(out["row_ptr"]) for _, out in sorted(got)])
+    assert np.array_equal(lens.sum(axis=0), np.diff(ref["row_ptr"])) and np.all((lens > 0).sum(axis=0) <= 1)
+    owner = np.where((lens > 0).any(axis=0), lens.argmax(axis=0), -1)
+    assert np.all(np.diff(owner[owner >= 0]) >= 0) and all((owner == r).any() for r in range(world))
+    s_rows = np.concatenate([np.repeat(np.arange(I), np.diff(out["row_ptr"])) for _, out in sorted(got)])
+    s_cols = np.concatenate([out["col"] for _, out in sorted(got)])
+    s_sims = np.concatenate([out["sim"] for _, out in sorted(got)])
+    o = np.lexsort((s_cols, s_rows))
+    assert np.array_equal(s_rows[o], np.repeat(np.arange(I), np.diff(ref["row_ptr"])))
+    assert np.array_equal(s_cols[o], ref["col"]) and np.array_equal(s_sims[o], ref["sim"])
+    # the two stage-A partitions are disjoint and together are the whole matrix
     rows = np.concatenate([out["part_row"] for _, out in got])
     cols = np.concatenate([out["part_col"] for _, out in got])
     sims = np.concatenate([out["part_sim"] for _, out in got])

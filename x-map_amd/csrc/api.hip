@@ -323,7 +323,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     XM_ALLOC(c->p_sim, col, kept); XM_ALLOC(c->p_sim, sim, kept); XM_ALLOC(c->p_sim, mutu, kept); XM_ALLOC(c->p_sim, nij, kept);
     T_ALLOC(fill, I); T_ALLOC(tot, I); T_ALLOC(mir_a, (size_t)3 * (n ? n : 1)); T_ALLOC(mir_b, (size_t)3 * (n ? n : 1));
     XM_TRY(xmap_sim3_mirror(c->st, I, cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, d_shards, n, own, mir, tot, row_ptr, mptr, fill,
-                            mir_a, mir_b, col, sim, mutu, nij, nullptr, nullptr));
+                            mir_a, mir_b, col, sim, mutu, nij, nullptr, nullptr, 0, I));
     XM_HIP(hipStreamSynchronize(c->st));
     c->S.n_items = I; c->S.row_ptr = row_ptr; c->S.col = col; c->S.sim = sim; c->S.mutu = mutu; c->S.nij = nij; c->S.info = c->info;
     c->S.frac = nullptr;

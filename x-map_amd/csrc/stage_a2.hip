@@ -532,8 +532,14 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
     // table work was a fraction -- profiles/tools/trace_a.py): an inclusive scan of the prefix lengths over the lanes, then
     // lane l of round t takes co-rating 64 t + l, finds its rater by binary search over the scan (log2 RB permutes) and loads
     // its entry; all loads of WU rounds are in flight together and every lane of every round but the last is busy.
-    constexpr int RB = (NW == 1 || NW == 16) ? 64 : 16;
-    constexpr int WU = 2;
+#ifndef EXP_RB       // (tuning builds: profiles/tools/a_variants.sh; shipped values below)
+#define EXP_RB 16
+#endif
+#ifndef EXP_WU
+#define EXP_WU 2
+#endif
+    constexpr int RB = (NW == 1 || NW == 16) ? 64 : EXP_RB;
+    constexpr int WU = EXP_WU;
     auto rater = [&](int p, int &e0, int &pw, RT &r, int &usr) {
         e0 = 0; pw = 0; r = (RT)0; usr = -1;
         if (lane < RB && p < p1) {
@@ -1531,6 +1537,7 @@ struct CooLoaderT {
     const int *__restrict__ coo_mutu; const int *__restrict__ coo_nij; const double *__restrict__ coo_aux;
     const longlong2 *chunks; const unsigned *n_chunks;
     const long long *row_ptr; int *fill; int *col; double *sim; int *mutu; int *nij; double *aux;
+    int row_lo, row_hi;       // the rows this call builds (an item-sharded rank: its share; the counts outside it are zero)
     __device__ __forceinline__ bool chunk(long long, long long &i0, long long &i1) const {
         if (blockIdx.x >= *n_chunks) return false;
         const longlong2 c = chunks[blockIdx.x];
@@ -1544,7 +1551,8 @@ struct CooLoaderT {
         if (AUX) w[RW - 1] = (unsigned long long)__double_as_longlong(coo_aux[idx]);
     }
     __device__ __forceinline__ bool keep(const unsigned long long (&w)[RW]) const {
-        return !AUX || (unsigned)w[0] != (unsigned)(w[0] >> 32);
+        const int j = (int)(unsigned)w[0];
+        return (!AUX || j != (int)(w[0] >> 32)) && j >= row_lo && j < row_hi;
     }
     // own half of the chunk: for a fixed r the lanes of a wave hold consecutive COO slots
     __device__ __forceinline__ void extra(long long, const unsigned long long (&w)[ts::Chunk<RW>::EPT][RW],
@@ -1555,7 +1563,9 @@ struct CooLoaderT {
         long long rp[E];
 #pragma unroll
         for (int r = 0; r < E; r++) {
-            const int iu = on[r] ? (int)(w[r][0] >> 32) : -1 - lane;       // inactive lanes: unique fake rows
+            const int iw = (int)(w[r][0] >> 32);
+            const bool mine = on[r] && iw >= row_lo && iw < row_hi;
+            const int iu = mine ? iw : -1 - lane;                           // inactive lanes: unique fake rows
             const int prev = __shfl_up(iu, 1, 64);
             const bool leader = (lane == 0) || (prev != iu);
             const unsigned long long lm = __ballot(leader);
@@ -1563,14 +1573,14 @@ struct CooLoaderT {
             lead[r] = 63 - __clzll((long long)below);
             const unsigned long long above = (lane == 63) ? 0ull : (lm >> (lane + 1));
             const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-            base[r] = 0; rp[r] = 0;
-            if (leader && on[r]) base[r] = atomicAdd(&fill[iu], next - lane);
-            if (on[r]) rp[r] = row_ptr[iu];
+            base[r] = 0; rp[r] = -1;
+            if (leader && mine) base[r] = atomicAdd(&fill[iu], next - lane);
+            if (mine) rp[r] = row_ptr[iu];
         }
 #pragma unroll
         for (int r = 0; r < E; r++) {
             const int bs = __shfl(base[r], lead[r], 64);
-            if (on[r]) {
+            if (rp[r] >= 0) {
                 const long long a = rp[r] + bs + (lane - lead[r]);
                 col[a] = (int)(unsigned)w[r][0]; sim[a] = __longlong_as_double((long long)w[r][1]);
                 mutu[a] = (int)(unsigned)w[r][2]; nij[a] = (int)(w[r][2] >> 32);
@@ -1760,10 +1770,10 @@ template <bool AUX>
 int mirror_levels(hipStream_t st, const ts::Geo &G, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
                   const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_aux, const longlong2 *chunks, const unsigned *n_chunks,
                   long long chunk_cap, int64_t n_pairs, const int32_t *own, const int64_t *row_ptr, int32_t *fill, void *bufA, void *bufB,
-                  int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *aux) {
+                  int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *aux, int row_lo, int row_hi) {
     constexpr int RW = AUX ? 4 : 3;
     CooLoaderT<AUX> LA{coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, (const long long *)row_ptr, fill,
-                       col, sim, mutu, nij, aux};
+                       col, sim, mutu, nij, aux, row_lo, row_hi};
     ts::RecLoader<RW> LB{(const unsigned long long *)bufA};
     ts::k_ts_bin<RW, false, CooLoaderT<AUX>><<<dim3((unsigned)chunk_cap), dim3(ts::BT), 0, st>>>(G, LA, coo_cap, (unsigned long long *)bufA);
     XM_LAUNCH_CHECK();
@@ -2339,8 +2349,10 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
 int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
                      const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const int64_t *d_shards, int64_t n_pairs,
                      const int32_t *own, const int32_t *mir, int32_t *tot, int64_t *row_ptr, int64_t *mptr, int32_t *fill,
-                     void *bufA, void *bufB, int32_t *col, double *sim, int32_t *mutu, int32_t *nij, const double *coo_aux, double *aux) {
+                     void *bufA, void *bufB, int32_t *col, double *sim, int32_t *mutu, int32_t *nij, const double *coo_aux, double *aux,
+                     int32_t row_lo, int32_t row_hi) {
     XM_SCOPE(stream);
+    XM_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= n_items);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && own && mir && tot && row_ptr && mptr && fill && bufA && bufB);
     XM_ARG(col && sim && mutu && nij && n_items >= 0 && coo_cap >= 0 && n_pairs >= 0 && n_pairs < 0x7fffffffLL);
     XM_ARG(d_shards ? (coo_cap >= COO_SHARDS) : (n_pairs <= coo_cap));
@@ -2376,8 +2388,8 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
     XM_LAUNCH_CHECK();
     if (coo_aux)
         return mirror_levels<true>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, chunk_cap, n_pairs, own,
-                                   row_ptr, fill, bufA, bufB, col, sim, mutu, nij, aux);
+                                   row_ptr, fill, bufA, bufB, col, sim, mutu, nij, aux, row_lo, row_hi);
     return mirror_levels<false>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, chunks, n_chunks, chunk_cap, n_pairs, own,
-                                row_ptr, fill, bufA, bufB, col, sim, mutu, nij, nullptr);
+                                row_ptr, fill, bufA, bufB, col, sim, mutu, nij, nullptr, row_lo, row_hi);
 }
 }

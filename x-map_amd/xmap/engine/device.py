@@ -631,10 +631,12 @@ class Engine(object):
             L.finish = finish
         return (u_avg, u_norm, info, None, None), L
 
-    def tri_mirror(self, coo, own, mir, info, n, shards=None):
+    def tri_mirror(self, coo, own, mir, info, n, shards=None, rows=None):
         """round-3 mirror (xmap_sim3_mirror): a complete half COO with n valid entries, own[i] = pairs row i computed,
         mir[j] = pairs computed in lighter rows -> CSR, row = [own | mirrored].  shards: the cursors tri_pairs left (the
-        COO is cut into 4096 shards filled from their start); None: the COO is one range of n records."""
+        COO is cut into 4096 shards filled from their start); None: the COO is one range of n records.  rows = (lo, hi):
+        only these rows are built (the others stay empty) -- an item-sharded rank's share of the matrix, which is all its
+        knn and reverse-list shares read."""
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
@@ -642,6 +644,12 @@ class Engine(object):
         coo_ls = coo[5].contiguous() if len(coo) > 5 else None       # RecommenderSim: local sensitivities, self pairs
         cap = int(coo_i.numel())
         kept = 2 * int(n)                                            # (an upper bound with self pairs: one entry each)
+        lo, hi = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
+        if rows is not None and I > 0:
+            own, mir = own.clone(), mir.clone()
+            for c_ in (own, mir):
+                c_[:lo].zero_(); c_[hi:].zero_()
+            kept = int((own[lo:hi].long().sum() + mir[lo:hi].long().sum()).item())
         rw = 4 if coo_ls is not None else 3
         row_ptr = self._out(I + 1, torch.int64, I > 0)
         mptr = self._empty(I + 1, torch.int64)
@@ -657,7 +665,7 @@ class Engine(object):
         with self.timed("scatter"):
             check(lib.xmap_sim3_mirror(st, i32(I), i64(cap), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu), vp(coo_nij), vp(shards), i64(n),
                                        vp(own), vp(mir), vp(tot), vp(row_ptr), vp(mptr), vp(fill), vp(buf_a), vp(buf_b), vp(col),
-                                       vp(sim), vp(mutu), vp(nij), vp(coo_ls), vp(ls)))
+                                       vp(sim), vp(mutu), vp(nij), vp(coo_ls), vp(ls), i32(lo), i32(hi)))
         if coo_ls is not None:
             kept = int(row_ptr[I].item()) if I > 0 else 0
         S = self.sim_from_device(row_ptr, col[:kept], sim[:kept], mutu[:kept], nij[:kept], info)
@@ -985,17 +993,33 @@ class Engine(object):
         self.ext_gather(E, comm)
         return self.ext_reverse(S, E)
 
-    def ext_knn(self, S, top_k, comm=None):
-        """local part: the classified top-k lists of this rank's share of the rows (all rows without comm)"""
+    def row_shares(self, tot, world):
+        """cut points of `world` contiguous row shares of (about) equal entries; tot [I] = entries per row"""
         I = self.R.n_items
-        rows = None
-        if comm is not None and comm.world > 1 and I > 0:
+        cum = torch.cumsum(tot[:I].long(), 0)
+        tgt = (cum[I - 1].double() * torch.arange(1, world, dtype=torch.float64, device=self.dev) / world).long()
+        cuts = [0] + (torch.searchsorted(cum, tgt, right=False) + 1).clamp(max=I).tolist() + [I]
+        return np.maximum.accumulate(np.asarray(cuts))
+
+    def bridge_flags(self, S):
+        """B1: has the item a neighbour of the other domain?  From the rows S holds (an item-sharded rank: its share; the
+        flags of the other rows come out 0 and are all-reduced by the caller)."""
+        I = self.R.n_items
+        bb = self._zeros(max(I, 1), torch.uint8)
+        check(lib.xmap_bridge_flags(_stream(self.dev), C.byref(S.c), vp(self.R.prefix_cls), vp(bb)))
+        return bb
+
+    def ext_knn(self, S, top_k, comm=None, rows=None, bb=None):
+        """local part: the classified top-k lists of this rank's share of the rows (all rows without comm; rows = (lo, hi):
+        that share -- S then holds only those rows, and bb must be the complete bridge flags: a neighbour's class is read)"""
+        I = self.R.n_items
+        if rows is None and comm is not None and comm.world > 1 and I > 0:
             w = comm.world
             tgt = (S.row_ptr[I].double() * torch.arange(1, w, dtype=torch.float64, device=self.dev) / w).long()
             cuts = [0] + torch.searchsorted(S.row_ptr[:I + 1].contiguous(), tgt).clamp(max=I).tolist() + [I]
             cuts = np.maximum.accumulate(np.asarray(cuts))
             rows = (int(cuts[comm.rank]), int(cuts[comm.rank + 1]))
-        E = self.knn(S, top_k, rows=rows)
+        E = self.knn(S, top_k, bb=bb, rows=rows)
         E.rows = rows
         E.row_share = rows          # (kept for the reverse lists of a sharded step)
         ok = C.c_int32(1)
@@ -1012,6 +1036,9 @@ class Engine(object):
         lo, hi = rows
         with self.timed("knn_gather"):
             k = E.k
+            fd = torch.tensor([E.fast_div], dtype=torch.int64, device=self.dev)      # (every rank checked its own rows' edges)
+            comm.all_reduce(fd, "min")
+            E.fast_div = int(fd.item())
             E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
             E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
             E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)

@@ -68,7 +68,7 @@ class Comm(object):
         self.host = dist.get_backend(group) == "gloo"
 
     def all_reduce(self, t, op="sum"):
-        ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}
+        ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}
         if self.host and t.is_cuda:
             h = t.cpu()
             self.dist.all_reduce(h, op=ops[op], group=self.group)
@@ -327,8 +327,8 @@ def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot
 
 def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
     """stage B of a sharded step: coo / rowcnt = the n_local kept pairs this rank holds (any orientation, every unordered pair
-    on exactly one rank).  Returns (S: the full similarity matrix, E: the extension with the candidate arrays of ALL starts,
-    [paths, candidates] over all ranks)."""
+    on exactly one rank).  Returns (S: this rank's row share of the similarity matrix (the full one on the round-2 path), E: the
+    extension with the candidate arrays of ALL starts, [paths, candidates] over all ranks)."""
     dev = eng.dev
     # ---- stage B: knn tables + reverse lists everywhere (one HBM pass), paths sharded by start item with
     # ranges balanced by the exact per-start path counts
@@ -345,15 +345,30 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
             rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
             n_all = int(rec.shape[0])
             coo = eng.unpack_pairs(rec)
+            # the rows of the matrix this rank builds: its knn and reverse-list shares read nothing else (round 3: every rank
+            # mirrored the whole COO, 1.3 ms replicated)
+            share = None
+            if split and eng.R.n_items > 0:
+                cuts = eng.row_shares(rowcnt[0] + rowcnt[1], world)
+                share = (int(cuts[rank]), int(cuts[rank + 1]))
         # No collective sits between a possible raise and the agree() that follows it: the local phases run in try blocks,
         # the all-gathers of the knn tables (ext_gather) run outside any of them.
-        err, S, E = None, None, None
+        err, S, E, bb = None, None, None, None
         try:
-            S = eng.tri_mirror(coo, rowcnt[0], rowcnt[1], info, n_all) if split else eng.tri_scatter(coo, rowcnt, info, None, L)
-            E = eng.ext_knn(S, k, comm)
+            S = eng.tri_mirror(coo, rowcnt[0], rowcnt[1], info, n_all, rows=share) if split else eng.tri_scatter(coo, rowcnt, info, None, L)
+            if share is not None:
+                bb = eng.bridge_flags(S).to(torch.int32)      # of this rank's rows; a list entry is classified by its
+        except Exception as e:                                # NEIGHBOUR's flag, so the flags are completed first
+            err = e
+        comm.agree(err, "stage B (mirror)")
+        if share is not None:
+            comm.all_reduce(bb, "max")
+        err = None
+        try:
+            E = eng.ext_knn(S, k, comm, rows=share, bb=bb)
         except Exception as e:
             err = e
-        comm.agree(err, "stage B (mirror + knn tables)")
+        comm.agree(err, "stage B (knn tables)")
         eng.ext_gather(E, comm)
         # the three reverse adjacencies (attach / src / rnn) in row shares: the list of a row comes from that row alone, so
         # the ranks' pieces are contiguous -- counts all-gathered, entries all-gathered (S8 / S9 of SURVEY 2.3)
