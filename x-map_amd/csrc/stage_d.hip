@@ -91,7 +91,7 @@ void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, 
                   int *out_idx, float *out_val) {
     __shared__ __attribute__((aligned(16))) float Bs[2][D_GROUP * D_TILE][K + 4];   // row stride K+4: conflict-free ds_read_b128
 
-    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int w = uniform((int)(threadIdx.x >> 6)), lane = lane_id();      // (uniform: the schedule's branches are scalar ones)
     const bool late = w >= D_WAVES / 2;   // waves w and w + 4 share a SIMD (checked with HW_REG_HW_ID, build -DD_TRACE)
 #ifdef D_TRACE
     const unsigned long long rt0 = wall_clock64();
@@ -172,25 +172,36 @@ void k_dense_topk(int n_t, int n_s, int n_tiles, long long share, int n_pieces, 
             lv = lane > pos ? sv : (lane == pos ? cv : lv);
             li = lane > pos ? si : (lane == pos ? cj : li);
             const float nb = fabsf(rlf(lv, k - 1));
-            if ((lane >= 32) == upper) th = nb;
+            th = ((lane >= 32) == upper) ? nb : th;
         }
     };
     auto rank_tile = [&](const f32x16 &acc, int c0) {
         const int j = c0 + (lane & 31);
-        const bool jv = j < s_hi;
+        const bool whole = c0 + D_TILE <= s_hi;                 // every column of the tile exists (all tiles but the last)
+        const unsigned long long jm = whole ? ~0ull : __ballot(j < s_hi);
+        // the 16 threshold masks first (v_cmp_ge_f32 |v|, thr -> SGPR pair each; 3 = ordered >=; a __ballot of the bool costs
+        // a v_cndmask and a second compare per register), ONE branch for the common tile that has no candidate at all (a
+        // branch per register was sixteen taken branches per tile)
+        unsigned long long m[16], any = 0ull;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float v = acc[r];
-            const unsigned long long m = __ballot(jv && fabsf(v) >= thr[r]);
-#ifdef D_NOINSERT
-            if (m == 0x123456789abcull) out_val[1] = 1.f;
-#else
-            if (m) {
-                insert(Lv[2 * r], Li[2 * r], thr[r], (unsigned)m, 0, v, c0, false);
-                insert(Lv[2 * r + 1], Li[2 * r + 1], thr[r], (unsigned)(m >> 32), 32, v, c0, true);
-            }
-#endif
+            m[r] = __builtin_amdgcn_fcmpf(fabsf(acc[r]), thr[r], 3) & jm;
+            any |= m[r];
         }
+#ifdef D_NOINSERT
+        if (any == 0x123456789abcull) out_val[1] = 1.f;
+#else
+        if (any) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (m[r]) {
+                    const float v = acc[r];
+                    insert(Lv[2 * r], Li[2 * r], thr[r], (unsigned)m[r], 0, v, c0, false);
+                    insert(Lv[2 * r + 1], Li[2 * r + 1], thr[r], (unsigned)(m[r] >> 32), 32, v, c0, true);
+                }
+            }
+        }
+#endif
     };
 
     const int n_groups = ((s_hi - s_lo + D_TILE - 1) / D_TILE + D_GROUP - 1) / D_GROUP;
