@@ -477,8 +477,23 @@ struct ATraceEnd { long long u; long long t0;
 #else
 #define A_STAMP(k) do {} while (0)
 #endif
+// A field of the kernel's argument struct, read from the kernarg segment where it is used (a volatile scalar load: it stays
+// at that place).  The finalisation needs seventeen pointers the walk never touches; as plain uses of A they are all loaded
+// at the kernel's entry and kept -- 101 SGPRs, i.e. 7 waves per SIMD, or ~100 v_writelane / v_readlane spill moves per unit
+// (a sixth of its vector instructions) when the kernel is held to 8.
+#ifdef EXP_NOKARG
+#define KARG(field) (A.field)
+#else
+#define KARG(field) (*(decltype(TriArgs::field) const volatile __attribute__((address_space(4))) *)( \
+    (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TriArgs, field)))
+#endif
 template <int METHOD, int LOG_SLOTS, int NW, bool LS>
-__global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pair_tri(TriArgs A) {   // (128 slots: 8 waves per SIMD fit, keep the SGPRs below the limit for that)
+#ifdef EXP_NOMINW
+#define PAIR_MINW 1
+#else
+#define PAIR_MINW ((LOG_SLOTS == 7 && !LS) ? 8 : 1)
+#endif
+__global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   // (128 slots: 8 waves per SIMD fit, keep the SGPRs below the limit for that)
     constexpr int SLOTS_ = 1 << LOG_SLOTS;
     constexpr bool ADJ = METHOD == XMAP_ADJUST_COSINE;
     using RT = typename std::conditional<LS, double, float>::type;      // rating type of the profile copy and the rater records
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
     const int i = uniform(A.uq_item[unit]);
     const int4 ud = ((const int4 *)A.uq_q)[unit];
     const int q = uniform(ud.x), p0 = uniform(ud.y), p1 = uniform(ud.z), Qi = uniform(ud.w);
-    const int w = threadIdx.x >> 6;
+    const int w = uniform((int)(threadIdx.x >> 6));      // (a scalar: the block loop of the walk is a scalar loop)
     for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
         key[s] = T_EMPTY; cm[s] = (CM)0; dot[s] = 0.0;
         if (ADJ) dlo[s] = 0.0;
@@ -540,17 +555,23 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
 #endif
     constexpr int RB = (NW == 1 || NW == 16) ? 64 : EXP_RB;
     constexpr int WU = EXP_WU;
-    auto rater = [&](int p, int &e0, int &pw, RT &r, int &usr) {
-        e0 = 0; pw = 0; r = (RT)0; usr = -1;
-        if (lane < RB && p < p1) {
-            if (LS) {       // fp64 ratings, user average 0 by construction
-                const RaterRecWide rr = ((const RaterRecWide *)A.rc)[p];
-                e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating;
-            } else {
-                const RaterRec rr = A.rc[p];
-                e0 = rr.e0; pw = rr.pos_ge; r = (RT)rr.rating; usr = rr.user;
-            }
+    // Loads of the walk: every one is unconditional (a clamped index for a lane that has nothing to load) and nothing is
+    // done with a loaded value before the loads that can go out with it are out -- a load under `if (act)`, or a select on a
+    // freshly prefetched record, is waited for on the spot, which had put a block's record prefetch, the user averages and the
+    // two rounds' entries one round trip after the other.  The user average is read per co-rating next to the profile entry
+    // (the lanes of one rater read one address), not per rater ahead of the rounds.
+    struct RawRec { int e0, pw, usr; RT r; };
+    auto rater = [&](int p) {
+        const int pc = (lane < RB && p < p1) ? p : p0;
+        RawRec o;
+        if (LS) {       // fp64 ratings, user average 0 by construction
+            const RaterRecWide rr = ((const RaterRecWide *)A.rc)[pc];
+            o.e0 = rr.e0; o.pw = rr.pos_ge; o.r = (RT)rr.rating; o.usr = 0;
+        } else {
+            const RaterRec rr = A.rc[pc];
+            o.e0 = rr.e0; o.pw = rr.pos_ge; o.r = (RT)rr.rating; o.usr = rr.user;
         }
+        return o;
     };
     auto entry = [&](int e, int &jw_, RT &rj_) {        // one entry of a sorted profile
         if (LS) { const UbWide v = ((const UbWide *)A.ub)[e]; jw_ = v.item_ge; rj_ = (RT)v.rating; }
@@ -559,17 +580,14 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
     auto walk = [&](auto &&body) {
         int base = p0 + RB * w;
         if (base >= p1) return;
-        int e0, pw, usr, ne0 = 0, npw = 0, nusr = -1;
-        RT r, nr_ = (RT)0;
-        rater(base + lane, e0, pw, r, usr);
+        RawRec cur = rater(base + lane);
         for (; base < p1; base += RB * NW) {
-            const bool more = base + RB * NW < p1;            // this wave's next block: its records are loaded now
-            if (more) rater(base + RB * NW + lane, ne0, npw, nr_, nusr);
-            double au = 0.0;
-#ifndef EXP_NOUAVG
-            if (ADJ && !LS && usr >= 0) au = A.u_avg[usr];
-#endif
-            const int len = pw & 0x7fffffff;                  // the rater's prefix: entries [e0, e0 + len) of its profile
+            RawRec nxt = cur;
+            if (base + RB * NW < p1) nxt = rater(base + RB * NW + lane);      // this wave's next block (a scalar branch)
+            const bool ok = lane < RB && base + lane < p1;
+            const int e0 = cur.e0, pw = cur.pw, usr = cur.usr;
+            const RT r = cur.r;
+            const int len = ok ? (pw & 0x7fffffff) : 0;       // the rater's prefix: entries [e0, e0 + len) of its profile
             int end = len;
 #pragma unroll
             for (int d = 1; d < RB; d <<= 1) { const int v = __shfl_up(end, d, 64); if (lane >= d) end += v; }
@@ -580,31 +598,43 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
 #endif
             for (int f0 = 0; f0 < total; f0 += 64 * WU) {
                 int jw[WU]; RT rj[WU]; bool act[WU]; double ri[WU], a[WU]; unsigned gei[WU];
+                int tt[WU], ee[WU], uu[WU];
 #pragma unroll
                 for (int u = 0; u < WU; u++) {
-                    jw[u] = 0; rj[u] = (RT)0; act[u] = false; ri[u] = 0.0; a[u] = 0.0; gei[u] = 0u;
-                    if (u && f0 + u * 64 >= total) continue;  // (uniform)
                     const int f = f0 + u * 64 + lane;
                     act[u] = f < total;
                     int t = 0;                                // the rater of co-rating f: #{k : end[k] <= f}
 #pragma unroll
                     for (int step = RB / 2; step >= 1; step >>= 1) { const int v = __shfl(end, t + step - 1, 64); if (v <= f) t += step; }
-                    const int eb = __shfl(e0, t, 64), sb = __shfl(start, t, 64), pwt = __shfl(pw, t, 64);
-                    if (act[u]) entry(eb + (f - sb), jw[u], rj[u]);
-                    ri[u] = (double)__shfl(r, t, 64);
-                    if (ADJ) a[u] = __shfl(au, t, 64);
+                    const int eb = __shfl(e0, t, 64), sb = __shfl(start, t, 64), ut = __shfl(usr, t, 64);
+                    tt[u] = t;
+                    ee[u] = act[u] ? eb + (f - sb) : 0;
+                    uu[u] = act[u] ? ut : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < WU; u++) {
+                    entry(ee[u], jw[u], rj[u]);
+                    a[u] = 0.0;
+#ifndef EXP_NOUAVG
+                    if (ADJ && !LS) a[u] = A.u_avg[uu[u]];
+#endif
+                }
+#pragma unroll
+                for (int u = 0; u < WU; u++) {
+                    const int pwt = __shfl(pw, tt[u], 64);
+                    ri[u] = (double)__shfl(r, tt[u], 64);
                     gei[u] = ((unsigned)pwt) >> 31;
                 }
 #pragma unroll
                 for (int u = 0; u < WU; u++) {
-                    if (u && f0 + u * 64 >= total) continue;
+                    if (u && f0 + u * 64 >= total) continue;  // (uniform)
                     const int j = jw[u] & 0x7fffffff;
                     bool ac = act[u];
                     if (ac && Qi > 1) ac = (int)__umulhi(mix32((uint32_t)j), (uint32_t)Qi) == q;
                     body(ac, j, jw[u], rj[u], ri[u], a[u], gei[u]);
                 }
             }
-            e0 = ne0; pw = npw; r = nr_; usr = nusr;
+            cur = nxt;
         }
     };
 
@@ -630,10 +660,14 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
             const double term = (ri - a) * ((double)rj - a);
             // volatile: the sums are shared between lanes (and waves); the compiler must neither forward the
             // claim / lock store to the load nor hoist the sum loads out of the loop
-            volatile double *vhi = dot, *vlo = dlo;
+            // (LDS-qualified: through a generic volatile pointer these become flat_load / flat_store, which also count on
+            // vmcnt -- every turn then waited for the prefix loads in flight as well)
+            typedef __attribute__((address_space(3))) volatile double lds_vf64;
+            typedef __attribute__((address_space(3))) volatile unsigned short lds_vu16;
+            lds_vf64 *vhi = (lds_vf64 *)dot, *vlo = (lds_vf64 *)dlo;
             bool pending = act;
             if (NW == 1) {
-                volatile unsigned short *vclaim = claim;
+                lds_vu16 *vclaim = (lds_vu16 *)claim;
                 while (__ballot(pending)) {       // lanes that share a slot take turns
                     if (pending) vclaim[h] = (unsigned short)lane;
                     if (pending && vclaim[h] == (unsigned short)lane) {
@@ -724,6 +758,24 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
     // finalisation: this wave's share of the slots stays in registers (NIT rounds of 64); the norm and the heavy id of
     // every partner are gathered in one go (round 2: norm gather -> cursor atomic -> heavy-id gather, three dependent round
     // trips and the slots read twice from LDS), then one returning atomic on the shard cursor, then the stores
+    // (the argument fields of this part: see KARG)
+    const auto k_coo_i = KARG(coo_i);
+    const auto k_coo_j = KARG(coo_j);
+    const auto k_coo_sim = KARG(coo_sim);
+    const auto k_coo_mutu = KARG(coo_mutu);
+    const auto k_coo_nij = KARG(coo_nij);
+    const auto k_coo_aux = KARG(coo_aux);
+    const auto k_hid = KARG(hid);
+    const auto k_nrm = KARG(nrm);
+    const auto k_rowcnt = KARG(rowcnt);
+    const auto k_mircnt = KARG(mircnt);
+    const auto k_rowcnt_h = KARG(rowcnt_h);
+    const auto k_shard_cur = KARG(shard_cur);
+    const auto k_shard_occ = KARG(shard_occ);
+    const auto k_shard_cap = KARG(shard_cap);
+    const auto k_cap = KARG(cap);
+    const auto k_raw = KARG(raw);
+    const auto k_counters = KARG(counters);
     constexpr int NIT = SLOTS_ / NW / 64;
     const int sb0 = w * (SLOTS_ / NW);
     int fj[NIT], fn[NIT], fm[NIT], fh[NIT];
@@ -738,16 +790,16 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
         const CM c = cm[sl];
         fn[t] = (int)(c & NMASK); fm[t] = (int)(c >> MSH);
         fs[t] = dot[sl];
-        fa[t] = (ADJ && A.raw) ? dlo[sl] : 0.0;
+        fa[t] = (ADJ && k_raw) ? dlo[sl] : 0.0;
         fy[t] = 0.0; fh[t] = -1;
         if (fo[t]) {
 #ifdef EXP_NONRM
             fy[t] = nx;
 #else
-            if (!A.raw) fy[t] = A.nrm[kj];
+            if (!k_raw) fy[t] = k_nrm[kj];
 #endif
 #ifndef EXP_NOHID
-            fh[t] = A.hid[kj];
+            fh[t] = k_hid[kj];
 #endif
         }
     }
@@ -755,11 +807,11 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
 #pragma unroll
     for (int t = 0; t < NIT; t++) {
         bool keep = fo[t];
-        if (keep && !A.raw) {          // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207): finish_pair
+        if (keep && !k_raw) {          // cosine (:91-95), significance weighting (:84-89), zero filter (:198,:207): finish_pair
             const double np = nx * fy[t];
             const double cs = (np != 0.0) ? 1.0 * fs[t] / np : 0.0;
-            const int mn = fn[t] < A.cap ? fn[t] : A.cap;
-            fs[t] = 1.0 * cs * (double)mn / (double)A.cap;
+            const int mn = fn[t] < k_cap ? fn[t] : k_cap;
+            fs[t] = 1.0 * cs * (double)mn / (double)k_cap;
             keep = (fs[t] != 0.0) && (fm[t] != 0);
         }
         fk[t] = keep;
@@ -767,32 +819,32 @@ __global__ __launch_bounds__(64 * NW, (LOG_SLOTS == 7 && !LS) ? 8 : 1) void k_pa
         occ += __popcll(__ballot(fo[t]));
     }
     const int shard = (blockIdx.x * NW + w) & (COO_SHARDS - 1);
-    if (lane == 0 && occ) atomicAdd(&A.shard_occ[shard], (unsigned long long)occ);
+    if (lane == 0 && occ) atomicAdd(&k_shard_occ[shard], (unsigned long long)occ);
     if (!kept) return;
     unsigned long long cbase = 0;
     if (lane == 0) {
-        cbase = atomicAdd(&A.shard_cur[shard], (unsigned long long)kept);
-        atomicAdd(&A.rowcnt[i], kept);
+        cbase = atomicAdd(&k_shard_cur[shard], (unsigned long long)kept);
+        atomicAdd(&k_rowcnt[i], kept);
     }
     cbase = ((unsigned long long)(unsigned)rl32((int)(cbase >> 32), 0) << 32) | (unsigned)rl32((int)(cbase & 0xffffffffull), 0);
-    if ((long long)(cbase + kept) > A.shard_cap) {
-        if (lane == 0) atomicOr(&A.counters[3], 1ull);
+    if ((long long)(cbase + kept) > k_shard_cap) {
+        if (lane == 0) atomicOr(&k_counters[3], 1ull);
         return;
     }
-    cbase += (unsigned long long)shard * (unsigned long long)A.shard_cap;
+    cbase += (unsigned long long)shard * (unsigned long long)k_shard_cap;
 #pragma unroll
     for (int t = 0; t < NIT; t++) {
         const unsigned long long km = __ballot(fk[t]);
         if (fk[t]) {
             const long long pp = (long long)cbase + __popcll(km & lanemask_lt());
             const int j = fj[t];
-            A.coo_i[pp] = i; A.coo_j[pp] = j;
+            k_coo_i[pp] = i; k_coo_j[pp] = j;
 #ifndef EXP_NOCOO
-            A.coo_sim[pp] = fs[t]; A.coo_mutu[pp] = fm[t]; A.coo_nij[pp] = fn[t];
-            if (A.coo_aux) A.coo_aux[pp] = fa[t];
+            k_coo_sim[pp] = fs[t]; k_coo_mutu[pp] = fm[t]; k_coo_nij[pp] = fn[t];
+            if (k_coo_aux) k_coo_aux[pp] = fa[t];
 #endif
-            if (fh[t] >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + fh[t]], 1);
-            else atomicAdd(&(A.mircnt ? A.mircnt : A.rowcnt)[j], 1);
+            if (fh[t] >= 0) atomicAdd(&k_rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + fh[t]], 1);
+            else atomicAdd(&(k_mircnt ? k_mircnt : k_rowcnt)[j], 1);
         }
         cbase += __popcll(km);
     }
