@@ -1542,7 +1542,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
                 }
                 ent++;
             }
+#ifdef EXP_NOFIN     // (ablation, profiles/tools/a_variants.sh with FILE=stage_b: no finalisation -- wrong results, timing only)
+        if (row < 0) cand_total += W.nt;
+#else
         if (row < 0) cand_total += finalize_start(A, fin[threadIdx.x >> 6], W.acc, W.touched, W.nt, start);
+#endif
         else if (lane == 0) A.unit_nt[unit] = W.nt;
     }
     if (lane == 0) {
