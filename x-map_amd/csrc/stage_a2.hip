@@ -134,7 +134,7 @@ __device__ __forceinline__ void bitonic_desc(int width, int pos, unsigned long l
     }
 }
 
-constexpr int SORT_LDS = 1024;   // keys of a long profile staged in LDS (8 KB per wave)
+constexpr int SORT_LDS = 256;    // keys of a long profile staged in LDS (2 KB per wave: 8 KB per block leaves the kernel its full occupancy; 1024 had held it to 5 waves per SIMD for the sake of the few profiles of 257..1024 ratings, which now rank from the global scratch)
 
 __device__ __forceinline__ int pow2_at_least(int d) {
     int w = 2;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
                                                        const float *urating, const long long *iptr, const double *info,
                                                        unsigned long long *ub_key, int2 *ub) {
     __shared__ unsigned long long lkeys[4][SORT_LDS];
-    const long long u0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const long long u0 = ((long long)blockIdx.x * 4 + uniform((int)(threadIdx.x >> 6))) * 4;
     if (u0 >= U) return;
     const int lane = lane_id();
     const int g = lane >> 4, gl = lane & 15;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles(long long U, const long l
         }
         // longer than a wave: rank by counting.  The keys are staged in LDS
         // (or, past SORT_LDS of them, in the ub_key scratch) and every entry counts the heavier ones.
-        unsigned long long *keys = d <= SORT_LDS ? lkeys[threadIdx.x >> 6] : ub_key + a;
+        unsigned long long *keys = d <= SORT_LDS ? lkeys[uniform((int)(threadIdx.x >> 6))] : ub_key + a;
         for (int p = lane; p < d; p += 64) {
             unsigned long long key;
             int px, py;
@@ -374,7 +374,7 @@ template <typename Fin, typename Park, typename Get, typename Aux>
 __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begin, int n_slots, Fin fin, Park park, Get get,
                                              Aux aux) {
     const int lane = lane_id();
-    const int shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (COO_SHARDS - 1);
+    const int shard = (blockIdx.x * (blockDim.x >> 6) + uniform((int)(threadIdx.x >> 6))) & (COO_SHARDS - 1);
     int kept = 0, occ = 0;
     for (int s0 = s_begin; s0 < n_slots; s0 += 64) {
         int j, n, m; double sv; bool o;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   
     const int i = uniform(A.uq_item[unit]);
     const int4 ud = ((const int4 *)A.uq_q)[unit];
     const int q = uniform(ud.x), p0 = uniform(ud.y), p1 = uniform(ud.z), Qi = uniform(ud.w);
-    const int w = uniform((int)(threadIdx.x >> 6));      // (a scalar: the block loop of the walk is a scalar loop)
+    const int w = uniform((int)uniform((int)(threadIdx.x >> 6)));      // (a scalar: the block loop of the walk is a scalar loop)
     for (int s = threadIdx.x; s < SLOTS_; s += 64 * NW) {
         key[s] = T_EMPTY; cm[s] = (CM)0; dot[s] = 0.0;
         if (ADJ) dlo[s] = 0.0;
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(64 * HEAVY_WAVES) void k_pair_heavy(TriArgs A) {
     __shared__ double dot[HMAX];
     __shared__ double dlo[METHOD == XMAP_ADJUST_COSINE ? HMAX : 1];
     __shared__ unsigned lockw[METHOD == XMAP_ADJUST_COSINE ? HMAX : 1];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = uniform((int)(threadIdx.x >> 6));
     const int unit = blockIdx.x;
     for (int s = threadIdx.x; s < HMAX; s += 64 * HEAVY_WAVES) {
         cnt[s] = 0; mut[s] = 0; dot[s] = 0.0;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void k_heavy_merge(TriArgs A, int n_heavy) {
     }
     if (nc == 0) return;
     __syncthreads();
-    const int w = threadIdx.x >> 6;
+    const int w = uniform((int)(threadIdx.x >> 6));
     append_pairs(A, i, w * (HMAX / 4), (w + 1) * (HMAX / 4),
         [&](int s, int &j, int &n, int &m, double &sv, bool &o) {
             o = cnt[s] != 0;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void k_scatter(long long n, const int *coo_i, 
                                                  const long long *row_ptr, int *fill, int *col, double *sim, int *mutu,
                                                  int *nij, double *aux) {
     const int lane = lane_id();
-    const long long r0 = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 * SC_U) + lane;
+    const long long r0 = ((long long)blockIdx.x * (blockDim.x >> 6) + uniform((int)(threadIdx.x >> 6))) * (64 * SC_U) + lane;
     int i[SC_U], j[SC_U], m[SC_U], nn[SC_U];
     double s[SC_U], x[SC_U];
     bool valid[SC_U];
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles3(long long U, const long 
                                                         const double *ur64, const int *cnt, unsigned long long *ub_key,
                                                         void *ub, unsigned long long *srec) {
     __shared__ unsigned long long lkeys[4][SORT_LDS];
-    const long long u0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const long long u0 = ((long long)blockIdx.x * 4 + uniform((int)(threadIdx.x >> 6))) * 4;
     if (u0 >= U) return;
     const int lane = lane_id();
     const int g = lane >> 4, gl = lane & 15;
@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(256) void k_sort_profiles3(long long U, const long 
             if (lane < d) emit_entry3<WIDE>(a, d, lane, u, px, py, ub, srec);
             continue;
         }
-        unsigned long long *keys = d <= SORT_LDS ? lkeys[threadIdx.x >> 6] : ub_key + a;
+        unsigned long long *keys = d <= SORT_LDS ? lkeys[uniform((int)(threadIdx.x >> 6))] : ub_key + a;
         for (int p = lane; p < d; p += 64) {
             unsigned long long key;
             int px;
@@ -1443,7 +1443,7 @@ struct BigList {
 template <typename Src>
 __global__ __launch_bounds__(256) void k_item_stats3(int I, int lo, int hi, const long long *iptr, const Src src, double *info,
                                                      double *norms, BigList B) {
-    const int i0 = lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const int i0 = lo + (blockIdx.x * 4 + uniform((int)(threadIdx.x >> 6))) * 4;
     if (i0 >= hi) return;
     const int lane = lane_id();
     {
@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(256) void k_item_stats3(int I, int lo, int hi, cons
 // one wave per listed chunk: the item's partial sums over raters [c STAT_CHK, (c + 1) STAT_CHK)
 template <typename Src>
 __global__ __launch_bounds__(256) void k_item_chunks(const long long *iptr, const Src src, BigList B) {
-    const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned c = blockIdx.x * 4 + uniform((int)(threadIdx.x >> 6));
     if (c >= B.counters[0]) return;
     const int2 d = B.chunks[c];
     const int lane = lane_id();
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(64) void k_item_big(int I, BigList B, double *info,
 
 template <typename Src>
 __global__ __launch_bounds__(256) void k_item_big_flags(const long long *iptr, const Src src, BigList B, const double *info) {
-    const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned c = blockIdx.x * 4 + uniform((int)(threadIdx.x >> 6));
     if (c >= B.counters[0]) return;
     const int2 d = B.chunks[c];
     const double avg = info[(size_t)d.x * 4];
