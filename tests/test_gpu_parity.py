@@ -322,7 +322,40 @@ def test_keys_larger_than_a_tile(dev, method):
             os.environ.pop("XMAP_A_V2", None)
         else:
             os.environ["XMAP_A_V2"] = old
+    # the rater counts of large inputs come from the partitioned count (k_cb_*: bucket histogram, scatter, LDS windows),
+    # forced here on this input: the hub items are 8000 same-word increments of one window
+    os.environ["XMAP_COUNT_PART_MIN"] = "1"
+    try:
+        S = eng.item_sim_tri(method, CAP)
+        rows, cols, sim, mutu, nij = _sorted_sim(S)
+        assert np.array_equal(rows, orow) and np.array_equal(cols, ocol) and np.array_equal(sim, So.sim)
+        assert np.array_equal(S.info.cpu().numpy(), So.info)
+    finally:
+        os.environ.pop("XMAP_COUNT_PART_MIN", None)
     xo.sim_free(So)
+
+
+def test_partitioned_count_on_random_shapes(dev):
+    """xmap_sim3_layout's partitioned rater count (large inputs) forced on small random shapes, incl. fewer items than
+    buckets and items beyond a bucket boundary: stage A against the oracle, bit for bit."""
+    from oracle import xmap_oracle as xo
+    from xmap.engine import synth
+    os.environ["XMAP_COUNT_PART_MIN"] = "1"
+    try:
+        for seed, (U, Is, It) in enumerate(((300, 40, 50), (2500, 900, 700), (6000, 2100, 1900))):
+            r = synth.make_two_domain(100 + seed, U, Is, It, overlap=0.3)
+            attrs = r.item_attrs()
+            eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, attrs)
+            T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
+            So = xo.item_sim(T, "adjust_cosine", CAP, nthreads=8)
+            S = eng.item_sim_tri("adjust_cosine", CAP)
+            rows, cols, sim, mutu, nij = _sorted_sim(S)
+            orow, ocol = csr_to_pairs(So.row_ptr, So.col)
+            assert np.array_equal(rows, orow) and np.array_equal(cols, ocol) and np.array_equal(sim, So.sim)
+            assert np.array_equal(S.info.cpu().numpy(), So.info)
+            xo.sim_free(So)
+    finally:
+        os.environ.pop("XMAP_COUNT_PART_MIN", None)
 
 
 def test_middle_lists_in_column_ranges(dev, monkeypatch):

@@ -1212,6 +1212,100 @@ __global__ __launch_bounds__(256) void k_count3(long long nnz, const int *uitem,
         if (loc[t]) atomicAdd(&cnt[tag[t]], loc[t]);
 }
 
+// The same counts for large inputs without a global atomic per rating (k_count3 issues ~0.9 per rating whatever its LDS cache
+// catches: a chunk of 8192 ratings holds ~7000 different items; 9.7e6 device-scope atomics are 0.37 ms at BASELINE configs[1]).
+// The item column is first partitioned into <= 1024 buckets of 2^sh consecutive items -- bucket histogram, scan, scatter with
+// one reservation per (workgroup, bucket) -- and then counted slice by slice of the partitioned column in an LDS window of
+// CB_WIN items anchored at the slice's first bucket: a slice of 8192 entries lies in one or two buckets, so its counts leave
+// as one atomic per item it holds (~3e6 atomics in all, three coalesced passes over 39 MB).
+constexpr int CB_MAX = 1024;          // buckets
+constexpr int CB_CHUNK = 8192;        // entries per workgroup of the histogram / scatter / count passes
+constexpr int CB_WIN = 8192;          // items of the count pass's LDS window
+
+__global__ __launch_bounds__(256) void k_cb_hist(long long nnz, const int *uitem, int sh, unsigned *bcnt) {
+    __shared__ unsigned h[CB_MAX];
+    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
+    __syncthreads();
+    const long long e0 = (long long)blockIdx.x * CB_CHUNK;
+#pragma unroll 4
+    for (int q = threadIdx.x; q < CB_CHUNK; q += 256) {
+        const long long e = e0 + q;
+        if (e < nnz) atomicAdd(&h[uitem[e] >> sh], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CB_MAX; t += 256)
+        if (h[t]) atomicAdd(&bcnt[t], h[t]);
+}
+
+// exclusive scan of the bucket counts (one workgroup of CB_MAX threads); clears the scatter cursors
+__global__ __launch_bounds__(CB_MAX) void k_cb_scan(const unsigned *bcnt, long long *bptr, unsigned *bcur) {
+    __shared__ long long ws[CB_MAX / 64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long c = bcnt[t];
+    long long inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
+    long long base = 0;
+    for (int x = 0; x < w; x++) base += ws[x];
+    bptr[t] = base + inc - c;
+    if (t == CB_MAX - 1) bptr[CB_MAX] = base + inc;
+    bcur[t] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_cb_scatter(long long nnz, const int *uitem, int sh, const long long *bptr, unsigned *bcur,
+                                                    int *out) {
+    __shared__ unsigned h[CB_MAX];
+    __shared__ long long base[CB_MAX];
+    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
+    __syncthreads();
+    constexpr int EPT = CB_CHUNK / 256;
+    const long long e0 = (long long)blockIdx.x * CB_CHUNK;
+    int it[EPT];
+    unsigned rk[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        const long long e = e0 + r * 256 + threadIdx.x;
+        it[r] = e < nnz ? uitem[e] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; r++) rk[r] = it[r] >= 0 ? atomicAdd(&h[it[r] >> sh], 1u) : 0u;
+    __syncthreads();
+    for (int t = threadIdx.x; t < CB_MAX; t += 256)
+        if (h[t]) base[t] = bptr[t] + (long long)atomicAdd(&bcur[t], h[t]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EPT; r++)
+        if (it[r] >= 0) out[base[it[r] >> sh] + rk[r]] = it[r];
+}
+
+__global__ __launch_bounds__(256) void k_cb_count(long long nnz, const int *part, int sh, const long long *bptr, int n_items, int *cnt) {
+    __shared__ unsigned win[CB_WIN];
+    __shared__ int s_b;
+    const long long p0 = (long long)blockIdx.x * CB_CHUNK;
+    if (p0 >= nnz) return;
+    if (threadIdx.x == 0) {       // the bucket that holds position p0: the last b with bptr[b] <= p0
+        int lo = 0, hi = CB_MAX;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bptr[mid] <= p0) lo = mid; else hi = mid; }
+        s_b = lo;
+    }
+    for (int t = threadIdx.x; t < CB_WIN; t += 256) win[t] = 0u;
+    __syncthreads();
+    const int item0 = s_b << sh;
+#pragma unroll 4
+    for (int q = threadIdx.x; q < CB_CHUNK; q += 256) {
+        const long long p = p0 + q;
+        if (p >= nnz) break;
+        const int it = part[p];
+        const unsigned d = (unsigned)(it - item0);
+        if (d < (unsigned)CB_WIN) atomicAdd(&win[d], 1u); else atomicAdd(&cnt[it], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CB_WIN; t += 256)
+        if (win[t] && item0 + t < n_items) atomicAdd(&cnt[item0 + t], (int)win[t]);
+}
+
 // Sort records (tilesort.h: key = low 32 bits of word 0).  Narrow (float ratings): {item, pos | flag << 31, rating bits,
 // user}.  Wide (fp64 ratings -- RecommenderSim over AlterEgo means, core/recommenderSim.py:64-133 takes np.float64): {item,
 // pos | flag, rating (8 B), user, -}.
@@ -1582,7 +1676,7 @@ __global__ __launch_bounds__(256) void k_row_totals(int I, const int *own, const
 // COO and share the lighter item i -- one cursor bump per run, coalesced writes, the chunk still in the caches.
 // AUX: a sixth COO column travels along (RecommenderSim: the pair's local sensitivity; 32-byte records), and a row may pair
 // with itself -- such a record has an own entry and no mirrored one (k_ts_bin does not route it)
-template <bool AUX>
+template <bool AUX, bool SHARE>      // SHARE: only the rows [row_lo, row_hi) are built
 struct CooLoaderT {
     static constexpr int RW = AUX ? 4 : 3;
     const int *__restrict__ coo_i; const int *__restrict__ coo_j; const double *__restrict__ coo_sim;
@@ -1604,7 +1698,7 @@ struct CooLoaderT {
     }
     __device__ __forceinline__ bool keep(const unsigned long long (&w)[RW]) const {
         const int j = (int)(unsigned)w[0];
-        return (!AUX || j != (int)(w[0] >> 32)) && j >= row_lo && j < row_hi;
+        return (!AUX || j != (int)(w[0] >> 32)) && (!SHARE || (j >= row_lo && j < row_hi));
     }
     // own half of the chunk: for a fixed r the lanes of a wave hold consecutive COO slots
     __device__ __forceinline__ void extra(long long, const unsigned long long (&w)[ts::Chunk<RW>::EPT][RW],
@@ -1616,7 +1710,7 @@ struct CooLoaderT {
 #pragma unroll
         for (int r = 0; r < E; r++) {
             const int iw = (int)(w[r][0] >> 32);
-            const bool mine = on[r] && iw >= row_lo && iw < row_hi;
+            const bool mine = on[r] && (!SHARE || (iw >= row_lo && iw < row_hi));
             const int iu = mine ? iw : -1 - lane;                           // inactive lanes: unique fake rows
             const int prev = __shfl_up(iu, 1, 64);
             const bool leader = (lane == 0) || (prev != iu);
@@ -1818,16 +1912,16 @@ int ts_prepare(hipStream_t st, ts::Geo &G, const long long *ptr) {
 }  // namespace
 
 namespace {
-template <bool AUX>
+template <bool AUX, bool SHARE>
 int mirror_levels(hipStream_t st, const ts::Geo &G, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j, const double *coo_sim,
                   const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_aux, const longlong2 *chunks, const unsigned *n_chunks,
                   long long chunk_cap, int64_t n_pairs, const int32_t *own, const int64_t *row_ptr, int32_t *fill, void *bufA, void *bufB,
                   int32_t *col, double *sim, int32_t *mutu, int32_t *nij, double *aux, int row_lo, int row_hi) {
     constexpr int RW = AUX ? 4 : 3;
-    CooLoaderT<AUX> LA{coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, (const long long *)row_ptr, fill,
-                       col, sim, mutu, nij, aux, row_lo, row_hi};
+    CooLoaderT<AUX, SHARE> LA{coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, (const long long *)row_ptr, fill,
+                              col, sim, mutu, nij, aux, row_lo, row_hi};
     ts::RecLoader<RW> LB{(const unsigned long long *)bufA};
-    ts::k_ts_bin<RW, false, CooLoaderT<AUX>><<<dim3((unsigned)chunk_cap), dim3(ts::BT), 0, st>>>(G, LA, coo_cap, (unsigned long long *)bufA);
+    ts::k_ts_bin<RW, false, CooLoaderT<AUX, SHARE>><<<dim3((unsigned)chunk_cap), dim3(ts::BT), 0, st>>>(G, LA, coo_cap, (unsigned long long *)bufA);
     XM_LAUNCH_CHECK();
     ts::k_ts_bin<RW, true, ts::RecLoader<RW>><<<dim3((unsigned)G.clist_cap), dim3(ts::BT), 0, st>>>(G, LB, n_pairs, (unsigned long long *)bufB);
     XM_LAUNCH_CHECK();
@@ -2269,7 +2363,27 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
     if (phases & 1) {
     // raters per item -> item_ptr
     XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * In, st));
-    if (nnz > 0) {
+    const char *cb_env = getenv("XMAP_COUNT_PART_MIN");          // (tests force the partitioned count on small inputs)
+    const long long cb_min = cb_env ? atoll(cb_env) : 2000000ll;
+    if (nnz >= cb_min && I > 0) {         // partitioned count (k_cb_*): the item column through bufA (free until the tile sort)
+        int sh = 0;
+        while (((long long)(I - 1) >> sh) >= CB_MAX) sh++;
+        unsigned *bcnt = nullptr, *bcur = nullptr;
+        long long *bptr = nullptr;
+        XM_HIP(xm_malloc_async((void **)&bcnt, sizeof(unsigned) * CB_MAX, st));
+        XM_HIP(xm_malloc_async((void **)&bcur, sizeof(unsigned) * CB_MAX, st));
+        XM_HIP(xm_malloc_async((void **)&bptr, sizeof(long long) * (CB_MAX + 1), st));
+        XM_HIP(hipMemsetAsync(bcnt, 0, sizeof(unsigned) * CB_MAX, st));
+        const dim3 g((unsigned)((nnz + CB_CHUNK - 1) / CB_CHUNK));
+        k_cb_hist<<<g, dim3(256), 0, st>>>(nnz, R->user_item, sh, bcnt);
+        XM_LAUNCH_CHECK();
+        k_cb_scan<<<dim3(1), dim3(CB_MAX), 0, st>>>(bcnt, bptr, bcur);
+        XM_LAUNCH_CHECK();
+        k_cb_scatter<<<g, dim3(256), 0, st>>>(nnz, R->user_item, sh, bptr, bcur, (int *)bufA);
+        XM_LAUNCH_CHECK();
+        k_cb_count<<<g, dim3(256), 0, st>>>(nnz, (const int *)bufA, sh, bptr, I, cnt);
+        XM_LAUNCH_CHECK();
+    } else if (nnz > 0) {
         k_count3<<<dim3((unsigned)((nnz + CNT_CHUNK - 1) / CNT_CHUNK)), dim3(256), 0, st>>>(nnz, R->user_item, cnt);
         XM_LAUNCH_CHECK();
     }
@@ -2438,10 +2552,11 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
     k_coo_chunks<<<dim3((unsigned)((n_shards + 255) / 256)), dim3(256), 0, st>>>(n_shards, shard_cap, (const unsigned long long *)d_shards,
                                                                                  n_pairs, chunks, n_chunks, chunk_cap);
     XM_LAUNCH_CHECK();
-    if (coo_aux)
-        return mirror_levels<true>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, coo_aux, chunks, n_chunks, chunk_cap, n_pairs, own,
-                                   row_ptr, fill, bufA, bufB, col, sim, mutu, nij, aux, row_lo, row_hi);
-    return mirror_levels<false>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, chunks, n_chunks, chunk_cap, n_pairs, own,
-                                row_ptr, fill, bufA, bufB, col, sim, mutu, nij, nullptr, row_lo, row_hi);
+    const bool share = row_lo > 0 || row_hi < I;
+#define XM_MIRROR(AUX_, SHARE_, CA_, A_) mirror_levels<AUX_, SHARE_>(st, G, coo_cap, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, CA_, chunks, n_chunks, \
+        chunk_cap, n_pairs, own, row_ptr, fill, bufA, bufB, col, sim, mutu, nij, A_, row_lo, row_hi)
+    if (coo_aux) return share ? XM_MIRROR(true, true, coo_aux, aux) : XM_MIRROR(true, false, coo_aux, aux);
+    return share ? XM_MIRROR(false, true, nullptr, nullptr) : XM_MIRROR(false, false, nullptr, nullptr);
+#undef XM_MIRROR
 }
 }
