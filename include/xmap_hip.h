@@ -137,7 +137,9 @@ int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, con
  *            of class rank 0..4, light units} (cls_ptr of xmap_sim2_pairs = h_counts + 2).
  *   pairs  : phases bit 8 = reset counters/rowcnt, 1 = k_pair_heavy (chunk partials of the rows of H), 2 = k_pair_tri
  *            (light units [unit_lo, unit_hi), one launch per table class; 16 / 4 / 2 waves share a 1024 / 1024 / 512-slot table),
- *            4 = k_heavy_merge, 16 = fold the heavy items' row-count replicas (last); with 1 | 2 | 4 in one call the
+ *            4 = k_heavy_merge, 16 = (last; mircnt == NULL only) the mirrored row counts rowcnt[j]++ from the COO's partner
+ *            column, 128 = with 8: do not mark the unused COO entries (a caller that reads the COO through the shard
+ *            cursors only saves a 4 B x coo_cap fill); with 1 | 2 | 4 in one call the
  *            heavy rows (partials, then merge) run on a side stream next to the class launches of the light rows;
  *            kept pairs (i lighter, j heavier) ->
  *            half COO: coo_cap entries cut into 4096 shards with a cursor each (d_shards[0][s]; unused entries keep
@@ -175,8 +177,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     int64_t *d_counters /*[4]; [6] with phases bit 64: [4] / [5] = kept / evaluated unordered pairs, the sums
                                           of d_shards[0] / [1]*/,
                     int32_t *mircnt /*[I] or NULL.  NULL: rowcnt[i]++ / rowcnt[j]++ as described above.  Else rowcnt counts
-                                      the pairs a row computed itself and mircnt those computed in lighter rows (the row layout
-                                      of xmap_sim3_mirror)*/);
+                                      the pairs a row computed itself only and mircnt is cleared: the caller gets the mirrored
+                                      counts from xmap_sim3_mircount (the pair kernels issue no atomic per kept pair)*/);
 int xmap_sim2_scatter(void *stream, int32_t n_items, int64_t n_coo, const int32_t *coo_i, const int32_t *coo_j,
                       const double *coo_sim, const int32_t *coo_mutu, const int32_t *coo_nij, const double *coo_ls /*or NULL*/,
                       const int64_t *row_ptr, int32_t *fill /*[I] scratch*/, const int32_t *hid, const int32_t *hlist,
@@ -217,8 +219,14 @@ int xmap_sim3_plan(void *stream, const xmap_ratings *R, int32_t slot_target, con
                    const int32_t *ctl, int32_t *Q, int32_t *C, uint8_t *small, uint64_t *Wp, int32_t *Qcat /*[5 I]*/,
                    int64_t *uq_ptr /*[5 I + 1]*/, int64_t *uc_ptr /*[I + 1]*/, int32_t dups, int32_t *uq_item, int32_t *uq_q /*[4 cap_light]*/,
                    int32_t *uc_item, int32_t *uc_c, int64_t cap_light, int64_t cap_heavy, int64_t *h_out /*[10], host*/);
-/* The mirror of round 3.  xmap_sim2_pairs was given mircnt: own[i] = pairs row i computed (rowcnt), mir[j] = pairs computed
- * in lighter rows.  Row i of the CSR = [own | mirrored]: row_ptr = exclusive scan of own + mir; the own halves are written
+/* mir[j] = entries of a half COO whose second index is j, i.e. the mirrored entries row j gets (skip_self: an entry pairing a
+ * row with itself has none).  Three coalesced passes over the partner column (bucket histogram, scatter, LDS windows) instead
+ * of the device atomic per kept pair the pair kernels used to issue: those 2.65e7 atomics per pass were what the class
+ * launches waited for.  scratch: n_pairs ints.  d_shards as in xmap_sim3_mirror. */
+int xmap_sim3_mircount(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
+                       const int64_t *d_shards /*or NULL*/, int64_t n_pairs, int32_t skip_self, void *scratch, int32_t *mir /*[I] out*/);
+/* The mirror of round 3.  own[i] = pairs row i computed (xmap_sim2_pairs' rowcnt), mir[j] = pairs computed in lighter rows
+ * (xmap_sim3_mircount).  Row i of the CSR = [own | mirrored]: row_ptr = exclusive scan of own + mir; the own halves are written
  * in runs straight from the COO, the mirrored halves go through the tile sort keyed by the heavier item (positions mptr =
  * exclusive scan of mir).  n_pairs = valid COO entries.  coo_aux / aux (both or neither; RecommenderSim): a sixth column --
  * the pair's local sensitivity -- travels along (32-byte records), and a row may pair with itself: such an entry is an own

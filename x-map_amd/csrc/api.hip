@@ -293,7 +293,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
         // all phases in one call: the heavy rows run on a side stream next to the class launches of the light rows; own and
         // mirrored row counts apart (mir), kept / evaluated pairs summed on the device (phase 64)
         XM_TRY(xmap_sim2_pairs(c->st, &R, method, cap, c->u_avg, norms, rcrec, ub, Q, small, uq_item, uq_q, hc + 2, 0, n_light, hid, hlist,
-                               ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, 8 | 1 | 2 | 4 | 16 | 64, hp_hi, hp_lo, hp_cnt,
+                               ctl, Cc, uc_ptr, uc_item, uc_c, (int32_t)n_hu, n_heavy, 8 | 1 | 2 | 4 | 16 | 64 | 128, hp_hi, hp_lo, hp_cnt,
                                hp_mut, cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, nullptr, own, rowcnt_h, d_shards, d_cnt, mir));
         int64_t h_cnt[6];
         XM_TRY(d2h(h_cnt, d_cnt, 6, c->st));
@@ -322,6 +322,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     uint64_t *mir_a, *mir_b;
     XM_ALLOC(c->p_sim, col, kept); XM_ALLOC(c->p_sim, sim, kept); XM_ALLOC(c->p_sim, mutu, kept); XM_ALLOC(c->p_sim, nij, kept);
     T_ALLOC(fill, I); T_ALLOC(tot, I); T_ALLOC(mir_a, (size_t)3 * (n ? n : 1)); T_ALLOC(mir_b, (size_t)3 * (n ? n : 1));
+    XM_TRY(xmap_sim3_mircount(c->st, I, cap_coo, coo_i, coo_j, d_shards, n, 0, mir_a, mir));
     XM_TRY(xmap_sim3_mirror(c->st, I, cap_coo, coo_i, coo_j, coo_sim, coo_mutu, coo_nij, d_shards, n, own, mir, tot, row_ptr, mptr, fill,
                             mir_a, mir_b, col, sim, mutu, nij, nullptr, nullptr, 0, I));
     XM_HIP(hipStreamSynchronize(c->st));

@@ -407,14 +407,6 @@ __device__ __forceinline__ void append_pairs(const TriArgs &A, int i, int s_begi
             A.coo_sim[p] = sv; A.coo_mutu[p] = m; A.coo_nij[p] = n;
             if (A.coo_aux) A.coo_aux[p] = aux(s0 + lane);
 #endif
-#ifdef EXP_NOHID
-            const int hj = -1;
-#else
-            const int hj = A.hid[j];
-#endif
-            if (j == i) {}   // a row paired with itself (RecommenderSim) has no mirror entry
-            else if (hj >= 0) atomicAdd(&A.rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + hj], 1);
-            else atomicAdd(&(A.mircnt ? A.mircnt : A.rowcnt)[j], 1);
         }
         base += __popcll(km);
     }
@@ -755,9 +747,10 @@ __global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   
             [&](int s) { return __longlong_as_double((long long)s_ls[s]); });
         return;
     }
-    // finalisation: this wave's share of the slots stays in registers (NIT rounds of 64); the norm and the heavy id of
-    // every partner are gathered in one go (round 2: norm gather -> cursor atomic -> heavy-id gather, three dependent round
-    // trips and the slots read twice from LDS), then one returning atomic on the shard cursor, then the stores
+    // finalisation: this wave's share of the slots stays in registers (NIT rounds of 64); the norms of all partners are
+    // gathered in one go (round 2: norm gather -> cursor atomic -> heavy-id gather, three dependent round trips and the slots
+    // read twice from LDS), then one returning atomic on the shard cursor, then the stores.  The mirrored row counts are
+    // not taken here (one device atomic per kept pair): xmap_sim2_pairs counts them from the COO afterwards (k_cbs_*)
     // (the argument fields of this part: see KARG)
     const auto k_coo_i = KARG(coo_i);
     const auto k_coo_j = KARG(coo_j);
@@ -765,11 +758,8 @@ __global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   
     const auto k_coo_mutu = KARG(coo_mutu);
     const auto k_coo_nij = KARG(coo_nij);
     const auto k_coo_aux = KARG(coo_aux);
-    const auto k_hid = KARG(hid);
     const auto k_nrm = KARG(nrm);
     const auto k_rowcnt = KARG(rowcnt);
-    const auto k_mircnt = KARG(mircnt);
-    const auto k_rowcnt_h = KARG(rowcnt_h);
     const auto k_shard_cur = KARG(shard_cur);
     const auto k_shard_occ = KARG(shard_occ);
     const auto k_shard_cap = KARG(shard_cap);
@@ -778,7 +768,7 @@ __global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   
     const auto k_counters = KARG(counters);
     constexpr int NIT = SLOTS_ / NW / 64;
     const int sb0 = w * (SLOTS_ / NW);
-    int fj[NIT], fn[NIT], fm[NIT], fh[NIT];
+    int fj[NIT], fn[NIT], fm[NIT];
     double fs[NIT], fy[NIT], fa[NIT];
     bool fo[NIT], fk[NIT];
 #pragma unroll
@@ -791,16 +781,14 @@ __global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   
         fn[t] = (int)(c & NMASK); fm[t] = (int)(c >> MSH);
         fs[t] = dot[sl];
         fa[t] = (ADJ && k_raw) ? dlo[sl] : 0.0;
-        fy[t] = 0.0; fh[t] = -1;
+        fy[t] = 0.0;
         if (fo[t]) {
 #ifdef EXP_NONRM
             fy[t] = nx;
 #else
             if (!k_raw) fy[t] = k_nrm[kj];
 #endif
-#ifndef EXP_NOHID
-            fh[t] = k_hid[kj];
-#endif
+
         }
     }
     int kept = 0, occ = 0;
@@ -843,8 +831,6 @@ __global__ __launch_bounds__(64 * NW, PAIR_MINW) void k_pair_tri(TriArgs A) {   
             k_coo_sim[pp] = fs[t]; k_coo_mutu[pp] = fm[t]; k_coo_nij[pp] = fn[t];
             if (k_coo_aux) k_coo_aux[pp] = fa[t];
 #endif
-            if (fh[t] >= 0) atomicAdd(&k_rowcnt_h[(blockIdx.x & (HEAVY_SHARDS - 1)) * HMAX + fh[t]], 1);
-            else atomicAdd(&(k_mircnt ? k_mircnt : k_rowcnt)[j], 1);
         }
         cbase += __popcll(km);
     }
@@ -1283,6 +1269,7 @@ __global__ __launch_bounds__(256) void k_cb_scatter(long long nnz, const int *ui
 __global__ __launch_bounds__(256) void k_cb_count(long long nnz, const int *part, int sh, const long long *bptr, int n_items, int *cnt) {
     __shared__ unsigned win[CB_WIN];
     __shared__ int s_b;
+    if (nnz < 0) nnz = bptr[CB_MAX];       // (the partitioned column's length is only known on the device)
     const long long p0 = (long long)blockIdx.x * CB_CHUNK;
     if (p0 >= nnz) return;
     if (threadIdx.x == 0) {       // the bucket that holds position p0: the last b with bptr[b] <= p0
@@ -1304,6 +1291,68 @@ __global__ __launch_bounds__(256) void k_cb_count(long long nnz, const int *part
     __syncthreads();
     for (int t = threadIdx.x; t < CB_WIN; t += 256)
         if (win[t] && item0 + t < n_items) atomicAdd(&cnt[item0 + t], (int)win[t]);
+}
+
+// The same three passes over the partner column of the half COO (shard s = entries [s shard_cap, s shard_cap + cur[s])): the
+// mirrored row counts.  Round 2 / 3 counted them with one device-scope atomic per kept pair inside the pair kernels
+// (2.65e7 per pass at BASELINE configs[1], replicas for the heavy partners): taken out, the class launches are 31 % shorter
+// (2.77 -> 1.91 ms summed; profiles/r03e_pair_mirsep.txt) -- the atomics, not the walk, were what the kernels waited for.
+// SELF: an entry may pair a row with itself (RecommenderSim) and then has no mirrored entry.
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_cbs_hist(long long shard_cap, const unsigned long long *cur, const int *coo_i, const int *coo_j,
+                                                  int sh, unsigned *bcnt) {
+    const long long n = (cur && (long long)cur[blockIdx.x] < shard_cap) ? (long long)cur[blockIdx.x] : shard_cap;   // (no cursors: one range)
+    const long long e0 = (long long)blockIdx.y * CB_CHUNK;
+    if (e0 >= n) return;
+    __shared__ unsigned h[CB_MAX];
+    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
+    __syncthreads();
+    const long long b = (long long)blockIdx.x * shard_cap;
+#pragma unroll 4
+    for (int q = threadIdx.x; q < CB_CHUNK; q += 256) {
+        const long long e = e0 + q;
+        if (e < n) {
+            const int j = coo_j[b + e];
+            if (!SELF || j != coo_i[b + e]) atomicAdd(&h[j >> sh], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CB_MAX; t += 256)
+        if (h[t]) atomicAdd(&bcnt[t], h[t]);
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_cbs_scatter(long long shard_cap, const unsigned long long *cur, const int *coo_i, const int *coo_j,
+                                                     int sh, const long long *bptr, unsigned *bcur, int *out) {
+    const long long n = (cur && (long long)cur[blockIdx.x] < shard_cap) ? (long long)cur[blockIdx.x] : shard_cap;
+    const long long e0 = (long long)blockIdx.y * CB_CHUNK;
+    if (e0 >= n) return;
+    __shared__ unsigned h[CB_MAX];
+    __shared__ long long base[CB_MAX];
+    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
+    __syncthreads();
+    constexpr int EPT = CB_CHUNK / 256;
+    const long long b = (long long)blockIdx.x * shard_cap;
+    int it[EPT];
+    unsigned rk[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        const long long e = e0 + r * 256 + threadIdx.x;
+        it[r] = -1;
+        if (e < n) {
+            const int j = coo_j[b + e];
+            if (!SELF || j != coo_i[b + e]) it[r] = j;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; r++) rk[r] = it[r] >= 0 ? atomicAdd(&h[it[r] >> sh], 1u) : 0u;
+    __syncthreads();
+    for (int t = threadIdx.x; t < CB_MAX; t += 256)
+        if (h[t]) base[t] = bptr[t] + (long long)atomicAdd(&bcur[t], h[t]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EPT; r++)
+        if (it[r] >= 0) out[base[it[r] >> sh] + rk[r]] = it[r];
 }
 
 // Sort records (tilesort.h: key = low 32 bits of word 0).  Narrow (float ratings): {item, pos | flag << 31, rating bits,
@@ -1935,6 +1984,37 @@ int mirror_levels(hipStream_t st, const ts::Geo &G, int64_t coo_cap, const int32
 }
 }  // namespace
 
+namespace {
+// counts[j] += entries of the half COO whose partner (second index) is j -- the mirrored entries row j will get; self pairs
+// (skip_self) have none.  n_ranges ranges of range_cap slots, the first cur[r] of range r valid (cur == NULL: all of them).
+// part: range_cap * n_ranges ints of scratch.  Three passes (k_cbs_hist, k_cbs_scatter, k_cb_count), no atomic per entry.
+int mirror_counts(hipStream_t st, int n_items, long long range_cap, int n_ranges, const unsigned long long *cur, const int *coo_i,
+                  const int *coo_j, bool skip_self, int *part, int *counts) {
+    if (n_items <= 0 || range_cap <= 0 || n_ranges <= 0) return XMAP_OK;
+    int sh = 0;
+    while (((long long)(n_items - 1) >> sh) >= CB_MAX) sh++;
+    unsigned *bcnt = nullptr, *bcur = nullptr;
+    long long *bptr = nullptr;
+    XM_HIP(xm_malloc_async((void **)&bcnt, sizeof(unsigned) * CB_MAX, st));
+    XM_HIP(xm_malloc_async((void **)&bcur, sizeof(unsigned) * CB_MAX, st));
+    XM_HIP(xm_malloc_async((void **)&bptr, sizeof(long long) * (CB_MAX + 1), st));
+    XM_HIP(hipMemsetAsync(bcnt, 0, sizeof(unsigned) * CB_MAX, st));
+    const dim3 g((unsigned)n_ranges, (unsigned)((range_cap + CB_CHUNK - 1) / CB_CHUNK));
+    if (skip_self) k_cbs_hist<true><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bcnt);
+    else k_cbs_hist<false><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bcnt);
+    XM_LAUNCH_CHECK();
+    k_cb_scan<<<dim3(1), dim3(CB_MAX), 0, st>>>(bcnt, bptr, bcur);
+    XM_LAUNCH_CHECK();
+    if (skip_self) k_cbs_scatter<true><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bptr, bcur, part);
+    else k_cbs_scatter<false><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bptr, bcur, part);
+    XM_LAUNCH_CHECK();
+    const long long cap = range_cap * n_ranges;
+    k_cb_count<<<dim3((unsigned)((cap + CB_CHUNK - 1) / CB_CHUNK)), dim3(256), 0, st>>>(-1, part, sh, bptr, n_items, counts);
+    XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+}  // namespace
+
 extern "C" {
 #ifdef A_TRACE
 int xmap_debug_astamp(unsigned int *host, long long n_units) {
@@ -2104,6 +2184,7 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
                     int32_t *coo_j, double *coo_sim, int32_t *coo_mutu, int32_t *coo_nij, double *coo_ls /*or NULL*/,
                     int32_t *rowcnt, int32_t *rowcnt_h /*[64][1024]*/, int64_t *d_shards /*[2][4096]*/,
                     int64_t *d_counters /*[4]*/, int32_t *mircnt /*[I] or NULL*/) {
+    XM_SCOPE(stream);
     XM_ARG(R && u_avg && norms && rc && ub);
     XM_ARG(Q && small && uq_item && uq_q && cls_ptr && hid && hlist && ctl && C && uc_ptr && uc_item && uc_c);
     XM_ARG(coo_i && coo_j && coo_sim && coo_mutu && coo_nij && rowcnt && rowcnt_h && d_shards && d_counters);
@@ -2120,7 +2201,8 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
         XM_HIP(hipMemsetAsync(d_shards, 0, 2 * COO_SHARDS * sizeof(int64_t), st));
         XM_HIP(hipMemsetAsync(rowcnt_h, 0, sizeof(int32_t) * HEAVY_SHARDS * HMAX, st));
-        XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry
+        if (!(phases & 128)) XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry (bit 128: the
+                                                                    // caller reads the COO through the shard cursors only: 0.4 GB less to write)
         XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
         if (mircnt) XM_HIP(hipMemsetAsync(mircnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
     }
@@ -2214,9 +2296,14 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
         k_shard_sums<<<dim3(1), dim3(256), 0, st>>>((const unsigned long long *)d_shards, (unsigned long long *)d_counters);
         XM_LAUNCH_CHECK();
     }
-    if ((phases & 16) && n_heavy > 0) {   // fold the heavy items' count replicas into rowcnt
-        k_fold_heavy<<<dim3((unsigned)((n_heavy + 255) / 256)), dim3(256), 0, st>>>(n_heavy, hlist, rowcnt_h, mircnt ? mircnt : rowcnt);
-        XM_LAUNCH_CHECK();
+    if ((phases & 16) && !raw && !mircnt && R->n_items > 0) {
+        // the round-2 sequence / cross-checks (one combined count per row): the mirrored counts on top of the own ones, from
+        // the partner column of the COO.  The round-3 caller (mircnt given) counts in xmap_sim3_mircount, where it has scratch.
+        int *part = nullptr;
+        XM_HIP(xm_malloc_async((void **)&part, sizeof(int) * (size_t)coo_cap, st));
+        int rc16 = mirror_counts(st, R->n_items, coo_cap / COO_SHARDS, COO_SHARDS, (const unsigned long long *)d_shards, coo_i, coo_j,
+                                 coo_ls != nullptr, part, rowcnt);
+        if (rc16) return rc16;
     }
     return XMAP_OK;
 }
@@ -2510,6 +2597,21 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
         }
     }
     return XMAP_OK;
+}
+
+int xmap_sim3_mircount(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,
+                       const int64_t *d_shards, int64_t n_pairs, int32_t skip_self, void *scratch, int32_t *mir) {
+    XM_SCOPE(stream);
+    XM_ARG(coo_i && coo_j && scratch && mir && n_items >= 0 && coo_cap >= 0 && n_pairs >= 0);
+    XM_ARG(d_shards ? (coo_cap >= COO_SHARDS) : (n_pairs <= coo_cap));
+    hipStream_t st = (hipStream_t)stream;
+    if (n_items == 0) return XMAP_OK;
+    XM_HIP(hipMemsetAsync(mir, 0, sizeof(int32_t) * (size_t)n_items, st));
+    if (n_pairs == 0 || coo_cap == 0) return XMAP_OK;
+    if (d_shards)
+        return mirror_counts(st, n_items, coo_cap / COO_SHARDS, COO_SHARDS, (const unsigned long long *)d_shards, coo_i, coo_j,
+                             skip_self != 0, (int *)scratch, mir);
+    return mirror_counts(st, n_items, n_pairs, 1, nullptr, coo_i, coo_j, skip_self != 0, (int *)scratch, mir);
 }
 
 int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32_t *coo_i, const int32_t *coo_j,

@@ -434,12 +434,14 @@ class Engine(object):
         return L._heavy_half
 
     def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False,
-                  heavy_deal=None):
+                  heavy_deal=None, marks=True):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
         rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity).
         split: count a row's own pairs (rowcnt) and the pairs lighter rows computed for it (a 5th return value) apart --
         what tri_mirror takes.  heavy_deal = (rank, world): of the heavy rows only those with item index % world == rank
-        (item-sharded ranks deal them round-robin; chunk partials and merge of a row stay on one rank)."""
+        (item-sharded ranks deal them round-robin; chunk partials and merge of a row stay on one rank).  split: the mirrored
+        counts are NOT taken (the returned array is cleared): tri_mirror / mir_counts count them from the COO.  marks=False:
+        the unused COO entries are left unmarked (for a consumer that goes by the shard cursors: tri_mirror with shards)."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -470,7 +472,7 @@ class Engine(object):
             deal = 0 if heavy_deal is None else ((int(heavy_deal[1]) & 0xff) << 16) | ((int(heavy_deal[0]) & 0xff) << 8)
 
             def run(phases):
-                phases |= deal
+                phases |= deal | (0 if marks else 128)
                 check(lib.xmap_sim2_pairs(
                     st, C.byref(R.c), m, int(cap), vp(u_avg), vp(self.norms), vp(L.rc), vp(L.ub), vp(L.Q), vp(L.small),
                     vp(L.uq_item),
@@ -553,7 +555,7 @@ class Engine(object):
             coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
             S = self.tri_scatter(coo, rowcnt, info, n, L)
         else:
-            coo, own, n, n_unordered, mir, shards = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True, split=True)
+            coo, own, n, n_unordered, mir, shards = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True, split=True, marks=False)
             S = self.tri_mirror(coo, own, mir, info, n, shards)
         S.cap, S.n_unordered, S.layout = int(cap), n_unordered, L
         S.norm = self.norms[R.n_items:2 * R.n_items]
@@ -631,12 +633,20 @@ class Engine(object):
             L.finish = finish
         return (u_avg, u_norm, info, None, None), L
 
-    def tri_mirror(self, coo, own, mir, info, n, shards=None, rows=None):
+    def mir_counts(self, coo, n, mir, shards=None, skip_self=False):
+        """mir[j] = entries of the half COO (n valid ones) whose partner is j (xmap_sim3_mircount)"""
+        I = self.R.n_items
+        scratch = self._empty(max(int(n), 1), torch.int32)
+        check(lib.xmap_sim3_mircount(_stream(self.dev), i32(I), i64(int(coo[0].numel())), vp(coo[0].contiguous()), vp(coo[1].contiguous()),
+                                     vp(shards), i64(n), i32(1 if skip_self else 0), vp(scratch), vp(mir)))
+        return mir
+
+    def tri_mirror(self, coo, own, mir, info, n, shards=None, rows=None, counted=False):
         """round-3 mirror (xmap_sim3_mirror): a complete half COO with n valid entries, own[i] = pairs row i computed,
         mir[j] = pairs computed in lighter rows -> CSR, row = [own | mirrored].  shards: the cursors tri_pairs left (the
         COO is cut into 4096 shards filled from their start); None: the COO is one range of n records.  rows = (lo, hi):
         only these rows are built (the others stay empty) -- an item-sharded rank's share of the matrix, which is all its
-        knn and reverse-list shares read."""
+        knn and reverse-list shares read.  mir is filled here from the COO unless counted=True (mir_counts ran already)."""
         R = self.R
         st = _stream(self.dev)
         I = R.n_items
@@ -646,10 +656,12 @@ class Engine(object):
         kept = 2 * int(n)                                            # (an upper bound with self pairs: one entry each)
         lo, hi = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
         if rows is not None and I > 0:
-            own, mir = own.clone(), mir.clone()
-            for c_ in (own, mir):
-                c_[:lo].zero_(); c_[hi:].zero_()
-            kept = int((own[lo:hi].long().sum() + mir[lo:hi].long().sum()).item())
+            own = own.clone()
+            own[:lo].zero_(); own[hi:].zero_()
+            if counted:
+                mir = mir.clone()
+                mir[:lo].zero_(); mir[hi:].zero_()
+                kept = int((own[lo:hi].long().sum() + mir[lo:hi].long().sum()).item())
         rw = 4 if coo_ls is not None else 3
         row_ptr = self._out(I + 1, torch.int64, I > 0)
         mptr = self._empty(I + 1, torch.int64)
@@ -663,6 +675,12 @@ class Engine(object):
         nij = self._empty(max(kept, 1), torch.int32)
         ls = self._empty(max(kept, 1), torch.float64) if coo_ls is not None else None
         with self.timed("scatter"):
+            if not counted:
+                check(lib.xmap_sim3_mircount(st, i32(I), i64(cap), vp(coo_i), vp(coo_j), vp(shards), i64(n), i32(1 if coo_ls is not None else 0),
+                                             vp(buf_a), vp(mir)))
+                if rows is not None and I > 0:
+                    mir[:lo].zero_(); mir[hi:].zero_()
+                    kept = int((own[lo:hi].long().sum() + mir[lo:hi].long().sum()).item())
             check(lib.xmap_sim3_mirror(st, i32(I), i64(cap), vp(coo_i), vp(coo_j), vp(coo_sim), vp(coo_mutu), vp(coo_nij), vp(shards), i64(n),
                                        vp(own), vp(mir), vp(tot), vp(row_ptr), vp(mptr), vp(fill), vp(buf_a), vp(buf_b), vp(col),
                                        vp(sim), vp(mutu), vp(nij), vp(coo_ls), vp(ls), i32(lo), i32(hi)))
@@ -683,7 +701,7 @@ class Engine(object):
             S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
         else:
             stats, L = self.layout3(slot_target, ch_min)
-            coo, rowcnt, n, n_unordered, mir, shards = self.tri_pairs(method, cap, stats, L, split=True)
+            coo, rowcnt, n, n_unordered, mir, shards = self.tri_pairs(method, cap, stats, L, split=True, marks=False)
             S = self.tri_mirror(coo, rowcnt, mir, stats[2], n, shards)
         S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
         S.cap = int(cap)

@@ -67,7 +67,7 @@ EXPORTS = [
     "xmap_last_error", "xmap_version", "xmap_trim", "xmap_debug_arena", "xmap_debug_arena_call", "xmap_exclusive_scan_i64", "xmap_exclusive_scan_i32_to_i64",
     "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", "xmap_sim_plan", "xmap_sim_units", "xmap_sim_count",
     "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
-    "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_sim3_layout", "xmap_sim3_plan", "xmap_sim3_mirror", "xmap_item_partials", "xmap_item_merge", "xmap_sim2_pack_partials",
+    "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_sim3_layout", "xmap_sim3_plan", "xmap_sim3_mircount", "xmap_sim3_mirror", "xmap_item_partials", "xmap_item_merge", "xmap_sim2_pack_partials",
     "xmap_sim2_sort_partials", "xmap_sim2_merge_partials", "xmap_sim2_pack_pairs", "xmap_sim2_unpack_pairs", "xmap_bridge_flags", "xmap_knn_classify", "xmap_knn_thresholds", "xmap_reverse_count",
     "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", "xmap_mid_tally", "xmap_mid_place",
     "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_extend_paths2", "xmap_edge_ranges", "xmap_end_universe", "xmap_extend_cols", "xmap_nb_index", "xmap_path_plan", "xmap_end_order", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_predict", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",

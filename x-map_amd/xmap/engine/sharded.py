@@ -339,23 +339,23 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
         # records (i | j << 32, sim bits, mutu | n_ij << 32) -- and every rank mirrors the full COO into the CSR.
         split = isinstance(rowcnt, tuple)          # (own, mirrored) counts of the round-3 mirror, or one combined array
         with eng.timed("exchange"):
-            for c_ in (rowcnt if split else (rowcnt,)):
-                comm.all_reduce(c_)
+            comm.all_reduce(rowcnt[0] if split else rowcnt)                     # (own counts; the mirrored ones: below)
             rec = eng.pack_pairs(coo, n_local)                                  # library kernels, no torch arithmetic
             rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
             n_all = int(rec.shape[0])
             coo = eng.unpack_pairs(rec)
-            # the rows of the matrix this rank builds: its knn and reverse-list shares read nothing else (round 3: every rank
-            # mirrored the whole COO, 1.3 ms replicated)
-            share = None
-            if split and eng.R.n_items > 0:
-                cuts = eng.row_shares(rowcnt[0] + rowcnt[1], world)
-                share = (int(cuts[rank]), int(cuts[rank + 1]))
         # No collective sits between a possible raise and the agree() that follows it: the local phases run in try blocks,
         # the all-gathers of the knn tables (ext_gather) run outside any of them.
-        err, S, E, bb = None, None, None, None
+        err, S, E, bb, share = None, None, None, None, None
         try:
-            S = eng.tri_mirror(coo, rowcnt[0], rowcnt[1], info, n_all, rows=share) if split else eng.tri_scatter(coo, rowcnt, info, None, L)
+            if split and eng.R.n_items > 0:
+                # mirrored entries per row, counted from the gathered COO (the pair kernels take no such counts); then the rows
+                # of the matrix this rank builds: its knn and reverse-list shares read nothing else (every rank had mirrored
+                # the whole COO, 1.3 ms replicated)
+                eng.mir_counts(coo, n_all, rowcnt[1])
+                cuts = eng.row_shares(rowcnt[0] + rowcnt[1], world)
+                share = (int(cuts[rank]), int(cuts[rank + 1]))
+            S = eng.tri_mirror(coo, rowcnt[0], rowcnt[1], info, n_all, rows=share, counted=True) if split else eng.tri_scatter(coo, rowcnt, info, None, L)
             if share is not None:
                 bb = eng.bridge_flags(S).to(torch.int32)      # of this rank's rows; a list entry is classified by its
         except Exception as e:                                # NEIGHBOUR's flag, so the flags are completed first
