@@ -1207,21 +1207,8 @@ __global__ __launch_bounds__(256) void k_count3(long long nnz, const int *uitem,
 constexpr int CB_MAX = 1024;          // buckets
 constexpr int CB_CHUNK = 8192;        // entries per workgroup of the histogram / scatter / count passes
 constexpr int CB_WIN = 8192;          // items of the count pass's LDS window
-
-__global__ __launch_bounds__(256) void k_cb_hist(long long nnz, const int *uitem, int sh, unsigned *bcnt) {
-    __shared__ unsigned h[CB_MAX];
-    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
-    __syncthreads();
-    const long long e0 = (long long)blockIdx.x * CB_CHUNK;
-#pragma unroll 4
-    for (int q = threadIdx.x; q < CB_CHUNK; q += 256) {
-        const long long e = e0 + q;
-        if (e < nnz) atomicAdd(&h[uitem[e] >> sh], 1u);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < CB_MAX; t += 256)
-        if (h[t]) atomicAdd(&bcnt[t], h[t]);
-}
+constexpr int CB_SPB = 4;             // segments (chunks) per workgroup
+constexpr int CB_T = 1024;            // threads per workgroup of the three passes
 
 // exclusive scan of the bucket counts (one workgroup of CB_MAX threads); clears the scatter cursors
 __global__ __launch_bounds__(CB_MAX) void k_cb_scan(const unsigned *bcnt, long long *bptr, unsigned *bcur) {
@@ -1240,48 +1227,22 @@ __global__ __launch_bounds__(CB_MAX) void k_cb_scan(const unsigned *bcnt, long l
     bcur[t] = 0u;
 }
 
-__global__ __launch_bounds__(256) void k_cb_scatter(long long nnz, const int *uitem, int sh, const long long *bptr, unsigned *bcur,
-                                                    int *out) {
-    __shared__ unsigned h[CB_MAX];
-    __shared__ long long base[CB_MAX];
-    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
-    __syncthreads();
-    constexpr int EPT = CB_CHUNK / 256;
-    const long long e0 = (long long)blockIdx.x * CB_CHUNK;
-    int it[EPT];
-    unsigned rk[EPT];
-#pragma unroll
-    for (int r = 0; r < EPT; r++) {
-        const long long e = e0 + r * 256 + threadIdx.x;
-        it[r] = e < nnz ? uitem[e] : -1;
-    }
-#pragma unroll
-    for (int r = 0; r < EPT; r++) rk[r] = it[r] >= 0 ? atomicAdd(&h[it[r] >> sh], 1u) : 0u;
-    __syncthreads();
-    for (int t = threadIdx.x; t < CB_MAX; t += 256)
-        if (h[t]) base[t] = bptr[t] + (long long)atomicAdd(&bcur[t], h[t]);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < EPT; r++)
-        if (it[r] >= 0) out[base[it[r] >> sh] + rk[r]] = it[r];
-}
-
-__global__ __launch_bounds__(256) void k_cb_count(long long nnz, const int *part, int sh, const long long *bptr, int n_items, int *cnt) {
+__global__ __launch_bounds__(CB_T) void k_cb_count(long long nnz, const int *part, int sh, const long long *bptr, int n_items, int *cnt) {
     __shared__ unsigned win[CB_WIN];
     __shared__ int s_b;
     if (nnz < 0) nnz = bptr[CB_MAX];       // (the partitioned column's length is only known on the device)
-    const long long p0 = (long long)blockIdx.x * CB_CHUNK;
+    const long long p0 = (long long)blockIdx.x * (CB_CHUNK * CB_SPB);
     if (p0 >= nnz) return;
     if (threadIdx.x == 0) {       // the bucket that holds position p0: the last b with bptr[b] <= p0
         int lo = 0, hi = CB_MAX;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bptr[mid] <= p0) lo = mid; else hi = mid; }
         s_b = lo;
     }
-    for (int t = threadIdx.x; t < CB_WIN; t += 256) win[t] = 0u;
+    for (int t = threadIdx.x; t < CB_WIN; t += CB_T) win[t] = 0u;
     __syncthreads();
     const int item0 = s_b << sh;
 #pragma unroll 4
-    for (int q = threadIdx.x; q < CB_CHUNK; q += 256) {
+    for (int q = threadIdx.x; q < CB_CHUNK * CB_SPB; q += CB_T) {
         const long long p = p0 + q;
         if (p >= nnz) break;
         const int it = part[p];
@@ -1289,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_cb_count(long long nnz, const int *part
         if (d < (unsigned)CB_WIN) atomicAdd(&win[d], 1u); else atomicAdd(&cnt[it], 1);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < CB_WIN; t += 256)
+    for (int t = threadIdx.x; t < CB_WIN; t += CB_T)
         if (win[t] && item0 + t < n_items) atomicAdd(&cnt[item0 + t], (int)win[t]);
 }
 
@@ -1298,61 +1259,104 @@ __global__ __launch_bounds__(256) void k_cb_count(long long nnz, const int *part
 // (2.65e7 per pass at BASELINE configs[1], replicas for the heavy partners): taken out, the class launches are 31 % shorter
 // (2.77 -> 1.91 ms summed; profiles/r03e_pair_mirsep.txt) -- the atomics, not the walk, were what the kernels waited for.
 // SELF: an entry may pair a row with itself (RecommenderSim) and then has no mirrored entry.
+// A workgroup of 1024 threads takes CB_SPB segments (a segment = chunk c of range r, listed chunk-major: with a sharded COO
+// consecutive segments are the same chunk of consecutive shards, each a quarter full) into ONE LDS histogram: the global
+// atomics of these passes are one per (workgroup, bucket), so the more entries a workgroup holds the fewer there are.
 template <bool SELF>
-__global__ __launch_bounds__(256) void k_cbs_hist(long long shard_cap, const unsigned long long *cur, const int *coo_i, const int *coo_j,
-                                                  int sh, unsigned *bcnt) {
-    const long long n = (cur && (long long)cur[blockIdx.x] < shard_cap) ? (long long)cur[blockIdx.x] : shard_cap;   // (no cursors: one range)
-    const long long e0 = (long long)blockIdx.y * CB_CHUNK;
-    if (e0 >= n) return;
+__global__ __launch_bounds__(CB_T) void k_cbs_hist(long long range_cap, int n_ranges, const unsigned long long *cur, const int *coo_i,
+                                                   const int *coo_j, int sh, unsigned *bcnt) {
     __shared__ unsigned h[CB_MAX];
-    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
+    for (int t = threadIdx.x; t < CB_MAX; t += CB_T) h[t] = 0u;
     __syncthreads();
-    const long long b = (long long)blockIdx.x * shard_cap;
-#pragma unroll 4
-    for (int q = threadIdx.x; q < CB_CHUNK; q += 256) {
-        const long long e = e0 + q;
-        if (e < n) {
-            const int j = coo_j[b + e];
-            if (!SELF || j != coo_i[b + e]) atomicAdd(&h[j >> sh], 1u);
+    const long long cpr = (range_cap + CB_CHUNK - 1) / CB_CHUNK;        // chunks per range
+#pragma unroll
+    for (int sg = 0; sg < CB_SPB; sg++) {
+        const long long g = (long long)blockIdx.x * CB_SPB + sg;
+        const long long c = g / n_ranges;
+        const int r = (int)(g - c * n_ranges);
+        if (c >= cpr) break;
+        const long long n = (cur && (long long)cur[r] < range_cap) ? (long long)cur[r] : range_cap;       // (no cursors: all valid)
+        const long long b = (long long)r * range_cap;
+#pragma unroll
+        for (int q = 0; q < CB_CHUNK / CB_T; q++) {
+            const long long e = c * CB_CHUNK + q * CB_T + threadIdx.x;
+            if (e < n) {
+                const int j = coo_j[b + e];
+                if (!SELF || j != coo_i[b + e]) atomicAdd(&h[j >> sh], 1u);
+            }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < CB_MAX; t += 256)
+    for (int t = threadIdx.x; t < CB_MAX; t += CB_T)
         if (h[t]) atomicAdd(&bcnt[t], h[t]);
 }
 
+// The workgroup's entries are staged in LDS in bucket order and leave as runs (consecutive lanes write consecutive words
+// of a bucket's range): written straight from the registers every lane hits another bucket, a 4-byte transaction each
+// (0.25 ms for the 2.65e7 partners of a pass against 0.06 ms for the histogram pass over the same data).
 template <bool SELF>
-__global__ __launch_bounds__(256) void k_cbs_scatter(long long shard_cap, const unsigned long long *cur, const int *coo_i, const int *coo_j,
-                                                     int sh, const long long *bptr, unsigned *bcur, int *out) {
-    const long long n = (cur && (long long)cur[blockIdx.x] < shard_cap) ? (long long)cur[blockIdx.x] : shard_cap;
-    const long long e0 = (long long)blockIdx.y * CB_CHUNK;
-    if (e0 >= n) return;
-    __shared__ unsigned h[CB_MAX];
+__global__ __launch_bounds__(CB_T) void k_cbs_scatter(long long range_cap, int n_ranges, const unsigned long long *cur, const int *coo_i,
+                                                      const int *coo_j, int sh, const long long *bptr, unsigned *bcur, int *out) {
+    static_assert(CB_T == CB_MAX, "one thread per bucket in the scan");
+    __shared__ unsigned h[CB_MAX], off[CB_MAX + 1], wsum[CB_T / 64];
     __shared__ long long base[CB_MAX];
-    for (int t = threadIdx.x; t < CB_MAX; t += 256) h[t] = 0u;
+    __shared__ int stage[CB_CHUNK * CB_SPB];
+    const int tid = threadIdx.x;
+    h[tid] = 0u;
     __syncthreads();
-    constexpr int EPT = CB_CHUNK / 256;
-    const long long b = (long long)blockIdx.x * shard_cap;
-    int it[EPT];
-    unsigned rk[EPT];
+    constexpr int EPT = CB_CHUNK / CB_T;
+    const long long cpr = (range_cap + CB_CHUNK - 1) / CB_CHUNK;
+    int it[CB_SPB][EPT];
+    unsigned rk[CB_SPB][EPT];
 #pragma unroll
-    for (int r = 0; r < EPT; r++) {
-        const long long e = e0 + r * 256 + threadIdx.x;
-        it[r] = -1;
-        if (e < n) {
-            const int j = coo_j[b + e];
-            if (!SELF || j != coo_i[b + e]) it[r] = j;
+    for (int sg = 0; sg < CB_SPB; sg++) {
+        const long long g = (long long)blockIdx.x * CB_SPB + sg;
+        const long long c = g / n_ranges;
+        const int r = (int)(g - c * n_ranges);
+        const long long n = (c < cpr) ? ((cur && (long long)cur[r] < range_cap) ? (long long)cur[r] : range_cap) : 0;
+        const long long b = (long long)r * range_cap;
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const long long e = c * CB_CHUNK + q * CB_T + tid;
+            it[sg][q] = -1;
+            if (e < n) {
+                const int j = coo_j[b + e];
+                if (!SELF || j != coo_i[b + e]) it[sg][q] = j;
+            }
         }
     }
 #pragma unroll
-    for (int r = 0; r < EPT; r++) rk[r] = it[r] >= 0 ? atomicAdd(&h[it[r] >> sh], 1u) : 0u;
+    for (int sg = 0; sg < CB_SPB; sg++)
+#pragma unroll
+        for (int q = 0; q < EPT; q++) rk[sg][q] = it[sg][q] >= 0 ? atomicAdd(&h[it[sg][q] >> sh], 1u) : 0u;
     __syncthreads();
-    for (int t = threadIdx.x; t < CB_MAX; t += 256)
-        if (h[t]) base[t] = bptr[t] + (long long)atomicAdd(&bcur[t], h[t]);
+    {   // exclusive scan of the bucket counts (one bucket per thread), and the workgroup's place in every bucket's range
+        const unsigned c = h[tid];
+        const int lane = tid & 63, w = tid >> 6;
+        unsigned inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        unsigned bs = 0;
+        for (int x = 0; x < w; x++) bs += wsum[x];
+        off[tid] = bs + inc - c;
+        if (tid == CB_T - 1) off[CB_MAX] = bs + inc;
+        if (c) base[tid] = bptr[tid] + (long long)atomicAdd(&bcur[tid], c);
+    }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < EPT; r++)
-        if (it[r] >= 0) out[base[it[r] >> sh] + rk[r]] = it[r];
+    for (int sg = 0; sg < CB_SPB; sg++)
+#pragma unroll
+        for (int q = 0; q < EPT; q++)
+            if (it[sg][q] >= 0) stage[off[it[sg][q] >> sh] + rk[sg][q]] = it[sg][q];
+    __syncthreads();
+    const int total = (int)off[CB_MAX];
+    for (int x = tid; x < total; x += CB_T) {
+        const int v = stage[x];
+        const int bk = v >> sh;
+        out[base[bk] + (x - (int)off[bk])] = v;
+    }
 }
 
 // Sort records (tilesort.h: key = low 32 bits of word 0).  Narrow (float ratings): {item, pos | flag << 31, rating bits,
@@ -1999,17 +2003,19 @@ int mirror_counts(hipStream_t st, int n_items, long long range_cap, int n_ranges
     XM_HIP(xm_malloc_async((void **)&bcur, sizeof(unsigned) * CB_MAX, st));
     XM_HIP(xm_malloc_async((void **)&bptr, sizeof(long long) * (CB_MAX + 1), st));
     XM_HIP(hipMemsetAsync(bcnt, 0, sizeof(unsigned) * CB_MAX, st));
-    const dim3 g((unsigned)n_ranges, (unsigned)((range_cap + CB_CHUNK - 1) / CB_CHUNK));
-    if (skip_self) k_cbs_hist<true><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bcnt);
-    else k_cbs_hist<false><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bcnt);
+    const long long segs = (long long)n_ranges * ((range_cap + CB_CHUNK - 1) / CB_CHUNK);
+    const dim3 g((unsigned)((segs + CB_SPB - 1) / CB_SPB));
+    if (skip_self) k_cbs_hist<true><<<g, dim3(CB_T), 0, st>>>(range_cap, n_ranges, cur, coo_i, coo_j, sh, bcnt);
+    else k_cbs_hist<false><<<g, dim3(CB_T), 0, st>>>(range_cap, n_ranges, cur, coo_i, coo_j, sh, bcnt);
     XM_LAUNCH_CHECK();
     k_cb_scan<<<dim3(1), dim3(CB_MAX), 0, st>>>(bcnt, bptr, bcur);
     XM_LAUNCH_CHECK();
-    if (skip_self) k_cbs_scatter<true><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bptr, bcur, part);
-    else k_cbs_scatter<false><<<g, dim3(256), 0, st>>>(range_cap, cur, coo_i, coo_j, sh, bptr, bcur, part);
+    if (skip_self) k_cbs_scatter<true><<<g, dim3(CB_T), 0, st>>>(range_cap, n_ranges, cur, coo_i, coo_j, sh, bptr, bcur, part);
+    else k_cbs_scatter<false><<<g, dim3(CB_T), 0, st>>>(range_cap, n_ranges, cur, coo_i, coo_j, sh, bptr, bcur, part);
     XM_LAUNCH_CHECK();
     const long long cap = range_cap * n_ranges;
-    k_cb_count<<<dim3((unsigned)((cap + CB_CHUNK - 1) / CB_CHUNK)), dim3(256), 0, st>>>(-1, part, sh, bptr, n_items, counts);
+    k_cb_count<<<dim3((unsigned)((cap + (long long)CB_CHUNK * CB_SPB - 1) / ((long long)CB_CHUNK * CB_SPB))), dim3(CB_T), 0, st>>>(
+        -1, part, sh, bptr, n_items, counts);
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
@@ -2452,24 +2458,9 @@ int xmap_sim3_layout(void *stream, const xmap_ratings *R, int64_t *item_ptr, con
     XM_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * In, st));
     const char *cb_env = getenv("XMAP_COUNT_PART_MIN");          // (tests force the partitioned count on small inputs)
     const long long cb_min = cb_env ? atoll(cb_env) : 2000000ll;
-    if (nnz >= cb_min && I > 0) {         // partitioned count (k_cb_*): the item column through bufA (free until the tile sort)
-        int sh = 0;
-        while (((long long)(I - 1) >> sh) >= CB_MAX) sh++;
-        unsigned *bcnt = nullptr, *bcur = nullptr;
-        long long *bptr = nullptr;
-        XM_HIP(xm_malloc_async((void **)&bcnt, sizeof(unsigned) * CB_MAX, st));
-        XM_HIP(xm_malloc_async((void **)&bcur, sizeof(unsigned) * CB_MAX, st));
-        XM_HIP(xm_malloc_async((void **)&bptr, sizeof(long long) * (CB_MAX + 1), st));
-        XM_HIP(hipMemsetAsync(bcnt, 0, sizeof(unsigned) * CB_MAX, st));
-        const dim3 g((unsigned)((nnz + CB_CHUNK - 1) / CB_CHUNK));
-        k_cb_hist<<<g, dim3(256), 0, st>>>(nnz, R->user_item, sh, bcnt);
-        XM_LAUNCH_CHECK();
-        k_cb_scan<<<dim3(1), dim3(CB_MAX), 0, st>>>(bcnt, bptr, bcur);
-        XM_LAUNCH_CHECK();
-        k_cb_scatter<<<g, dim3(256), 0, st>>>(nnz, R->user_item, sh, bptr, bcur, (int *)bufA);
-        XM_LAUNCH_CHECK();
-        k_cb_count<<<g, dim3(256), 0, st>>>(nnz, (const int *)bufA, sh, bptr, I, cnt);
-        XM_LAUNCH_CHECK();
+    if (nnz >= cb_min && I > 0) {         // partitioned count (k_cbs_*, k_cb_count): the item column as one range, through bufA
+        rcode = mirror_counts(st, I, nnz, 1, nullptr, nullptr, R->user_item, false, (int *)bufA, cnt);        // (free until the tile sort)
+        if (rcode) return rcode;
     } else if (nnz > 0) {
         k_count3<<<dim3((unsigned)((nnz + CNT_CHUNK - 1) / CNT_CHUNK)), dim3(256), 0, st>>>(nnz, R->user_item, cnt);
         XM_LAUNCH_CHECK();
