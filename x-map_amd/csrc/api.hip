@@ -253,7 +253,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     T_ALLOC(hist, U + 2); T_ALLOC(pre, U + 3); T_ALLOC(ctl, 4); T_ALLOC(hid, I); T_ALLOCZ(hlist, 1024);
     T_ALLOC(ub_key, n1); T_ALLOC(ub, n1); T_ALLOC(rcrec, 2 * n1); T_ALLOC(Wp, I);
     T_ALLOC(srec, 2 * n1); T_ALLOC(buf_a, 2 * n1); T_ALLOC(buf_b, 2 * n1);
-    const int ch_min = 1024;
+    const int ch_min = 2048;
     XM_TRY(xmap_sim3_layout(c->st, &R, (int64_t *)R.item_ptr, nullptr, ch_min, 1 | 2 | 4, 0, I, cnt, c->u_avg, c->u_norm, hist, pre, ctl,
                             hid, hlist, ub_key, ub, srec, buf_a, buf_b, rcrec, Wp, c->info, norms, nullptr));
     const int64_t half_contrib = c->half_contrib;
@@ -262,7 +262,7 @@ int xmap_ctx_item_sim(xmap_ctx *c, int method, int cap, int64_t *n_kept, int64_t
     int64_t *uq_ptr, *uc_ptr;
     T_ALLOCZ(Q, I); T_ALLOCZ(Cc, I); T_ALLOCZ(small, I); T_ALLOC(Qcat, (size_t)5 * (I ? I : 1)); T_ALLOCZ(uq_ptr, (size_t)5 * I + 1);
     T_ALLOCZ(uc_ptr, I + 1);
-    int slot_target = 640;
+    int slot_target = 768;          // (75 % load of the 1024-slot tables; device.py: SLOT_TARGET / CH_MIN)
     double coo_slack = 1.0;
     int64_t hc[10];
     int64_t n_light = 0, n_hu = 0;

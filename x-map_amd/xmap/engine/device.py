@@ -20,6 +20,13 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# Stage A: partner bound of one hash partition of a row in the 1024-slot LDS table (75 % load, like the 96 / 192 / 384 of the
+# smaller table classes) and the least rater count of a heavy row (profiles/tools/tune_a.py at BASELINE configs[1]: pair kernels
+# 1.28 ms at 640 / 1024, 1.20 ms at 768 / 2048)
+SLOT_TARGET = 768
+CH_MIN = 2048
+
+
 class DeviceRatings(object):
     """trainRDD in index space, resident in HBM: CSR by user (trainRDD / profile order).  The CSC by item is
     derived on the device at the start of every stage-A pass (Engine.build_csc); only the id dictionary and the
@@ -279,7 +286,7 @@ class Engine(object):
         n = (R.item_ptr[1:] - R.item_ptr[:-1])
         return n * Pn.Q[:R.n_items].to(torch.int64)
 
-    def item_sim(self, method, cap, slot_target=640, item_range=None, stats=None, plan=None, algo="tri"):
+    def item_sim(self, method, cap, slot_target=SLOT_TARGET, item_range=None, stats=None, plan=None, algo="tri"):
         """baseliner_calculate_sim_pipeline.  algo "tri" (default): each unordered pair once + mirror
         (stage_a2.hip); algo "rows": complete rows per unit (stage_a.hip), supports item_range."""
         if algo == "tri" and item_range is None and plan is None:
@@ -342,7 +349,7 @@ class Engine(object):
         return S
 
     # ---- stage A, second formulation (stage_a2.hip): each unordered pair once, mirrored into the CSR
-    def tri_layout(self, stats, slot_target=640, ch_min=1024, dups=False):
+    def tri_layout(self, stats, slot_target=SLOT_TARGET, ch_min=CH_MIN, dups=False):
         """weight-sorted private profiles, rater records, heavy set, work units (method independent).
         dups: a profile may hold an item more than once (AlterEgo rows)."""
         R = self.R
@@ -542,7 +549,7 @@ class Engine(object):
         S.ls = ls[:kept] if ls is not None else None
         return S
 
-    def rec_sim(self, cap, slot_target=640):
+    def rec_sim(self, cap, slot_target=SLOT_TARGET):
         """RecommenderSim.calculate_sim (reference core/recommenderSim.py:65-133,188-195; both method names take the
         cosine branch) over this engine's ratings, which are AlterEgo rows: weighted cosine and leave-one-out local
         sensitivity of every directed item pair with a co-rater, CSR by first item (col, sim, nij, ls).  The same
@@ -575,7 +582,7 @@ class Engine(object):
                                       vp(col), vp(sim), vp(ls)))
         return cnt[:I], col[:I], sim[:I], ls[:I]
 
-    def layout3(self, slot_target=640, ch_min=1024, wide=False, item_range=None):
+    def layout3(self, slot_target=SLOT_TARGET, ch_min=CH_MIN, wide=False, item_range=None):
         """Round-3 layout of the "tri" formulation, one transposition per pass (xmap_sim3_layout): item counts, user and
         item info, weight-sorted profiles, rater records through the tile sort, heavy set, work units.  Returns (stats, L)
         like stats() + tri_layout().  wide: fp64 ratings (R.user_rating64) with zero user averages -- the RecommenderSim
@@ -690,7 +697,7 @@ class Engine(object):
         S.ls = ls[:kept] if ls is not None else None
         return S
 
-    def item_sim_tri(self, method, cap, slot_target=640, ch_min=1024):
+    def item_sim_tri(self, method, cap, slot_target=SLOT_TARGET, ch_min=CH_MIN):
         """baseliner_calculate_sim_pipeline, second formulation (all rows, one GPU).  XMAP_A_V2=1: the round-2 sequence
         (CSC build, CSC-driven rater records, cursor-atomic mirror) -- kept as a cross-check of the round-3 one."""
         if os.environ.get("XMAP_A_V2") == "1":

@@ -251,7 +251,7 @@ class _Rows(object):
     pass
 
 
-def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot_target=640):
+def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot_target=768):
     """stage A -> B -> C once over USER-sharded input (BASELINE configs[2]: "reduce-scatter of cross-shard
     partial similarities"): eng.R holds the complete profiles of this rank's users -- users [user_lo, user_lo + n_users) of
     the whole data set, items indexed globally -- instead of a replica of all ratings.
