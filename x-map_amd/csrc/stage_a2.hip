@@ -2629,11 +2629,11 @@ int xmap_sim3_mirror(void *stream, int32_t n_items, int64_t coo_cap, const int32
     if (n_pairs == 0 || I == 0 || coo_cap == 0) return XMAP_OK;
     XM_HIP(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)I, st));
     ts::Geo G;
-    ts_geometry(I, n_pairs, ts::Chunk<3>::CH, G);      // (n_pairs bounds the mirrored records: a self pair has none)
+    ts_geometry(I, n_pairs, coo_aux ? ts::Chunk<4>::CH : ts::Chunk<3>::CH, G);      // (n_pairs bounds the mirrored records: a self pair has none)
     rcode = ts_prepare(st, G, (const long long *)mptr);
     if (rcode) return rcode;
     // the COO's chunks: from the shard cursors of the pair kernels, or one range of n_pairs records
-    static_assert(ts::Chunk<3>::CH == ts::Chunk<4>::CH, "one chunk list for both record widths");
+    static_assert(ts::Chunk<3>::CH <= ts::Chunk<4>::CH && ts::Chunk<4>::CH % ts::Chunk<3>::CH == 0, "chunk lists by the narrow record width");
     const int n_shards = d_shards ? COO_SHARDS : 1;
     const long long shard_cap = d_shards ? coo_cap / COO_SHARDS : coo_cap;
     const long long chunk_cap = n_pairs / ts::Chunk<3>::CH + n_shards + 1;

@@ -30,7 +30,10 @@ namespace ts {
 constexpr int BT = 256;           // threads of a binning workgroup
 // records per workgroup of a binning level: the chunk is staged in LDS in bucket order (16-byte records: 64 KB, 24-byte
 // records: 48 KB, 32-byte records: 64 KB; two workgroups per CU either way)
-template <int RW> struct Chunk { static constexpr int CH = RW == 2 ? 4096 : 2048; static constexpr int EPT = CH / BT; };
+#ifndef EXP_CH3       // (tuning builds)
+#define EXP_CH3 2048
+#endif
+template <int RW> struct Chunk { static constexpr int CH = RW == 2 ? 4096 : (RW == 3 ? EXP_CH3 : 2048); static constexpr int EPT = CH / BT; };
 constexpr int NB_LOG = 7;
 constexpr int NB = 1 << NB_LOG;   // fine tiles per level-A bucket
 constexpr int NA_MAX = 256;       // level-A buckets (LDS histogram; two staged chunks of 16-byte records per CU need the rest)
