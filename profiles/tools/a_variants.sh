@@ -33,7 +33,7 @@ import sys, json
 try:
     d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
     k = d["kernel_ms"]
-    print(sys.argv[1], "stage_a %.3f" % d["stage_ms"]["A_item_sim"], " ".join("%s %.3f" % (x, k[x]) for x in ("layout3", "tri_plan", "pair_tri", "scatter", "paths", "knn_classify", "reverse", "mid_build") if x in k))
+    print(sys.argv[1], "stage_a %.3f" % d["stage_ms"]["A_item_sim"], " ".join("%s %.3f" % (x, k[x]) for x in ("layout3", "tri_plan", "pair_tri", "mir_count", "scatter", "paths", "knn_classify", "reverse", "mid_build") if x in k))
 except Exception as e:
     print(sys.argv[1], "failed", e)
 P

@@ -441,14 +441,16 @@ class Engine(object):
         return L._heavy_half
 
     def tri_pairs(self, method, cap, stats, L, unit_range=None, do_heavy=True, retry=True, rec=False, raw=False, split=False,
-                  heavy_deal=None, marks=True):
+                  heavy_deal=None, marks=True, count_mir=False):
         """half COO of the kept pairs computed by the light units in unit_range (+ the heavy rows).
         rec: the RecommenderSim variant (nothing filtered, self pairs, a 6th COO column with the local sensitivity).
         split: count a row's own pairs (rowcnt) and the pairs lighter rows computed for it (a 5th return value) apart --
         what tri_mirror takes.  heavy_deal = (rank, world): of the heavy rows only those with item index % world == rank
         (item-sharded ranks deal them round-robin; chunk partials and merge of a row stay on one rank).  split: the mirrored
         counts are NOT taken (the returned array is cleared): tri_mirror / mir_counts count them from the COO.  marks=False:
-        the unused COO entries are left unmarked (for a consumer that goes by the shard cursors: tri_mirror with shards)."""
+        the unused COO entries are left unmarked (for a consumer that goes by the shard cursors: tri_mirror with shards).
+        count_mir (with split, all units on this device): the mirrored counts are taken here, launched BEFORE the read-back of
+        the kept-pair count so that the host's wait falls into their 0.2 ms; tri_mirror is then called with counted=True."""
         R = self.R
         st = _stream(self.dev)
         m = abi.METHODS[method] if isinstance(method, str) else int(method)
@@ -497,6 +499,11 @@ class Engine(object):
             else:       # the heavy rows (chunk partials + merge) on a side stream next to the class launches of the light rows
                 with self.timed("pair_tri"):
                     run(8 | 2 | 16 | 64 | (5 if do_heavy else 0) | (32 if raw else 0))
+            if count_mir and split and not raw:
+                with self.timed("mir_count"):
+                    scratch = self._empty(cap_coo, torch.int32)
+                    check(lib.xmap_sim3_mircount(st, i32(I), i64(cap_coo), vp(coo_i), vp(coo_j), vp(d_shards), i64(cap_coo),
+                                                 i32(1 if rec else 0), vp(scratch), vp(mircnt)))
             h = d_cnt.tolist()          # the one synchronisation of the pair kernels: flags + kept / evaluated pairs
             if h[2]:
                 if L.slot_target <= 32:
@@ -562,8 +569,8 @@ class Engine(object):
             coo, rowcnt, n, n_unordered = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True)
             S = self.tri_scatter(coo, rowcnt, info, n, L)
         else:
-            coo, own, n, n_unordered, mir, shards = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True, split=True, marks=False)
-            S = self.tri_mirror(coo, own, mir, info, n, shards)
+            coo, own, n, n_unordered, mir, shards = self.tri_pairs("adjust_cosine", cap, stats, L, do_heavy=False, rec=True, split=True, marks=False, count_mir=True)
+            S = self.tri_mirror(coo, own, mir, info, n, shards, counted=True)
         S.cap, S.n_unordered, S.layout = int(cap), n_unordered, L
         S.norm = self.norms[R.n_items:2 * R.n_items]
         return S
@@ -708,8 +715,8 @@ class Engine(object):
             S = self.tri_scatter(coo, rowcnt, stats[2], n, L)
         else:
             stats, L = self.layout3(slot_target, ch_min)
-            coo, rowcnt, n, n_unordered, mir, shards = self.tri_pairs(method, cap, stats, L, split=True, marks=False)
-            S = self.tri_mirror(coo, rowcnt, mir, stats[2], n, shards)
+            coo, rowcnt, n, n_unordered, mir, shards = self.tri_pairs(method, cap, stats, L, split=True, marks=False, count_mir=True)
+            S = self.tri_mirror(coo, rowcnt, mir, stats[2], n, shards, counted=True)
         S.method = abi.METHODS[method] if isinstance(method, str) else int(method)
         S.cap = int(cap)
         S.u_avg, S.u_norm = stats[0], stats[1]
