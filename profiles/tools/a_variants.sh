@@ -2,7 +2,7 @@
 # Attribution of the stage-A pair kernels: builds libxmap_hip.so variants with one memory stream removed each
 # (-DEXP_*: switches in csrc/stage_a2.hip, results are WRONG by construction -- timing only) and, on the GPU box,
 # times the pair phase of every variant with bench.py's own HIP-event brackets.
-#   here:        profiles/tools/a_variants.sh build  "NONRM NOHID NOUAVG NOCOO"      (FILE=stage_b: flags of csrc/stage_b.hip, -DEXP_x)
+#   here:        profiles/tools/a_variants.sh build  "NONRM NOUAVG NOCOO"      (FILE=stage_b: flags of csrc/stage_b.hip, -DEXP_x)
 #   on the box:  profiles/tools/a_variants.sh run TAG "BASE NONRM NOCNT NOUAVG NOCOO"
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)

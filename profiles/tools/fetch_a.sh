@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: fetch_a.sh TAG "BASE NONRM NOHID ..."  (GPU box, repo root): FETCH_SIZE / WRITE_SIZE of the stage-A kernels per library
+# usage: fetch_a.sh TAG "BASE NONRM NOUAVG ..."  (GPU box, repo root): FETCH_SIZE / WRITE_SIZE of the stage-A kernels per library
 # variant (profiles/tools/a_variants.sh), one pass of stage A each -> gpurun_out/TAG_fetch_variants.txt
 T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -334,10 +334,9 @@ struct TriArgs {
     unsigned long long *shard_occ;  // [COO_SHARDS] unordered pairs evaluated
     int *coo_i; int *coo_j; double *coo_sim; int *coo_mutu; int *coo_nij;
     double *coo_aux;                // optional 6th column (RecommenderSim: local sensitivity)
-    int *rowcnt;
-    int *mircnt;                    // NULL: the mirrored entries of a row are counted in rowcnt as well; else separately
-                                    // (round-3 mirror: row = [own | mirrored], xmap_sim3_mirror)
-    int *rowcnt_h;                  // [HEAVY_SHARDS][HMAX] replicas for the heavy items
+    int *rowcnt;                    // pairs a row computed itself
+    int *mircnt;                    // (host side only: NULL = the mirrored counts are added to rowcnt after the kernels)
+    int *rowcnt_h;                  // (unused)
     unsigned long long *counters;   // [2] table overflow, [3] COO overflow
     int heavy_mod, heavy_rem;       // the rows of H this call computes: item index % heavy_mod == heavy_rem (item-sharded ranks
                                     // deal the heavy rows round-robin; 1, 0: all of them)
@@ -364,9 +363,9 @@ __device__ __forceinline__ bool finish_pair(const TriArgs &A, int i, int j, int 
 // appending waves: one word sustains only ~90 atomics/us); unused entries keep coo_i = -1.
 constexpr int COO_SHARDS = 4096;
 
-// Row counts of the (at most HMAX) heavy items are taken in HEAVY_SHARDS replicas: a heavy item is the partner of
-// up to ~I rows, and that many atomics on one word would serialise (k_fold_heavy adds the replicas up).
-constexpr int HEAVY_SHARDS = 64;
+// (the mirrored row counts are not taken here any more -- one device atomic per kept pair, with HEAVY_SHARDS replicas for
+// the heavy partners, was what the pair kernels waited for: xmap_sim3_mircount / mirror_counts take them from the COO;
+// rowcnt_h stays in the signature of xmap_sim2_pairs, unused)
 
 // finalise(s, j, n, m, sim, occupied) -> keep.  Pass 1 finalises every slot once (the result is parked by `park`),
 // pass 2 writes the kept ones.
@@ -420,14 +419,6 @@ __global__ __launch_bounds__(256) void k_shard_sums(const unsigned long long *sh
     a = (unsigned long long)wave_sum_ll((long long)a);
     b = (unsigned long long)wave_sum_ll((long long)b);
     if (lane_id() == 0) { atomicAdd(&counters[4], a); atomicAdd(&counters[5], b); }
-}
-
-__global__ __launch_bounds__(256) void k_fold_heavy(int n_heavy, const int *hlist, int *rowcnt_h, int *rowcnt) {
-    int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_heavy) return;
-    int t = 0;
-    for (int s = 0; s < HEAVY_SHARDS; s++) { t += rowcnt_h[s * HMAX + h]; rowcnt_h[s * HMAX + h] = 0; }
-    if (t) atomicAdd(&rowcnt[hlist[h]], t);
 }
 
 // Light rows.  The co-ratings of a block of raters are walked as one flat list, one per lane (k_pair_tri: walk).  Lanes
@@ -2206,7 +2197,6 @@ int xmap_sim2_pairs(void *stream, const xmap_ratings *R, int method, int cap, co
     if (phases & 8) {   // reset the COO cursor / counters / row counts
         XM_HIP(hipMemsetAsync(d_counters, 0, 4 * sizeof(int64_t), st));
         XM_HIP(hipMemsetAsync(d_shards, 0, 2 * COO_SHARDS * sizeof(int64_t), st));
-        XM_HIP(hipMemsetAsync(rowcnt_h, 0, sizeof(int32_t) * HEAVY_SHARDS * HMAX, st));
         if (!(phases & 128)) XM_HIP(hipMemsetAsync(coo_i, 0xff, sizeof(int32_t) * (size_t)coo_cap, st));   // -1 = unused entry (bit 128: the
                                                                     // caller reads the COO through the shard cursors only: 0.4 GB less to write)
         XM_HIP(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * (size_t)(R->n_items > 0 ? R->n_items : 1), st));
