@@ -27,7 +27,10 @@
 namespace xmap {
 namespace ts {
 
-constexpr int BT = 256;           // threads of a binning workgroup
+#ifndef EXP_BT
+#define EXP_BT 256
+#endif
+constexpr int BT = EXP_BT;       // threads of a binning workgroup
 // records per workgroup of a binning level: the chunk is staged in LDS in bucket order (16-byte records: 64 KB, 24-byte
 // records: 48 KB, 32-byte records: 64 KB; two workgroups per CU either way)
 #ifndef EXP_CH3       // (tuning builds)
