@@ -35,7 +35,7 @@ while time.time() < t_end:
     U = int(rng.integers(50, 4000)); Is = int(rng.integers(20, 900)); It = int(rng.integers(20, 900))
     k = int(rng.choice([2, 3, 5, 10, 50, 100])); method = str(rng.choice(["cosine", "adjust_cosine"]))
     ov = round(float(rng.uniform(0.1, 0.9)), 6); mu = round(float(rng.uniform(0.3, 3.0)), 6); sg = round(float(rng.uniform(0.5, 1.6)), 6)
-    if k >= 50 and mu > 1.2: k = 10          # (the one-thread oracle enumerates such a shape for minutes: 1e9 paths)
+    if k >= 50 and (mu > 1.2 or Is + It > 600): k = 10          # (the one-thread oracle enumerates such a shape for minutes: 1e9 paths)
     if rng.random() < 0.3: os.environ["XMAP_REV_LONG"] = "64"
     else: os.environ.pop("XMAP_REV_LONG", None)
     rr = synth.make_two_domain(seed, U, Is, It, overlap=ov, mu=mu, sigma=sg)
