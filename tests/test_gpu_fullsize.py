@@ -228,6 +228,52 @@ def test_full_lists_at_full_size(c2):
         assert np.array_equal(e[order], te[s, :m]) and np.array_equal(v[order], tv[s, :m])
 
 
+def test_rec_sim_full_size_against_the_oracle(c2):
+    """RecommenderSim over the 5.2 M AlterEgo rows the hot path produces at BASELINE configs[1] (k = 50,
+    private mapping; fp64 means, items held twice): every pair's weighted cosine, local sensitivity and count against the
+    CPU oracle over the same rows, bit for bit -- the tile-sorted mirror with the sixth column, the self pairs and the
+    mirrored counts taken from the COO at full size."""
+    import torch
+    from oracle import xmap_oracle as xo
+    from xmap.engine import device, ids
+    r, eng = c2
+    S = eng.item_sim("adjust_cosine", CAP)
+    E = eng.extend(S, 50)
+    _, _, mp = eng.select(E, True)
+    G = eng.alterego(mp)
+    u, it, ra = G.user.cpu().numpy(), G.item.cpu().numpy(), G.rating.cpu().numpy()
+    del S, E, G
+    torch.cuda.empty_cache()
+    o = np.argsort(u, kind="stable")
+    uu, uinv = np.unique(u[o], return_inverse=True)
+    ii, iinv = np.unique(it[o], return_inverse=True)
+    ptr = np.zeros(len(uu) + 1, np.int64)
+    np.cumsum(np.bincount(uinv, minlength=len(uu)), out=ptr[1:])
+    item, rating = iinv.astype(np.int32), ra[o].astype(np.float64)
+    rating[::97] /= 3.0            # means no float32 holds (the stage takes np.float64 values: build_alterEgo's np.mean results)
+    assert len(item) > 4_000_000 and np.any(rating != rating.astype(np.float32).astype(np.float64))
+    all_ids = r.item_ids()
+    iids = [all_ids[x] for x in ii]
+    R = device.DeviceRatings(ptr, item, rating, np.zeros(len(item), np.int64), len(iids), ids.item_attrs(iids), "cuda:0", rating64=True)
+    e2 = device.Engine(R)
+    S2 = e2.rec_sim(CAP)
+    rp = S2.row_ptr.cpu().numpy()
+    rows = np.repeat(np.arange(len(iids), dtype=np.int64), np.diff(rp))
+    col = S2.col.cpu().numpy().astype(np.int64)
+    od = np.lexsort((col, rows))
+    O = xo.rec_sim(ptr, item, rating, len(iids), CAP)
+    orow = np.repeat(np.arange(len(iids), dtype=np.int64), np.diff(O.row_ptr))
+    assert len(rows) == len(orow) > 30_000_000
+    assert np.array_equal(rows[od], orow) and np.array_equal(col[od], O.col.astype(np.int64))
+    assert np.array_equal(S2.nij.cpu().numpy()[od], O.nij)
+    assert np.array_equal(S2.sim.cpu().numpy()[od].view(np.uint64), O.sim.view(np.uint64))
+    assert np.array_equal(S2.ls.cpu().numpy()[od].view(np.uint64), O.ls.view(np.uint64))
+    assert (rows == col).any()                                           # an item held twice pairs with itself
+    assert np.array_equal(S2.norm.cpu().numpy(), O.norm)
+    del S2, e2, R
+    torch.cuda.empty_cache()
+
+
 def test_k100_full_size(c2):
     """the list length of BASELINE configs[3] (k = 100) at configs[1] size, through the size-independent properties"""
     r, eng = c2
