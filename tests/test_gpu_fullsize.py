@@ -51,16 +51,29 @@ def test_stage_a_full_size(c2):
     assert np.array_equal(rp, rp2) and np.array_equal(cols, cols2) and np.array_equal(sim, sim2)
     assert np.array_equal(mutu, mutu2) and np.array_equal(nij, nij2)
     del S2
-    # bounded oracle sample: complete rows [0, 3000) from the CPU oracle
+    # the CPU oracle over ALL rows (8 threads: seconds at this size): the whole matrix, bit for bit
     attrs = r.item_attrs()
     T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *attrs)
-    hi = 3000
-    So = xo.item_sim(T, method, CAP, nthreads=8, rows=(0, hi))
+    So = xo.item_sim(T, method, CAP, nthreads=8)
     assert np.array_equal(S.info.cpu().numpy(), So.info)
-    k = int(rp[hi])
-    assert np.array_equal(rp[:hi + 1], So.row_ptr[:hi + 1])
-    assert np.array_equal(cols[:k], So.col[:k]) and np.array_equal(sim[:k], So.sim[:k])
-    assert np.array_equal(mutu[:k], So.mutu[:k]) and np.array_equal(nij[:k], So.nij[:k])
+    assert S.n_eval == So.n_eval and S.n_contrib == So.n_contrib
+    assert np.array_equal(rp, So.row_ptr)
+    assert np.array_equal(cols, So.col) and np.array_equal(sim, So.sim)
+    assert np.array_equal(mutu, So.mutu) and np.array_equal(nij, So.nij)
+    xo.sim_free(So)
+
+
+def test_stage_a_full_size_cosine(c2):
+    """the plain-cosine branch (fp64 LDS atomic sums, integer-exact) at BASELINE configs[1]: the whole matrix against the oracle"""
+    from oracle import xmap_oracle as xo
+    r, eng = c2
+    S = eng.item_sim("cosine", CAP)
+    rp, rows, cols, sim, mutu, nij = _csr(S)
+    T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *r.item_attrs())
+    So = xo.item_sim(T, "cosine", CAP, nthreads=8)
+    assert S.n_eval == So.n_eval and np.array_equal(rp, So.row_ptr)
+    assert np.array_equal(cols, So.col) and np.array_equal(sim, So.sim)
+    assert np.array_equal(mutu, So.mutu) and np.array_equal(nij, So.nij)
     xo.sim_free(So)
 
 
