@@ -182,9 +182,9 @@ def test_stage_b_against_the_oracle_at_full_size(c2):
     rng = np.random.default_rng(11)
     small = np.nonzero((P > 0) & (P <= 2000000))[0]
     mid = np.nonzero((P > 2000000) & (P <= 30000000))[0]
-    sample = np.sort(np.concatenate([rng.choice(small, size=min(40, len(small)), replace=False),
-                                     rng.choice(mid, size=min(4, len(mid)), replace=False)]))
-    assert len(sample) >= 20
+    sample = np.sort(np.concatenate([rng.choice(small, size=min(90, len(small)), replace=False),
+                                     rng.choice(mid, size=min(6, len(mid)), replace=False)]))
+    assert len(sample) >= 40
     Xs = xo.extend(T, So, k, starts=sample)
     assert Xs.n_paths == int(P[sample].sum())
     n_cand = E.n_cand.cpu().numpy()[:I]
