@@ -136,6 +136,14 @@ def test_stage_b_c_full_size(c2, k):
     key = users[mapped] * np.int64(I) + mp[r.item][mapped]
     assert G.n_rows - n_t == len(np.unique(key))                      # one AlterEgo row per (user, mapped target)
     assert (rt >= 1).all() and (rt <= 5).all()
+    if k == 50:
+        # stage C against the oracle on the same replacement map: all 5.2 M rows (users, items, fp64 means, times), exactly
+        from oracle import xmap_oracle as xo
+        T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *r.item_attrs())
+        ae = xo.alterego(T, mp)
+        assert np.array_equal(u, ae["user"]) and np.array_equal(it, ae["item"])
+        assert np.array_equal(rt, ae["rating"]) and np.array_equal(G.time.cpu().numpy(), ae["time"])
+        assert eng.n_profiles(G) == ae["n_profiles"] and G.n_target_rows == ae["n_target_rows"]
 
 
 def test_stage_b_against_the_oracle_at_full_size(c2):
