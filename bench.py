@@ -1,7 +1,12 @@
 """bench.py -- one "step" = one pass of the X-MAP hot path (item-item similarity -> cross-domain
 extension -> AlterEgo generation) over synthetic Amazon-format ratings already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK) every
+process is a rank; WITHOUT one, `python bench.py --gpus N` starts the N ranks itself -- the parent touches no GPU, runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` as a
+child process, relays rank 0's line and exits with the child's code (reference README.md:53-66: one spark-submit command).
 
 Prints ONE JSON line (rank 0).  metric = item-item sim pairs/s: D (distinct directed item pairs with
 >= 1 co-rater evaluated by stage A) / stage-A time; AlterEgo profiles/s and the per-stage
@@ -29,14 +34,23 @@ CAP = 50                # parameters.yaml:18
 
 
 # The bench line is the ONLY thing on stdout: native libraries write there too (RCCL prints a version banner on
-# communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
-_REAL_STDOUT = os.fdopen(os.dup(1), "w")
-os.dup2(2, 1)
+# communicator creation), so fd 1 is pointed at stderr for the whole run (claim_stdout, first thing in main) and the JSON
+# goes to the saved descriptor.
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 def emit(out):
-    _REAL_STDOUT.write(json.dumps(out) + "\n")
-    _REAL_STDOUT.flush()
+    f = _REAL_STDOUT or sys.stdout
+    f.write(json.dumps(out) + "\n")
+    f.flush()
 
 
 def log(*a):
@@ -415,7 +429,59 @@ def bench_api(args, rank, world, local, dist):
           "setup_s": setup})
 
 
+def launcher_argv(n_ranks, port, argv):
+    """the command `bench.py --gpus N` runs when no launcher started it: N ranks of this script on this node"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(n_gpus, env):
+    """--gpus N > 1 outside a launcher (XMAP_FORCE_DIST=1 is the one-rank rehearsal of the collectives, not a launch)"""
+    return n_gpus > 1 and "WORLD_SIZE" not in env and "RANK" not in env and env.get("XMAP_FORCE_DIST") != "1"
+
+
+def self_launch(n_ranks, argv):
+    """Parent of a self-started N-rank run.  No GPU call happens in this process (no torch.cuda.* beyond the device COUNT,
+    no DeviceRatings): a process that has initialised the GPU must not start the ranks, and the ranks own the devices."""
+    import socket
+    import subprocess
+    backend = os.environ.get("XMAP_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()                 # counting does not initialise the GPU
+    if backend == "nccl" and n_dev < n_ranks:
+        log("bench.py: --gpus %d over RCCL needs %d visible devices, %d found (XMAP_DIST_BACKEND=gloo rehearses several "
+            "ranks on fewer GPUs)" % (n_ranks, n_ranks, n_dev))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    cmd = launcher_argv(n_ranks, port, argv)
+    log("bench.py: starting %d ranks: %s" % (n_ranks, " ".join(cmd)))
+    assert not torch.cuda.is_initialized()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in child.stdout:                           # rank 0 prints ONE JSON line; anything else on stdout goes to the log
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            log(t)
+    rc = child.wait()
+    if rc == 0 and line is not None:
+        f = _REAL_STDOUT or sys.stdout
+        f.write(line + "\n")
+        f.flush()
+    elif rc == 0:
+        log("bench.py: the ranks exited cleanly but printed no bench line")
+        rc = 3
+    return rc
+
+
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -436,8 +502,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("XMAP_DIST_BACKEND", "nccl") != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
-    if args.gpus > 1 and world == 1:
-        log("bench.py: --gpus %d needs torch.distributed.run; running 1 rank" % args.gpus)
+    if needs_self_launch(args.gpus, os.environ):
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     dist = None
     # XMAP_FORCE_DIST=1: take the sharded path with one rank (rehearses the RCCL collectives on a one-GPU box)
     force = world == 1 and os.environ.get("XMAP_FORCE_DIST") == "1"
@@ -539,10 +605,19 @@ def main():
         stage = dict(zip(("stage_a", "stage_b", "stage_c"), [float(x) for x in v.tolist()]))
     t_a, t_b, t_c = stage["stage_a"] / 1e3, stage["stage_b"] / 1e3, stage["stage_c"] / 1e3
     n_upd = int(getattr(res["E"], "n_updates", 0))      # row updates of this rank's starts
+    per_rank = None
     if dist:
         nu = torch.tensor([n_upd], dtype=torch.int64, device=dev)
         dist.all_reduce(nu)
         n_upd = int(nu.item())
+        # the brackets an N-way run cannot divide, and the sharded ones beside them, of EVERY rank (mean ms per step)
+        keys = ("stage_a", "stage_b", "stage_c", "stats_gather", "exchange", "exchange_partials", "knn_gather", "reverse",
+                "mid_build", "paths", "pair_tri", "layout3")
+        mine = torch.tensor([float(np.mean(tm[n])) if n in tm else -1.0 for n in keys], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        per_rank = {n: [round(float(x), 4) for x in allr[:, j]] for j, n in enumerate(keys) if (allr[:, j] >= 0).any()}
 
     if rank == 0:
         D, Dk, P, nnz, I = res["n_eval"], res["n_kept"], res["n_contrib"], r.nnz, r.n_items
@@ -559,15 +634,23 @@ def main():
         ach = bytes_tri / (tri_ms * 1e-3) / 1e9 if tri_ms > 0 else 0.0
         # SURVEY.md 8d states the whole-stage figure too: B_A = 8 P + 16 nnz + 32 I + 20 D' over t_A
         bytes_a = 8.0 * P + 16.0 * nnz + 32.0 * I + 20.0 * Dk
-        # Stage-B dominant kernel: k_paths2.  Compulsory HBM bytes are the knn tables + the outputs (SURVEY.md 8d:
+        # Stage-B dominant kernel: k_paths4.  Compulsory HBM bytes are the knn tables + the outputs (SURVEY.md 8d:
         # 12 E + 12 N_out); it is latency / random-access bound, paths/s is the figure of merit.
         paths_ms = float(np.mean(tm.get("paths", [0.0])))
         bytes_paths = 12.0 * res["knn_entries"] + 12.0 * res["n_out"]
+        bytes_fused = 12.0 * res["knn_entries"] + 124.0 * I
         tr_a, tr_b = pmc_traffic("k_pair_tri"), pmc_traffic("k_paths4")
 
         ach_b = bytes_paths / (paths_ms * 1e-3) / 1e9 if paths_ms > 0 else 0.0
         rf_b = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
                 "traffic": tr_b, "traffic_ratio": (tr_b / bytes_paths) if (tr_b and bytes_paths) else None,
+                "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command; not measured in this run)",
+                # the timed call is the FUSED mode (extender_pipeline's lazy handle, full=False): it never writes the
+                # 12 N_out bytes of the lists, only the per-start candidate arrays (count + ten best: 124 B per item)
+                "fused_mode": {"algorithmic_bytes_per_launch": bytes_fused,
+                               "achieved": bytes_fused / (paths_ms * 1e-3) / 1e9 if paths_ms > 0 else 0.0,
+                               "frac": bytes_fused / (paths_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if paths_ms > 0 else 0.0,
+                               "note": "12 E + 124 I: knn tables in, (n_cand, top_end[10], top_val[10]) out"},
                 "traffic_fetch_x1": pmc_traffic("k_paths4_fetch_x1"),     # FETCH_SIZE as is: exact for lone 32-byte reads (profiles/README.md)
                 "algorithmic_bytes_per_launch": bytes_paths, "launch_ms": paths_ms,
                 "paths_per_s": res["n_paths"] / (paths_ms * 1e-3) if paths_ms > 0 else 0.0,
@@ -592,6 +675,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
+            # ranks that talk through RCCL (0: one process, or a gloo rehearsal of several ranks on fewer GPUs)
+            "rccl_ranks": dist.get_world_size() if (dist and dist.get_backend() == "nccl") else 0,
+            "dist_backend": dist.get_backend() if dist else None,
+            "kernel_ms_per_rank": per_rank,
             "config": {"workload": wl["name"], "method": args.method, "top_k": k, "private": True,
                        "users": r.n_users, "items": I, "nnz": nnz, "P_contributions": P,
                        "D_pairs_evaluated": D, "D_pairs_kept": Dk, "paths": res["n_paths"],
@@ -607,6 +694,7 @@ def main():
             "roofline": dict(rf_b, kernel="k_paths4"),
             "roofline_stage_a": {"bound": "hbm", "kernel": "k_pair_tri" if split else "k_pair_tri + k_pair_heavy / k_heavy_merge (side stream)", "achieved": ach, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr_a,
+                                 "traffic_source": "profiles/pmc_traffic.json (committed PMC passes; not measured in this run)",
                                  "traffic_ratio": (tr_a / bytes_tri) if (tr_a and bytes_tri) else None,
                                  "algorithmic_bytes_per_launch": bytes_tri, "launch_ms": tri_ms,
                                  "stage_a_whole": {"algorithmic_bytes": bytes_a, "ms": stage["stage_a"],

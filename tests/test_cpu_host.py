@@ -2,6 +2,7 @@
 the host logic (id predicates, RDD-like container, pyspark stand-in, shard planning, RNG draws) behaves."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -150,3 +151,60 @@ def test_synth_is_deterministic_and_lexicographic():
     for u in range(0, 500, 50):
         prof = a.item[a.user_ptr[u]:a.user_ptr[u + 1]]
         assert len(set(prof.tolist())) == len(prof)
+
+
+# ---- bench.py --gpus N outside a launcher: the parent starts the ranks itself (reference README.md:53-66: one command)
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("xmap_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)          # importing must not redirect stdout or touch a GPU: both happen in main()
+    return mod
+
+
+def test_bench_launcher_argv_and_when_it_applies():
+    b = _bench_module()
+    argv = b.launcher_argv(8, 29999, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "8"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29999"
+    assert argv[-7].endswith("bench.py") and argv[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert b.needs_self_launch(8, {}) and b.needs_self_launch(2, {"HOME": "/"})
+    assert not b.needs_self_launch(1, {})
+    assert not b.needs_self_launch(8, {"WORLD_SIZE": "8", "RANK": "3"})      # under torch.distributed.run: this IS a rank
+    assert not b.needs_self_launch(8, {"XMAP_FORCE_DIST": "1"})               # one-rank rehearsal of the collectives
+
+
+def test_bench_parent_starts_the_ranks_without_touching_the_gpu(monkeypatch):
+    """the parent of a self-started run: builds the launcher command, relays rank 0's line, returns the child's exit code --
+    and has not initialised CUDA when it starts the ranks (a process that has must not; the ranks own the devices)"""
+    import io
+    import subprocess
+    import torch
+    b = _bench_module()
+    seen = {}
+
+    class FakeChild(object):
+        def __init__(self, cmd, stdout=None, env=None, text=None):
+            seen["cmd"], seen["env"], seen["cuda"] = cmd, env, torch.cuda.is_initialized()
+            self.stdout = io.StringIO('NCCL version banner\n{"metric": "item_sim_pairs_per_s", "n_gpus": 2}\n')
+
+        def wait(self):
+            return seen.get("rc", 0)
+
+    monkeypatch.setattr(subprocess, "Popen", FakeChild)
+    monkeypatch.setenv("XMAP_DIST_BACKEND", "gloo")      # (nccl refuses up front when fewer devices than ranks are visible)
+    out = io.StringIO()
+    monkeypatch.setattr(b, "_REAL_STDOUT", out)
+    assert b.self_launch(2, ["--gpus", "2", "--workload", "c1"]) == 0
+    assert seen["cuda"] is False and not torch.cuda.is_initialized()
+    assert seen["cmd"][:3] == [sys.executable, "-m", "torch.distributed.run"] and seen["cmd"][-4:] == ["--gpus", "2", "--workload", "c1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert out.getvalue().strip() == '{"metric": "item_sim_pairs_per_s", "n_gpus": 2}'     # the banner went to the log
+    seen["rc"] = 7                                        # a failing rank: non-zero exit, no line
+    out.seek(0); out.truncate()
+    assert b.self_launch(2, ["--gpus", "2"]) == 7 and out.getvalue() == ""
+    monkeypatch.setenv("XMAP_DIST_BACKEND", "nccl")
+    if torch.cuda.device_count() < 2:
+        assert b.self_launch(2, ["--gpus", "2"]) == 2    # RCCL needs one device per rank

@@ -1,5 +1,6 @@
 """The library's runtime pieces that are not a stage: the arena of temporaries (csrc/util.hip)."""
 import ctypes as C
+import os
 
 import pytest
 
@@ -38,3 +39,30 @@ def test_arena_resets_after_an_error_return_and_trims():
     # ... and xmap_trim returns the rest
     assert lib.xmap_trim() == 0
     assert _arena(lib, st) == (0, 0)
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher environment: the parent starts two ranks (gloo here: both on the one GPU
+    of the test box; on a multi-GPU node the default backend is RCCL), ONE line comes back with n_gpus = 2 and the counts
+    of the one-rank line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extra"]
+
+    def line(extra, **more):
+        p = subprocess.run(base + extra, env=dict(env, **more), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rows = [x for x in p.stdout.splitlines() if x.strip()]
+        assert len(rows) == 1, p.stdout
+        return json.loads(rows[0])
+    one = line(["--gpus", "1"])
+    two = line(["--gpus", "2"], XMAP_DIST_BACKEND="gloo")
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 0
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 0 and two["dist_backend"] == "gloo"
+    for key in ("D_pairs_evaluated", "D_pairs_kept", "paths", "P_contributions"):
+        assert two["config"][key] == one["config"][key], key
+    assert two["alterego_rows"] == one["alterego_rows"] and two["profiles"] == one["profiles"]
+    assert set(two["kernel_ms_per_rank"]["exchange"]) and len(two["kernel_ms_per_rank"]["stage_b"]) == 2

@@ -36,27 +36,56 @@ def _summary(res):
                 ae_user=G.user.cpu().numpy(), ae_item=G.item.cpu().numpy(), ae_rating=G.rating.cpu().numpy())
 
 
-def _engine():
+def _engine(dev="cuda:0"):
     from xmap.engine import synth, device
     r = synth.make_two_domain(21, 4000, 700, 700)
-    return device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs()))
+    return device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev))
 
 
-def _worker(rank, world, port, q):
+def _init(rank, world, port, backend):
+    """gloo: every rank on cuda:0 (several ranks on the one GPU of the test box); nccl: rank r on cuda:r over RCCL"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
     import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        return dist, "cuda:%d" % rank
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, "cuda:0"
+
+
+def _rccl_world():
+    """ranks of the RCCL tests: one per visible GPU, at most 8; the tests are skipped on a one-GPU box"""
+    import torch
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("RCCL with more than one rank needs >= 2 visible GPUs (%d here)" % n)
+    return n
+
+
+def _worker(rank, world, port, q, backend="gloo"):
+    dist, dev = _init(rank, world, port, backend)
     from xmap.engine import sharded
-    res = sharded.run_step(_engine(), "adjust_cosine", 50, 5, True, dist, rank, world)
+    res = sharded.run_step(_engine(dev), "adjust_cosine", 50, 5, True, dist, rank, world)
     q.put((rank, _summary(res)))
     dist.barrier()
     dist.destroy_process_group()
 
 
+def test_item_sharded_over_rccl_equals_world1():
+    """run_step on the nccl backend, one rank per visible GPU (BASELINE configs[2]); bit-equal to one rank"""
+    _check_world_equals_world1(_rccl_world(), "nccl")
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_world2_equals_world1(world):
+    _check_world_equals_world1(world, "gloo")
+
+
+def _check_world_equals_world1(world, backend):
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
@@ -65,7 +94,7 @@ def test_world2_equals_world1(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(world)]
@@ -83,7 +112,8 @@ def test_world2_equals_world1(world):
     lens = np.stack([np.diff(out["row_ptr"]) for _, out in sorted(got)])
     assert np.array_equal(lens.sum(axis=0), np.diff(ref["row_ptr"])) and np.all((lens > 0).sum(axis=0) <= 1)
     owner = np.where((lens > 0).any(axis=0), lens.argmax(axis=0), -1)
-    assert np.all(np.diff(owner[owner >= 0]) >= 0) and all((owner == r).any() for r in range(world))
+    assert np.all(np.diff(owner[owner >= 0]) >= 0)
+    assert world > 4 or all((owner == r).any() for r in range(world))      # (eight shares of this small matrix may leave one empty)
     s_rows = np.concatenate([np.repeat(np.arange(I), np.diff(out["row_ptr"])) for _, out in sorted(got)])
     s_cols = np.concatenate([out["col"] for _, out in sorted(got)])
     s_sims = np.concatenate([out["sim"] for _, out in sorted(got)])
@@ -98,26 +128,27 @@ def test_world2_equals_world1(world):
     full_rows = np.repeat(np.arange(I), np.diff(ref["row_ptr"]))
     assert np.array_equal(rows[o], full_rows) and np.array_equal(cols[o], ref["col"])
     assert np.array_equal(sims[o], ref["sim"])
-    assert all(len(out["part_row"]) > 0 for _, out in got)
+    assert world > 4 or all(len(out["part_row"]) > 0 for _, out in got)
 
 
-def _md_engine(d):
+def _md_engine(d, dev="cuda:0"):
     from xmap.engine import synth, device
     r = synth.make_multi_domain(33, 3000, 500, 600, 3)[d]
-    return device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs())), r.n_src_items
+    return device.Engine(device.DeviceRatings(r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs(), dev)), r.n_src_items
 
 
-def _md_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _md_worker(rank, world, port, q, backend="gloo"):
+    dist, dev = _init(rank, world, port, backend)
     from xmap.engine import multidomain
-    out = multidomain.run_multidomain(_md_engine, 3, "adjust_cosine", 50, 5, True, dist)
+    out = multidomain.run_multidomain(lambda d: _md_engine(d, dev), 3, "adjust_cosine", 50, 5, True, dist)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_multidomain_over_rccl_equals_one_rank():
+    """run_multidomain on the nccl backend, one rank per visible GPU (rank groups with group-local RCCL communicators)"""
+    _check_multidomain(_rccl_world(), "nccl")
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -125,6 +156,10 @@ def test_multidomain_rank_groups_equal_one_rank(world):
     """BASELINE configs[3] shape (3 source domains -> one target): the domains dealt to rank groups (world 2: one rank
     takes two domains; world 4: one domain is item-sharded over a group of two ranks) give exactly the union one rank
     computes domain after domain."""
+    _check_multidomain(world, "gloo")
+
+
+def _check_multidomain(world, backend):
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
@@ -135,7 +170,7 @@ def test_multidomain_rank_groups_equal_one_rank(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_md_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_md_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(world)]
@@ -147,25 +182,21 @@ def test_multidomain_rank_groups_equal_one_rank(world):
             assert np.array_equal(out[key], v), (rank, key)
 
 
-def _user_share(rank, world):
+def _user_share(rank, world, dev="cuda:0"):
     """the complete profiles of a contiguous share of the users (items indexed globally)"""
     from xmap.engine import synth, device
     r = synth.make_two_domain(21, 4000, 700, 700)
     lo, hi = r.n_users * rank // world, r.n_users * (rank + 1) // world
     e0, e1 = int(r.user_ptr[lo]), int(r.user_ptr[hi])
     ptr = (r.user_ptr[lo:hi + 1] - r.user_ptr[lo]).astype(np.int64)
-    R = device.DeviceRatings(ptr, r.item[e0:e1].copy(), r.rating[e0:e1].copy(), r.time[e0:e1].copy(), r.n_items, r.item_attrs())
+    R = device.DeviceRatings(ptr, r.item[e0:e1].copy(), r.rating[e0:e1].copy(), r.time[e0:e1].copy(), r.n_items, r.item_attrs(), dev)
     return device.Engine(R), lo
 
 
-def _users_worker(rank, world, port, method, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _users_worker(rank, world, port, method, q, backend="gloo"):
+    dist, dev = _init(rank, world, port, backend)
     from xmap.engine import sharded
-    eng, lo = _user_share(rank, world)
+    eng, lo = _user_share(rank, world, dev)
     res = sharded.run_step_users(eng, lo, method, 50, 5, True, dist)
     out = _summary(res)
     out["info"] = res["info"].cpu().numpy()
@@ -174,11 +205,21 @@ def _users_worker(rank, world, port, method, q):
     dist.destroy_process_group()
 
 
+def test_user_sharded_over_rccl_equals_world1():
+    """run_step_users on the nccl backend, one rank per visible GPU: the all-to-all of the partial similarities between
+    real peers (the one-rank RCCL test below only sends to itself)"""
+    _check_user_sharded(_rccl_world(), "adjust_cosine", "nccl")
+
+
 @pytest.mark.parametrize("world,method", [(2, "adjust_cosine"), (3, "cosine"), (4, "adjust_cosine")])
 def test_user_sharded_equals_world1(world, method):
     """BASELINE configs[2]'s other split: every rank holds a share of the USERS, the partial similarities of a pair are
     sent to the rank that owns it and added up there (sharded.run_step_users).  Item statistics, similarity matrix, extension,
     replacements and AlterEgo rows must be those of one rank over all ratings, bit for bit."""
+    _check_user_sharded(world, method, "gloo")
+
+
+def _check_user_sharded(world, method, backend):
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
@@ -189,7 +230,7 @@ def test_user_sharded_equals_world1(world, method):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_users_worker, args=(r, world, port, method, q)) for r in range(world)]
+    procs = [ctx.Process(target=_users_worker, args=(r, world, port, method, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(world)]
