@@ -102,9 +102,17 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4, k=0):
         t0 = time.time()
         S = xo.item_sim(T, method, CAP, uavg, info, nthreads=threads, rows=(0, rows))
         dt = time.time() - t0
-    out = dict(value=S.n_eval / dt, unit="pairs/s", cores=threads, kind="port",
-               sample="oracle stage A (item-item sim) on item rows [0,%d) of %d: %d pairs in %.1f s, OpenMP %d threads"
-                      % (rows, I, S.n_eval, dt, threads))
+    # `value` is the whole call as Python sees it (set-up, rows, concatenation, the copy of the 1 GB result into NumPy);
+    # `rows_only` is the part that IS the pair work, timed inside the C call -- the figure to hold against the GPU's
+    # pair kernels, and the one that scales with the cores (the serial item-major copy and the result copies do not)
+    sec = getattr(S, "seconds", (0.0, dt, 0.0))
+    dt_c = max(sum(sec), 1e-9)        # the C call itself (the wrapper's copy of the 1 GB result into NumPy arrays is not the stage)
+    out = dict(value=S.n_eval / dt_c, unit="pairs/s", cores=threads, kind="port",
+               sample="oracle stage A (item-item sim) on item rows [0,%d) of %d: %d pairs in %.1f s inside the C call "
+                      "(%.1f s with the Python wrapper's result copies), OpenMP %d threads" % (rows, I, S.n_eval, dt_c, dt, threads),
+               rows_only=dict(value=S.n_eval / max(sec[1], 1e-9), unit="pairs/s", seconds=sec[1],
+                              note="inside the C call: item-major copy %.2f s (serial), rows %.2f s, concatenation %.2f s"
+                                   % sec))
     # SURVEY.md 8d asks for two legs of the restatement -- 4 threads (spark-submit --master local[4], the one the >= 10x
     # target is judged against: `value` above) and every core this process may use -- and, beside them, the reference's own
     # modules on the RDD stand-in: a constant measured in the survey container, not on this host
@@ -117,8 +125,13 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4, k=0):
         t0 = time.time()
         S = xo.item_sim(T, method, CAP, uavg, info, nthreads=ncpu, rows=(0, rows))
         dt_all = time.time() - t0
-        out["all_cores"] = dict(value=S.n_eval / dt_all, unit="pairs/s", cores=ncpu, kind="port",
-                                sample="the same rows, OpenMP %d threads: %.1f s" % (ncpu, dt_all))
+        sec = getattr(S, "seconds", (0.0, dt_all, 0.0))
+        out["all_cores"] = dict(value=S.n_eval / max(sum(sec), 1e-9), unit="pairs/s", cores=ncpu, kind="port",
+                                sample="the same rows, OpenMP %d threads: %.1f s inside the C call (%.1f s with the wrapper)"
+                                       % (ncpu, sum(sec), dt_all),
+                                rows_only=dict(value=S.n_eval / max(sec[1], 1e-9), unit="pairs/s", seconds=sec[1],
+                                               note="inside the C call: item-major copy %.2f s (serial), rows %.2f s, "
+                                                    "concatenation %.2f s" % sec))
     out["reference_on_shim"] = dict(value=3.5e4, unit="pairs/s", cores=1, kind="reference",
                                     sample="the reference's Python modules on a list-backed RDD stand-in, 10k users / 2x5k items "
                                            "(915 852 pairs in 26.4 s): measured once in the survey container (BASELINE.md 2), "

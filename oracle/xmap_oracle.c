@@ -28,8 +28,16 @@
 #include <omp.h>
 #endif
 
+#include <stdio.h>
+
 #define XO_COSINE 0
 #define XO_ADJUST 1
+
+static double xo_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 /* ------------------------------------------------------------------ utils */
 /* numpy's float add-reduce kernel (pairwise summation, block 128, unroll 8);
@@ -115,6 +123,7 @@ typedef struct {
     double *sim;
     int32_t *mutu;
     int32_t *nij;
+    double seconds[3]; /* wall clock of the call's phases: item-major copy of the ratings, the rows (all pair work), output concatenation */
 } XoSim;
 
 typedef struct {
@@ -155,6 +164,7 @@ XoSim *xo_item_sim(int method, int cap, int64_t U, int32_t I, const int64_t *ptr
                    const float *rating, const double *uavg, const double *info, int nthreads,
                    int32_t row_lo, int32_t row_hi) {
     /* CSC (item -> raters ascending user index) */
+    const double t_begin = xo_now();
     int64_t nnz = ptr[U];
     int64_t *iptr = (int64_t *)calloc((size_t)I + 1, sizeof(int64_t));
     for (int64_t e = 0; e < nnz; e++) iptr[item[e] + 1]++;
@@ -173,6 +183,7 @@ XoSim *xo_item_sim(int method, int cap, int64_t U, int32_t I, const int64_t *ptr
         free(cur);
     }
     if (nthreads < 1) nthreads = 1;
+    const double t_csc = xo_now();
     Arena *arenas = (Arena *)calloc((size_t)nthreads, sizeof(Arena));
     int32_t *row_thr = (int32_t *)calloc((size_t)I, sizeof(int32_t));
     int64_t *row_off = (int64_t *)calloc((size_t)I, sizeof(int64_t));
@@ -267,6 +278,7 @@ XoSim *xo_item_sim(int method, int cap, int64_t U, int32_t I, const int64_t *ptr
         }
         free(cnt); free(pos); free(mut); free(touched); free(bj); free(bt); free(grouped);
     }
+    const double t_rows = xo_now();
     XoSim *S = (XoSim *)calloc(1, sizeof(XoSim));
     S->I = I;
     S->n_eval = n_eval;
@@ -292,6 +304,10 @@ XoSim *xo_item_sim(int method, int cap, int64_t U, int32_t I, const int64_t *ptr
     }
     for (int t = 0; t < nthreads; t++) { free(arenas[t].col); free(arenas[t].sim); free(arenas[t].mutu); free(arenas[t].nij); }
     free(arenas); free(row_thr); free(row_off); free(row_cnt); free(iptr); free(iuser); free(irat);
+    S->seconds[0] = t_csc - t_begin; S->seconds[1] = t_rows - t_csc; S->seconds[2] = xo_now() - t_rows;
+    if (getenv("XO_TIMING"))
+        fprintf(stderr, "xo_item_sim: %d threads, csc %.3f s, rows %.3f s, concat %.3f s\n", nthreads, t_csc - t_begin,
+                t_rows - t_csc, xo_now() - t_rows);
     return S;
 }
 void xo_sim_free(XoSim *S) {

@@ -28,7 +28,7 @@ class _XoSim(C.Structure):
     _fields_ = [("I", C.c_int32), ("n_eval", C.c_int64), ("n_contrib", C.c_int64),
                 ("row_ptr", C.POINTER(C.c_int64)), ("col", C.POINTER(C.c_int32)),
                 ("sim", C.POINTER(C.c_double)), ("mutu", C.POINTER(C.c_int32)),
-                ("nij", C.POINTER(C.c_int32))]
+                ("nij", C.POINTER(C.c_int32)), ("seconds", C.c_double * 3)]
 
 
 class _XoExt(C.Structure):
@@ -121,6 +121,7 @@ def item_sim(T, method, cap, uavg=None, info=None, nthreads=1, rows=None):
     out.I = T.I
     out.n_eval = int(s.n_eval)
     out.n_contrib = int(s.n_contrib)
+    out.seconds = tuple(float(x) for x in s.seconds)      # inside the C call: (item-major copy, rows, concatenation)
     out.row_ptr = _arr(s.row_ptr, T.I + 1, np.int64)
     D = int(out.row_ptr[-1])
     out.col = _arr(s.col, D, np.int32)

@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   mkdir -p $V
   make -C $C -j8 >/dev/null
   for n in $2; do
-    flags=""; for f in ${n//+/ }; do if [ "$f" = ATRACE ]; then flags="$flags -DA_TRACE"; elif [[ "$f" == *=* ]]; then flags="$flags -DEXP_$f"; else flags="$flags -DEXP_$f"; fi; done
+    flags=""; for f in ${n//+/ }; do if [ "$f" = ATRACE ]; then flags="$flags -DA_TRACE"; elif [[ "$f" == Q_* ]]; then flags="$flags -D$f"; elif [[ "$f" == *=* ]]; then flags="$flags -DEXP_$f"; else flags="$flags -DEXP_$f"; fi; done
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $flags -c $C/${FILE:-stage_a2}.hip -o $V/a2_$n.o &
   done
   wait
@@ -27,7 +27,8 @@ else
   cd $ROOT
   for n in $3; do
     lib=$V/libxmap_$n.so; [ "$n" = BASE ] && lib=$ROOT/x-map_amd/libxmap_hip.so
-    XMAP_HIP_LIB=$lib timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --no-cpu --no-extra > gpurun_out/${T}_$n.json 2> gpurun_out/${T}_$n.err || true
+    env_extra=""; [[ "$n" == *Q_STORE* ]] && env_extra="XMAP_ABL_ROW_ENTRIES=${ABL_ROW_ENTRIES:-830000}"
+    env $env_extra XMAP_HIP_LIB=$lib timeout -k 10 ${VAR_TIMEOUT:-200} python3 bench.py --steps ${VAR_STEPS:-10} --warmup ${VAR_WARMUP:-3} --no-cpu --no-extra > gpurun_out/${T}_$n.json 2> gpurun_out/${T}_$n.err || true
     python3 - $n gpurun_out/${T}_$n.json <<'P'
 import sys, json
 try:

@@ -474,6 +474,7 @@ struct PathArgs {
     // rows of k_paths4 are indexed by the rank of an item among the items that can end a path (U of them) instead of by
     // the item: uitem[rank] = item, urank[item] = rank.  The older kernels leave these NULL / U = I.
     int U; const int *urank; const int *uitem;
+    long long row_stride;          // entries per accumulator row (k_paths4: U unless an ablation build asks for more)
 };
 
 struct Carry { double sm, mu, c; };  // sum sim*mutu, sum mutu, prod frac_mutu along the path so far
@@ -1279,8 +1280,17 @@ struct QAcc {
     }
 };
 
+// An all-zero row entry: where the lanes of HOME ends read their "old" value from.  The home column of an end is the lowest
+// column that lists it (ColEnd::u bit 30, k_col_home); columns are visited in ascending order and a unit visits its columns
+// before anything else touches its row, so in the first head batch an end's entry is still zero when its home column
+// comes by -- the update of a home end needs no load from the row: its lanes read this one cached line instead (the add
+// of zero is exact, `first` comes out true by itself), and what the memory system sees is a store.
+__device__ double g_zero_entry[4] = {0.0, 0.0, 0.0, 0.0};
+constexpr int END_HOME = 1 << 30;
+
 template <bool FASTDIV>
-__device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi) {
+__device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi,
+                                        bool fresh) {
     __shared__ QLds stageq[4];          // one per wave of the block; DS operations of a wave execute in order
     const PathArgs &A = B.P;
     QLds &L = stageq[threadIdx.x >> 6];
@@ -1398,16 +1408,27 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 L.e_u[lane] = (b + lane < ne) ? eu_ : -1; L.e_sm[lane] = e.sm; L.e_mu[lane] = e.mu; L.e_f[lane] = e.f;
             }
             asm volatile("" ::: "memory");
-            const int eu = L.e_u[q];
-            const bool ok = eu >= 0;
+            const int eur = L.e_u[q];
+            const bool ok = eur >= 0;
+            const int eu = eur & (END_HOME - 1);
             const double sm5 = L.e_sm[q], mu5 = L.e_mu[q], f5 = L.e_f[q];
             const bool fl_ = ok && slice == 0;
+#ifdef Q_STORE      // (ablation: every (column, end) a slot of its own -- a column visit is one contiguous run of stores, no load)
+            double *a = W.acc + ((size_t)rl32(cur.pad, first_l) * (k + 1) + (size_t)(b + q)) * 4;
+#else
             double *a = W.acc + (size_t)(ok ? eu : 0) * 4;
+#endif
+#ifdef Q_NOHOME
+            const double *la = a;
+#else
+            const double *la = (ok && fresh && (eur & END_HOME)) ? g_zero_entry : a;
+#endif
             for (;;) {
                 // one round = up to Q_CAP prepared records (a column with more, < 1 % of them, updates its row once per round)
                 double h0_ = 0.0, l0_ = 0.0, h1_ = 0.0, l1_ = 0.0;
-#ifndef Q_NOFLUSH
-                h0_ = a[0]; l0_ = a[1]; h1_ = a[2]; l1_ = a[3];     // requested before the records are prepared and reduced
+#if !defined(Q_NOFLUSH) && !defined(Q_STORE)
+                h0_ = la[0]; l0_ = la[1]; h1_ = la[2]; l1_ = la[3];     // requested before the records are prepared and reduced
+                la = a;                                                 // (a second round of the same column finds the first one's sums)
 #endif
                 prepare(m0, 0);
                 int fill = set_n;
@@ -1453,8 +1474,10 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 }
                 asm volatile("" :: "v"(h0_), "v"(l0_), "v"(h1_), "v"(l1_) : "memory");
                 bool first = false;
-#ifdef Q_NOFLUSH
+#if defined(Q_NOFLUSH)
                 if (fl_ && a_sh == 1.2345e300 && a_cl == 7.7e-300) W.acc[0] = a_sh + a_sl + a_ch + a_cl;
+#elif defined(Q_STORE)
+                if (fl_) { a[0] = a_sh; a[1] = a_sl; a[2] = a_ch; a[3] = a_cl; }
 #else
                 if (fl_) {
                     first = (h1_ == 0.0);
@@ -1501,24 +1524,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
         const int G = uniform(A.unit_G[unit]);
         const int row = uniform(A.unit_row[unit]);
         if (row < 0) {
-            W.acc = A.acc + (size_t)slot * A.U * 4;
+            W.acc = A.acc + (size_t)slot * (size_t)A.row_stride * 4;
             W.touched = A.touched + (size_t)slot * A.U;
         } else {
             W.acc = A.hacc + (size_t)row * A.U * 4;
             W.touched = A.htouched + (size_t)row * A.U;
         }
         W.nt = 0;
-        int ent = 0;  // work entries of a start: role T; per head its (t,s) part; per (64-head batch, column range) the tiles
-        if (A.flags[start] & 2) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
+        // work entries of a start, numbered: role T; per head its (t,s) part; per (64-head batch, column range) the tiles.
+        // The tiles are walked FIRST (the numbering is what deals the entries to the G units of a heavy start, not the
+        // order): while the first head batch runs nothing else has touched the unit's row, which is what lets the home
+        // ends of a column be stored without a load (heads_Q); sums are exact, so the order does not show in the result.
+        const bool role_t = (A.flags[start] & 2) != 0;
+        const long long r0 = uniform((int)A.rnn_ptr[start]), r1 = uniform((int)A.rnn_ptr[start + 1]);
+        const int self = (A.cls[start] == 2) ? 1 : 0;   // head 0 = the start itself (target_path, extender.py:160-163)
+        const long long nH = self + (r1 - r0);          // heads >= self: start in NN(x') (longest_path, :164-167)
+        const long long nbatch = (nH + 63) / 64;
+        const int RX = (nbatch > 0) ? (int)((G + nbatch - 1) / nbatch) : 1;   // column ranges: nbatch * RX >= G entries
+        const int n_nb = B.n_nb;
+        long long ent = (role_t ? 1 : 0) + nH;
+        for (long long bt = 0; bt < nbatch; bt++)
+            for (int rx = 0; rx < RX; rx++) {
+                if (G == 1 || ent % G == c) {
+                    const int xlo = (rx == 0) ? 0 : B.nb_list[(long long)rx * n_nb / RX];
+                    const int xhi = (rx == RX - 1) ? 0x7fffffff : B.nb_list[(long long)(rx + 1) * n_nb / RX];
+                    heads_Q<FASTDIV>(B, W, start, bt * 64, nH, self, xlo, xhi, bt == 0);
+                }
+                ent++;
+            }
+        ent = 0;
+        if (role_t) {   // role T: non-joint paths from t = start (final_nonjoint_extend, extender.py:124-140,:180)
             if (G == 1 || ent % G == c) {
                 Carry none; none.sm = 0; none.mu = 0; none.c = 0;
                 through_t(A, W, start, false, none);
             }
             ent++;
         }
-        const long long r0 = uniform((int)A.rnn_ptr[start]), r1 = uniform((int)A.rnn_ptr[start + 1]);
-        const int self = (A.cls[start] == 2) ? 1 : 0;   // head 0 = the start itself (target_path, extender.py:160-163)
-        const long long nH = self + (r1 - r0);          // heads >= self: start in NN(x') (longest_path, :164-167)
         for (long long h = 0; h < nH; h++) {
             if (G == 1 || ent % G == c) {
                 const bool has_e1 = h >= self;
@@ -1530,18 +1571,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
             }
             ent++;
         }
-        const long long nbatch = (nH + 63) / 64;
-        const int RX = (nbatch > 0) ? (int)((G + nbatch - 1) / nbatch) : 1;   // column ranges: nbatch * RX >= G entries
-        const int n_nb = B.n_nb;
-        for (long long bt = 0; bt < nbatch; bt++)
-            for (int rx = 0; rx < RX; rx++) {
-                if (G == 1 || ent % G == c) {
-                    const int xlo = (rx == 0) ? 0 : B.nb_list[(long long)rx * n_nb / RX];
-                    const int xhi = (rx == RX - 1) ? 0x7fffffff : B.nb_list[(long long)(rx + 1) * n_nb / RX];
-                    heads_Q<FASTDIV>(B, W, start, bt * 64, nH, self, xlo, xhi);
-                }
-                ent++;
-            }
 #ifdef EXP_NOFIN     // (ablation, profiles/tools/a_variants.sh with FILE=stage_b: no finalisation -- wrong results, timing only)
         if (row < 0) cand_total += W.nt;
 #else
@@ -1568,20 +1597,35 @@ __global__ __launch_bounds__(256) void k_edge_ranges(long long n, const double *
 }
 
 // the ends of every column x (non-bridge record): x itself, then NN(x) in list order, as 32-byte records
+// home column of every end = the lowest column x whose end list {x} + NN(x) holds it (home[] preset to INT_MAX)
+__global__ __launch_bounds__(256) void k_col_home(int n_nb, int k, const int *nb_list, const int *kcnt, const int *kcol, int *home) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_nb * (k + 1)) return;
+    const int xid = (int)(t / (k + 1)), idx = (int)(t % (k + 1));
+    const int x = nb_list[xid];
+    int e = -1;
+    if (idx == 0) e = x;
+    else if (idx - 1 < kcnt[(size_t)x * 2 + 1]) e = kcol[((size_t)x * 2 + 1) * k + (idx - 1)];
+    if (e >= 0) atomicMin(&home[e], x);
+}
+
 __global__ __launch_bounds__(256) void k_col_ends(int n_nb, int k, const int *nb_list, const int *kcnt, const int *kcol, const double *kval,
-                                                  const int *urank, ColEnd *cend) {
+                                                  const int *urank, const int *home, ColEnd *cend) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n_nb * (k + 1)) return;
     const int xid = (int)(t / (k + 1)), idx = (int)(t % (k + 1));
     const int x = nb_list[xid];
     ColEnd e;
     e.sm = 0.0; e.mu = 0.0; e.f = 1.0; e.u = -1; e.pad = 0;
-    if (idx == 0) e.u = urank[x];
+    int item = -1;
+    if (idx == 0) item = x;
     else if (idx - 1 < kcnt[(size_t)x * 2 + 1]) {
         const size_t o = ((size_t)x * 2 + 1) * k + (idx - 1);
         const double v = kval[o * 3], m = kval[o * 3 + 1];
-        e.sm = v * m; e.mu = m; e.f = kval[o * 3 + 2]; e.u = urank[kcol[o]];
+        e.sm = v * m; e.mu = m; e.f = kval[o * 3 + 2];
+        item = kcol[o];
     }
+    if (item >= 0) e.u = urank[item] | (home[item] == x ? END_HOME : 0);      // (the ends of a column are distinct items)
     cend[t] = e;
 }
 
@@ -1921,7 +1965,7 @@ static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items
         A.n_cand = n_cand; A.top_end = top_end; A.top_val = top_val;
         A.xs_cap = xs_cap; A.xs_off = (long long *)xs_off; A.xs_end = xs_end; A.xs_val = xs_val;
         A.counters = (unsigned long long *)d_counters;
-        A.U = n_items; A.urank = nullptr; A.uitem = nullptr;
+        A.U = n_items; A.urank = nullptr; A.uitem = nullptr; A.row_stride = n_items;
         int slots = n_slots < n_units ? n_slots : n_units;
         A.n_slots = slots;
         if (mid) {
@@ -2187,13 +2231,24 @@ int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_uni
         A.n_slots = R->n_slots < Un->n_units ? R->n_slots : Un->n_units;
         B.nb_id = T->nb_id; B.nb_list = T->nb_list; B.n_nb = T->n_nb; B.midX = (const MidX *)T->midX; B.dir = (const MidDir *)T->dir;
         B.dir_ptr = (const long long *)T->dir_ptr; B.ng = nullptr;
+        A.row_stride = T->n_ends;
+#ifdef Q_STORE      // ablation build: rows of one slot per (column, end); the caller sizes the rows (XMAP_ABL_ROW_ENTRIES)
+        if (const char *env = getenv("XMAP_ABL_ROW_ENTRIES")) A.row_stride = atoll(env);
+        XM_ARG(A.row_stride >= (long long)T->n_nb * (T->top_k + 1) && A.row_stride >= T->n_ends);
+#endif
         ColEnd *cend = nullptr;
+        int *home = nullptr;
         if (T->n_nb > 0) {
             const long long n = (long long)T->n_nb * (T->top_k + 1);
             XM_HIP(xm_malloc_async((void **)&cend, sizeof(ColEnd) * (size_t)n, st));
-            k_col_ends<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(T->n_nb, T->top_k, T->nb_list, T->kcnt, T->kcol, T->kval,
-                                                                                 T->urank, cend);
+            XM_HIP(xm_malloc_async((void **)&home, sizeof(int) * (size_t)T->n_items, st));
+            XM_HIP(hipMemsetAsync(home, 0x7f, sizeof(int) * (size_t)T->n_items, st));
+            const dim3 cgrid((unsigned)((n + 255) / 256));
+            k_col_home<<<cgrid, dim3(256), 0, st>>>(T->n_nb, T->top_k, T->nb_list, T->kcnt, T->kcol, home);
             XM_LAUNCH_CHECK();
+            k_col_ends<<<cgrid, dim3(256), 0, st>>>(T->n_nb, T->top_k, T->nb_list, T->kcnt, T->kcol, T->kval, T->urank, home, cend);
+            XM_LAUNCH_CHECK();
+            XM_HIP(xm_free_async(home, st));
         }
         B.cend = cend;
         const dim3 grid((unsigned)((A.n_slots + 3) / 4)), block(256);

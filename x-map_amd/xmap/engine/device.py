@@ -975,7 +975,8 @@ class Engine(object):
         slot_budget = int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "120")) * (1 << 30))
         n_slots = int(os.environ.get("XMAP_N_SLOTS", n_slots))
         n_slots = int(max(4, min(n_slots, slot_budget // (36 * nU), max(U.n_units, 4))))
-        acc = self._zero_scratch("qacc", n_slots * nU * 4, torch.float64)
+        abl = int(os.environ.get("XMAP_ABL_ROW_ENTRIES", "0"))     # (ablation builds of k_paths4 with longer rows, -DQ_STORE)
+        acc = self._zero_scratch("qacc", n_slots * max(nU, abl) * 4, torch.float64)
         touched = self._empty(n_slots * nU, torch.int32)
         hacc = self._zero_scratch("qhacc", max(U.n_rows, 1) * nU * 4, torch.float64) if U.n_rows else None
         htouched = self._empty(max(U.n_rows, 1) * nU, torch.int32) if U.n_rows else None

@@ -6,13 +6,13 @@ computed for a share of the items and all-gathered (32 B x I: the all-gather of 
 set from them; the work units (item, partition) of the pair kernel are split into contiguous ranges of
 equal rater-steps and the heavy rows dealt round-robin; each rank appends the kept pairs of its units to a half COO (every
 unordered pair is owned by exactly one unit, so there are no cross-GPU partials) and mirrors them into a CSR of its own:
-that is the rank's partition of item2item_simRDD (both directions of its pairs), and where stage A ends.  Stage B starts with the exchange its input needs (the reference
-broadcasts the knn tables, utils/assist.py:88-101): the per-item row counts are all-reduced, the COO parts
-all-gathered (S4/S6 of SURVEY 2.3) and every rank mirrors the full COO into the CSR; then
-every rank classifies the top-k lists of a share of the rows and the knn tables are all-gathered (S7; round 1 rebuilt them
-everywhere), the reverse and middle lists are still derived on every rank, the path enumeration is sharded by start item
-(ranges of equal path counts), and the
-fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
+that is the rank's partition of item2item_simRDD (both directions of its pairs), and where stage A ends.  Stage B starts
+with the exchange its input needs (the reference broadcasts the knn tables, utils/assist.py:88-101): the per-item row
+counts are all-reduced, the kept pairs travel as packed 24-byte records (S4/S6 of SURVEY 2.3) and every rank mirrors only
+ITS SHARE of the rows into the CSR (contiguous row shares of equal entries); it classifies the top-k lists of those rows
+and the knn tables are all-gathered (S7), the three reverse adjacencies are built in the same row shares and all-gathered
+(S8/S9), the middle lists are derived on every rank, the path enumeration is sharded by start item (ranges of equal path
+counts), and the fixed-size per-start candidate arrays are combined with an all-reduce (S7/S10).  Stage C is a few HBM
 passes over nnz and is replicated.
 
 run_step_users is the other split (inputs sharded by USER, the partial similarities of a pair exchanged and added up at
