@@ -458,6 +458,9 @@ int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I
 int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *U, const xmap_path_rows *R,
                       const xmap_path_out *O, int fast_div, int64_t *d_counters /*[8] device*/,
                       int64_t *h_counters /*[8]: candidates, paths, -, -, row updates (read-modify-writes of row entries)*/);
+/* accumulator rows xmap_extend_cols can keep busy: one per wavefront resident on the device (compute units x SIMDs x the
+ * kernel's waves per SIMD); what a caller sizes xmap_path_rows.n_slots with (more rows are never touched). */
+int xmap_extend_cols_slots(int32_t *h_n_slots);
 
 /* ---- planning steps of stage B (round 1 did these with torch ops on the device) ----------------------------------
  * xmap_nb_index : nb_list = the non-bridge records (cls == 2) in item order, nb_id[item] = position in it or -1.

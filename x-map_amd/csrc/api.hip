@@ -427,8 +427,10 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
         T.n_ends = (int32_t)n_ends; T.urank = urank; T.uitem = uitem;
         len = n_ends > 0 ? n_ends : 1;
     }
-    // work units; accumulator rows: one per resident wavefront (5 per SIMD on 256 CUs), capped by 24 GB
-    int64_t n_slots = 5120;
+    // work units; accumulator rows: one per resident wavefront (xmap_extend_cols_slots), capped by 24 GB
+    int32_t resident = 0;
+    XM_TRY(xmap_extend_cols_slots(&resident));
+    int64_t n_slots = resident;
     const int64_t slot_cap = ((int64_t)24 << 30) / (36 * len);
     if (n_slots > slot_cap) n_slots = slot_cap > 4 ? slot_cap : 4;
     const int64_t max_rows = ((int64_t)16 << 30) / (36 * len) > 2 ? ((int64_t)16 << 30) / (36 * len) : 2;

@@ -1256,6 +1256,11 @@ struct QAcc {
     double *acc; int *touched;             // the unit's row [U][4] and touched list [U]
     const int *urank;
     int nt;
+    bool slot_rows;                        // (-DQ_STORE ablation: this unit's row has one slot per (column, end))
+    double *junk;                          // 64 bytes nobody reads: where the lanes without an update store (heads_P)
+#ifdef P_TRACE                             // (profiling build: shader cycles per segment of the column loop, summed per wave)
+    unsigned long long pt[12], pt_last;
+#endif
     unsigned long long paths;
     unsigned long long updates;            // read-modify-writes of row entries (the kernel's bound: DESIGN.md 4)
     __device__ __forceinline__ void add(bool active, int end, Carry p) {
@@ -1286,6 +1291,13 @@ struct QAcc {
 // comes by -- the update of a home end needs no load from the row: its lanes read this one cached line instead (the add
 // of zero is exact, `first` comes out true by itself), and what the memory system sees is a store.
 __device__ double g_zero_entry[4] = {0.0, 0.0, 0.0, 0.0};
+__device__ double g_junk[8192][8];        // per wave slot (heads_P): target of the lanes that have nothing to store
+#ifdef P_TRACE
+__device__ unsigned long long g_ptrace[16];
+#define PT(i) { const unsigned long long t_ = clock64(); W.pt[i] += t_ - W.pt_last; W.pt_last = t_; }
+#else
+#define PT(i)
+#endif
 constexpr int END_HOME = 1 << 30;
 
 template <bool FASTDIV>
@@ -1413,8 +1425,9 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             const int eu = eur & (END_HOME - 1);
             const double sm5 = L.e_sm[q], mu5 = L.e_mu[q], f5 = L.e_f[q];
             const bool fl_ = ok && slice == 0;
-#ifdef Q_STORE      // (ablation: every (column, end) a slot of its own -- a column visit is one contiguous run of stores, no load)
-            double *a = W.acc + ((size_t)rl32(cur.pad, first_l) * (k + 1) + (size_t)(b + q)) * 4;
+#ifdef Q_STORE      // (ablation: every (column, end) a slot of its own -- a column visit is one contiguous run of stores, no load;
+            //  the rows of the split heavy starts keep their U entries: the usual place there)
+            double *a = W.acc + (W.slot_rows ? ((size_t)rl32(cur.pad, first_l) * (k + 1) + (size_t)(b + q)) : (size_t)(ok ? eu : 0)) * 4;
 #else
             double *a = W.acc + (size_t)(ok ? eu : 0) * 4;
 #endif
@@ -1426,7 +1439,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             for (;;) {
                 // one round = up to Q_CAP prepared records (a column with more, < 1 % of them, updates its row once per round)
                 double h0_ = 0.0, l0_ = 0.0, h1_ = 0.0, l1_ = 0.0;
-#if !defined(Q_NOFLUSH) && !defined(Q_STORE)
+#if !defined(Q_NOFLUSH) && !defined(Q_STORE) && !defined(Q_STOREU)
                 h0_ = la[0]; l0_ = la[1]; h1_ = la[2]; l1_ = la[3];     // requested before the records are prepared and reduced
                 la = a;                                                 // (a second round of the same column finds the first one's sums)
 #endif
@@ -1476,7 +1489,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 bool first = false;
 #if defined(Q_NOFLUSH)
                 if (fl_ && a_sh == 1.2345e300 && a_cl == 7.7e-300) W.acc[0] = a_sh + a_sl + a_ch + a_cl;
-#elif defined(Q_STORE)
+#elif defined(Q_STORE) || defined(Q_STOREU)    // (Q_STOREU: the usual scattered places, stores only)
                 if (fl_) { a[0] = a_sh; a[1] = a_sl; a[2] = a_ch; a[3] = a_cl; }
 #else
                 if (fl_) {
@@ -1504,8 +1517,348 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     }
 }
 
+#ifdef Q_PIPE
+// ---- the column loop of k_paths4, software-pipelined (round 4; -DQ_PIPE: measured, NOT the default) ----------------------
+// The hypothesis it was built on (profiles/r04a_paths_row_ablations.txt: 329 ms without any row access, + 49 ms for the row
+// loads, + 73 ms for the scattered row stores, + 75 ms for the finalisation -- the parts ADD UP; removing 45 % of the row
+// loads outright bought nothing): the serial chain of a wave.  A column of heads_Q is three DEPENDENT memory trips --
+// directory entry of the advanced heads -> {end records, merged records} -> row entries -- plus the acknowledgement of
+// its row stores, which the next column's first wait also waits for (vmcnt retires loads and stores in issue order).
+// RESULT (profiles/r04b_paths_pipelined.txt): the trips ARE hidden -- a wave of this loop waits 2.0 % of its time for the
+// end records, 1.4 % for the directory entries, 0.2 % for the row entries (-DP_TRACE, profiles/tools/trace_p.py) -- and the
+// kernel takes as long as before: 539-544 ms at four waves per SIMD against 526 ms for heads_Q at five on the same box.
+// What the stamps show instead is waves queueing to ISSUE their vector-memory instructions (14.8 % of a wave's time for
+// the eight loads of a fetch, 9.8 % for a flush): the limit is work, not latency -- per column and CU about 375 cycles
+// of vector ALU issue and about 450 cycles of the CU's memory path (profiles/ta_rate.hip, ta_rate2.hip: ~5 cycles per
+// distinct 128-byte line of an instruction, whatever its width: the 15 row lines a column loads and stores again are
+// 40 % of it), out of the 740 the kernel takes; the two pipes overlap poorly with 16-20 waves per CU.  Hence neither
+// latency hiding nor occupancy moves the kernel, only fewer instructions / lines per column do.  Kept as the evidence.
+// How the trips of consecutive columns overlap here:
+//   * the advance of the heads that take part in column i+1 is requested when column i+1 is fetched, and consumed one
+//     column later (nxt): a whole column of time;
+//   * column i+1 -- merge step, lane assignment of its first set of records, its end records and those records -- is
+//     fetched before the record loop of column i runs, and consumed at the top of the next iteration;
+//   * the row entries of column i are requested at the top of its iteration as before; its stores are issued behind
+//     the loads of column i+1, so no wait on the chain includes their acknowledgement.
+// Every load is unconditional (clamped index; lanes without an advance read directory entry 0) and is consumed at one
+// unconditional place.  A column whose records do not fit one set of 64, or with more than 64 ends (top_k > 63), is
+// worked through synchronously as in heads_Q and the next column is fetched after it (< 1 % of the columns).
+// The first column is peeled (body() is inlined twice): at the loop header the compiler merges the counter state of the
+// entry with that of the back edge, and an entry without the stores of a previous column would turn the counted
+// waits of the steady state into waits for those stores.
 template <bool FASTDIV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_WAVES))) void k_paths4(Path2Args B) {
+__device__ __forceinline__ void heads_P(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi,
+                                        bool fresh) {
+    __shared__ QLds stagep[4];          // one per wave of the block; DS operations of a wave execute in order
+    const PathArgs &A = B.P;
+    QLds &L = stagep[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int k = A.k;
+    const int INF = 0x7fffffff;
+    // this lane's head
+    const long long h = h0 + lane;
+    const bool hv = h < nH;
+    double sm1 = 0.0, mu1 = 0.0, f1 = 1.0;
+    bool has_e1 = false;
+    long long dpos = 0, dend = 0;
+    if (hv) {
+        int xp = start;
+        if (h >= self) {
+            const long long rp = A.rnn_ptr[start] + (h - self);
+            xp = A.rnn_idx[rp];
+            const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1];
+            sm1 = sv * mu; mu1 = mu; f1 = A.rnn_val[rp * 3 + 2];
+            has_e1 = true;
+        }
+        const int xpid = B.nb_id[xp];
+        dpos = B.dir_ptr[xpid];
+        dend = B.dir_ptr[xpid + 1];
+        if (xlo > 0) {   // lower bound of xlo in this head's directory (sorted by x)
+            long long lo = dpos, hi = dend;
+            while (lo < hi) {
+                long long mid = (lo + hi) >> 1;
+                if (B.dir[mid].x < xlo) lo = mid + 1; else hi = mid;
+            }
+            dpos = lo;
+        }
+    }
+    MidDir cur;
+    cur.x = INF; cur.ne = 0; cur.cnt = 0; cur.pad = 0; cur.off = 0;
+    if (hv && dpos < dend) { cur = B.dir[dpos]; if (cur.x >= xhi) cur.x = INF; }
+    const int nloc = (nH - h0) < 64 ? (int)(nH - h0) : 64;      // heads of this batch (lanes 0 .. nloc-1)
+
+    // smallest column among the heads (wave-uniform result)
+    auto col_min = [&](int xmin) -> int {
+#define XM_DPP_MIN(CTRL) { const int o = __builtin_amdgcn_update_dpp(INF, xmin, CTRL, 0xf, 0xf, false); xmin = o < xmin ? o : xmin; }
+#define XM_SWZ_MIN(PAT) { const int o = __builtin_amdgcn_ds_swizzle(xmin, PAT); xmin = o < xmin ? o : xmin; }
+        if (nloc <= 16) {      // the common batch of a few heads: DPP inside the first row of lanes, no LDS round trips
+            XM_DPP_MIN(0xB1) XM_DPP_MIN(0x4E)                               // quad_perm [1,0,3,2], [2,3,0,1]
+            if (nloc > 4) { XM_DPP_MIN(0x141) XM_DPP_MIN(0x140) }           // row_half_mirror, row_mirror
+            xmin = rl32(xmin, 0);
+        } else {
+            XM_SWZ_MIN(0x041F) XM_SWZ_MIN(0x081F) XM_SWZ_MIN(0x101F) XM_SWZ_MIN(0x201F) XM_SWZ_MIN(0x401F)
+            const int x0 = rl32(xmin, 0), x1 = rl32(xmin, 32);
+            xmin = x0 < x1 ? x0 : x1;
+        }
+#undef XM_SWZ_MIN
+#undef XM_DPP_MIN
+        return xmin;
+    };
+
+    // ---- lane assignment of record sets.  k_cnt / k_off: the tiles of the participating heads of the column whose sets
+    // are being dealt (a snapshot of cur taken when the column was fetched: cur itself moves on)
+    int k_cnt = 0;
+    long long k_off = 0;
+    unsigned long long pm = 0;       // participating heads with records not yet dealt
+    int pos = 0;                     // records of the first of them already dealt
+    int set_n = 0, my_h = 0;
+    long long my_rec = 0;
+    // a set = up to 64 records, one per lane, of whichever participating head the lane falls to
+    auto assign = [&]() {
+        set_n = 0; my_h = 0;
+        my_rec = rl64(k_off, __ffsll((long long)pm) - 1);     // lanes beyond the set: any record
+        for (;;) {
+            // (pm, pos and set_n are wave-uniform; said explicitly, or the loop is compiled as a divergent one)
+            pm = ((unsigned long long)(unsigned)uniform((int)(pm >> 32)) << 32) | (unsigned)uniform((int)pm);
+            pos = uniform(pos); set_n = uniform(set_n);
+            if (pm == 0 || set_n >= 64) break;
+            const int l = __ffsll((long long)pm) - 1;
+            const int cnt = rl32(k_cnt, l);
+            const long long off = rl64(k_off, l);
+            int n = cnt - pos;
+            if (n > 64 - set_n) n = 64 - set_n;
+            if (lane >= set_n && lane < set_n + n) { my_rec = off + pos + (lane - set_n); my_h = l; }
+            set_n += n; pos += n;
+            if (pos == cnt) { pm &= pm - 1; pos = 0; }
+        }
+    };
+    // prepared form of a record: first edge of its head (from the head's lane) + the three middle edges
+    auto prepare = [&](const MidX &m, int fill) {
+        const bool he1 = __shfl((int)has_e1, my_h, 64) != 0;
+        const double hsm1 = __shfl(sm1, my_h, 64), hmu1 = __shfl(mu1, my_h, 64), hf1 = __shfl(f1, my_h, 64);
+        asm volatile("" :: "v"(m.sm2), "v"(m.sm3), "v"(m.sm4), "v"(m.f2), "v"(m.f3), "v"(m.f4), "v"(m.mu));
+        double bsm, bc;
+        if (he1) { bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4; bc = ((hf1 * m.f2) * m.f3) * m.f4; }
+        else { bsm = (m.sm2 + m.sm3) + m.sm4; bc = (m.f2 * m.f3) * m.f4; }
+        const double bmu = m.mu + (he1 ? hmu1 : 0.0);
+        if (lane < set_n) { L.bsm[fill + lane] = bsm; L.bc[fill + lane] = bc; L.bmu[fill + lane] = bmu; }
+    };
+
+    // ---- the column that has been fetched (and, once body() has taken its scalars, the one in work)
+    bool have = false;
+    unsigned long long part = 0;
+    int ne = 0, col = 0;
+    ColEnd e;                        // end record of this lane (first 64 ends)
+    MidX m0;                         // this lane's record of the first set
+    e.sm = 0.0; e.mu = 0.0; e.f = 1.0; e.u = -1; e.pad = 0;
+    m0.sm2 = m0.sm3 = m0.sm4 = m0.f2 = m0.f3 = m0.f4 = m0.mu = 0.0; m0.xid = 0; m0.pad = 0;
+    MidDir nxt = cur;                // the advanced heads' next directory entry, requested with the column, used a column later
+    bool adv = false, took = false;
+    // Fetch the next column: complete the advance requested a column ago, merge step, first set of records, loads.
+    // The loads are issued whether or not a column is left (valid dummy addresses): one shape of the memory-operation
+    // queue on every path is what keeps the compiler's counted waits counted.
+    auto fetch = [&]() {
+        PT(7)
+        if (adv) { cur = nxt; if (cur.x >= xhi) cur.x = INF; }      // (selects: the one place nxt is consumed)
+        else if (took) cur.x = INF;
+#ifdef P_TRACE
+        asm volatile("" : "+v"(cur.x), "+v"(cur.cnt));
+#endif
+        PT(8)
+        const int xmin = col_min(cur.x);
+        have = xmin != INF;
+        const bool mine = have && cur.x == xmin;
+        part = __ballot(mine);
+        const int fl = have ? __ffsll((long long)part) - 1 : 0;
+        ne = rl32(cur.ne, fl);
+        col = rl32(cur.pad, fl);
+        if (!have) { ne = 1; col = 0; }
+        k_cnt = cur.cnt; k_off = have ? cur.off : 0;
+        pm = part; pos = 0;
+        set_n = 0; my_h = 0; my_rec = 0;
+        if (have) assign();
+        PT(9)
+        m0 = B.midX[my_rec];
+        e = (B.cend + (size_t)col * (k + 1))[(lane < ne) ? lane : ne - 1];      // one 32-byte record per end (k_col_ends)
+        took = mine;
+        adv = mine && (dpos + 1 < dend);
+        if (mine) dpos++;
+        nxt = B.dir[adv ? dpos : 0];
+        PT(10)
+    };
+
+    auto body = [&]() {
+        // the column in work takes its scalars out of the fetch state
+        const int c_ne = uniform(ne), c_col = uniform(col);
+        const unsigned long long c_part = ((unsigned long long)(unsigned)uniform((int)(part >> 32)) << 32) | (unsigned)uniform((int)part);
+        const ColEnd *ce = B.cend + (size_t)c_col * (k + 1);
+        const int b_last = ((c_ne - 1) >> 6) << 6;       // first end of the last chunk of 64 ends (0 unless top_k > 63)
+        // ---- the chunk of ends in work: lanes = ends x record slices
+        int nact = 0, sh = 0, slice = 0, eu = 0;
+        bool ok = false, fl_ = false;
+        double sm5 = 0.0, mu5 = 0.0, f5 = 1.0;
+        double *a = W.acc;
+        const double *la = W.acc;
+        auto ends_ctx = [&](int b) {
+            nact = (c_ne - b) < 64 ? (c_ne - b) : 64;
+            sh = nact <= 16 ? 2 : (nact <= 32 ? 1 : 0);     // log2 of the record slices per end
+            const int q = lane >> sh;
+            slice = lane & ((1 << sh) - 1);
+            // ends: natural layout -> LDS -> (end, slice) layout
+            {
+                int eu_ = e.u;
+                asm volatile("" : "+v"(eu_));          // (keeps the select below, and with it the wait for e, down here)
+                L.e_u[lane] = (b + lane < c_ne) ? eu_ : -1; L.e_sm[lane] = e.sm; L.e_mu[lane] = e.mu; L.e_f[lane] = e.f;
+            }
+            asm volatile("" ::: "memory");
+            const int eur = L.e_u[q];
+            ok = eur >= 0;
+            eu = eur & (END_HOME - 1);
+            sm5 = L.e_sm[q]; mu5 = L.e_mu[q]; f5 = L.e_f[q];
+            fl_ = ok && slice == 0;
+            a = W.acc + (size_t)(ok ? eu : 0) * 4;
+#ifdef Q_NOHOME
+            la = a;
+#else
+            la = (ok && fresh && (eur & END_HOME)) ? g_zero_entry : a;
+#endif
+        };
+        // the row entries of the chunk's ends and the prepared records of one round (up to Q_CAP: a column with more,
+        // < 1 % of them, updates its row once per round)
+        double h0_ = 0.0, l0_ = 0.0, h1_ = 0.0, l1_ = 0.0;
+        int fill = 0;
+        auto round_in = [&]() {
+            h0_ = la[0]; l0_ = la[1]; h1_ = la[2]; l1_ = la[3];     // requested before the records are prepared and reduced
+            la = a;                                                 // (a second round of the same ends finds the first one's sums)
+            prepare(m0, 0);
+            fill = set_n;
+            while (pm && fill < Q_CAP) {
+                assign();
+                const MidX m = B.midX[my_rec];
+                prepare(m, fill);
+                fill += set_n;
+            }
+            asm volatile("" ::: "memory");
+        };
+        // record loop, slices added up, ONE update of the row
+        auto round_out = [&]() {
+            double a_sh = 0.0, a_sl = 0.0, a_ch = 0.0, a_cl = 0.0;
+            const int steps = (fill + (1 << sh) - 1) >> sh;
+            for (int it = 0; it < steps; it++) {
+                const int r = (it << sh) + slice;
+                if (ok && r < fill) {
+                    const double sm = L.bsm[r] + sm5;
+                    const double c = L.bc[r] * f5;
+                    const double mu = L.bmu[r] + mu5;
+                    double sp;
+                    if (FASTDIV) sp = div_mid(sm, mu);
+                    else sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;      // calculate_path_confidence (extender.py:83-89)
+                    acc2(a_sh, a_sl, sp * c);
+                    acc2(a_ch, a_cl, c);
+                }
+            }
+            // the slices of an end sit in adjacent lanes
+            if (sh >= 1) {
+                const double o_sh = quad_swap<0xB1>(a_sh), o_sl = quad_swap<0xB1>(a_sl);      // lane ^ 1
+                const double o_ch = quad_swap<0xB1>(a_ch), o_cl = quad_swap<0xB1>(a_cl);
+                acc2(a_sh, a_sl, o_sh); a_sl += o_sl;
+                acc2(a_ch, a_cl, o_ch); a_cl += o_cl;
+            }
+            if (sh == 2) {
+                const double o_sh = quad_swap<0x4E>(a_sh), o_sl = quad_swap<0x4E>(a_sl);      // lane ^ 2
+                const double o_ch = quad_swap<0x4E>(a_ch), o_cl = quad_swap<0x4E>(a_cl);
+                acc2(a_sh, a_sl, o_sh); a_sl += o_sl;
+                acc2(a_ch, a_cl, o_ch); a_cl += o_cl;
+            }
+            PT(4)
+            asm volatile("" :: "v"(h0_), "v"(l0_), "v"(h1_), "v"(l1_) : "memory");
+            PT(5)
+            // (every lane adds; the lanes that own an end store: the masked region is the stores alone, so that no
+            //  skip branch -- a second path with a different number of queued stores -- appears around them)
+            const bool first = fl_ && (h1_ == 0.0);
+            acc2(h0_, l0_, a_sh); l0_ += a_sl;
+            acc2(h1_, l1_, a_ch); l1_ += a_cl;
+            const unsigned long long fm = __ballot(first);
+            // The stores are UNCONDITIONAL: lanes without an update write the wave's junk entry (one address: one
+            // request).  A masked store would sit behind a skip branch (the compiler keeps `s_cbranch_execz` around
+            // vector-memory instructions), i.e. two paths with different numbers of queued stores, and the counted
+            // waits of the next column would fall back to the smaller count -- to waiting for these stores.
+            double *dst = fl_ ? a : W.junk;
+            int *tp = first ? W.touched + (W.nt + __popcll(fm & lanemask_lt())) : (int *)W.junk + 8;
+            dst[0] = h0_; dst[1] = l0_; dst[2] = h1_; dst[3] = l1_;
+            *tp = eu;
+            W.nt += __popcll(fm);
+            W.paths += (unsigned long long)fill * (unsigned long long)nact;
+            W.updates += (unsigned long long)nact;
+        };
+        PT(0)
+        ends_ctx(0);
+        PT(1)
+        round_in();
+        PT(2)
+        if (!(pm == 0 && b_last == 0)) {
+            // every (chunk of ends, round of records) of the column but its last, one after the other (top_k > 63, or more
+            // than Q_CAP records: rare).  Kept off the common path: a loop around round_in() would merge this side's
+            // counter state into the common one at its header.
+            int b = 0;
+            do {
+                round_out();
+                if (pm == 0) {
+                    b += 64;
+                    e = ce[(b + lane < c_ne) ? b + lane : c_ne - 1];
+                    pm = c_part; pos = 0;
+                    assign();
+                    m0 = B.midX[my_rec];
+                    ends_ctx(b);
+                } else {
+                    assign();
+                    m0 = B.midX[my_rec];
+                }
+                // (round_in() in another order and behind opaque statements: the same code here would be merged with the
+                //  common one, and this side's counter state with it)
+                asm volatile("s_nop 0" ::: "memory");
+                prepare(m0, 0);
+                fill = set_n;
+                while (pm && fill < Q_CAP) {
+                    assign();
+                    const MidX m = B.midX[my_rec];
+                    prepare(m, fill);
+                    fill += set_n;
+                }
+                asm volatile("s_nop 0" ::: "memory");
+                h0_ = la[0]; l0_ = la[1]; h1_ = la[2]; l1_ = la[3];
+                la = a;
+                asm volatile("s_nop 0" ::: "memory");
+            } while (!(pm == 0 && b == b_last));
+        }
+        // the column's final round: the next column is fetched before its record loop -- the trips of that column run
+        // under the loop and the row update of this one
+        fetch();
+        PT(3)
+        round_out();
+        PT(6)
+    };
+
+    fetch();
+    if (have) {
+        body();
+        while (have) body();
+    }
+}
+#endif  // Q_PIPE
+
+// Waves per SIMD of k_paths4: five with the serial column loop (96 VGPRs).  The pipelined loop (-DQ_PIPE) keeps the next
+// column's end record, merged record and directory entry in registers while the current column is reduced: 126 VGPRs,
+// four waves.
+#ifndef P_WAVES
+#ifdef Q_PIPE
+#define P_WAVES 4
+#else
+#define P_WAVES 5
+#endif
+#endif
+template <bool FASTDIV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P_WAVES, P_WAVES))) void k_paths4(Path2Args B) {
     __shared__ FinBuf fin[4];
     const PathArgs &A = B.P;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1513,6 +1866,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
     const int lane = lane_id();
     QAcc W;
     W.paths = 0; W.updates = 0; W.urank = A.urank;
+    W.junk = g_junk[slot & 8191];
+#ifdef P_TRACE
+    for (int i = 0; i < 12; i++) W.pt[i] = 0;
+    W.pt_last = clock64();
+    const unsigned long long pt_begin = W.pt_last;
+#endif
     unsigned long long cand_total = 0;
     for (;;) {
         int u_ = 0;
@@ -1523,6 +1882,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
         const int c = uniform(A.unit_c[unit]);
         const int G = uniform(A.unit_G[unit]);
         const int row = uniform(A.unit_row[unit]);
+        W.slot_rows = row < 0;
         if (row < 0) {
             W.acc = A.acc + (size_t)slot * (size_t)A.row_stride * 4;
             W.touched = A.touched + (size_t)slot * A.U;
@@ -1548,7 +1908,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
                 if (G == 1 || ent % G == c) {
                     const int xlo = (rx == 0) ? 0 : B.nb_list[(long long)rx * n_nb / RX];
                     const int xhi = (rx == RX - 1) ? 0x7fffffff : B.nb_list[(long long)(rx + 1) * n_nb / RX];
+#ifdef Q_PIPE        // (the software-pipelined column loop: measured, not faster -- see the comment at heads_P)
+                    heads_P<FASTDIV>(B, W, start, bt * 64, nH, self, xlo, xhi, bt == 0);
+#else
                     heads_Q<FASTDIV>(B, W, start, bt * 64, nH, self, xlo, xhi, bt == 0);
+#endif
                 }
                 ent++;
             }
@@ -1582,6 +1946,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
         atomicAdd(&A.counters[0], cand_total);
         atomicAdd(&A.counters[1], W.paths);
         atomicAdd(&A.counters[4], W.updates);
+#ifdef P_TRACE
+        for (int i = 0; i < 12; i++) atomicAdd(&g_ptrace[i], W.pt[i]);
+        atomicAdd(&g_ptrace[12], clock64() - pt_begin);
+        atomicAdd(&g_ptrace[13], 1ull);
+#endif
     }
 }
 
@@ -1803,6 +2172,12 @@ __global__ __launch_bounds__(256) void k_w_starts(int I, const uint8_t *flags, c
 using namespace xmap;
 
 extern "C" {
+#ifdef P_TRACE
+int xmap_debug_ptrace(unsigned long long *host, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(xmap::g_ptrace), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_ptrace), 16 * sizeof(unsigned long long));
+}
+#endif
 #ifdef B_TRACE
 int xmap_debug_btrace(unsigned long long *host, long long n_units) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_btrace), (size_t)n_units * 16);
@@ -2195,6 +2570,16 @@ int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I
     if (rc) return rc;
     k_end_ranks<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, mark, (const long long *)rank, urank, uitem);
     XM_LAUNCH_CHECK();
+    return XMAP_OK;
+}
+
+int xmap_extend_cols_slots(int32_t *h_n_slots) {
+    XM_ARG(h_n_slots);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    XM_HIP(hipGetDevice(&dev));
+    XM_HIP(hipGetDeviceProperties(&prop, dev));
+    *h_n_slots = prop.multiProcessorCount * 4 * P_WAVES;
     return XMAP_OK;
 }
 

@@ -973,7 +973,12 @@ class Engine(object):
             self.end_universe(E)
         nU = max(E.n_ends, 1)
         slot_budget = int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "120")) * (1 << 30))
-        n_slots = int(os.environ.get("XMAP_N_SLOTS", n_slots))
+        if "XMAP_N_SLOTS" in os.environ:
+            n_slots = int(os.environ["XMAP_N_SLOTS"])
+        else:       # one row per wave the kernel keeps resident (4 per SIMD since round 4)
+            ns = C.c_int32(0)
+            check(lib.xmap_extend_cols_slots(C.byref(ns)))
+            n_slots = min(n_slots, int(ns.value))
         n_slots = int(max(4, min(n_slots, slot_budget // (36 * nU), max(U.n_units, 4))))
         abl = int(os.environ.get("XMAP_ABL_ROW_ENTRIES", "0"))     # (ablation builds of k_paths4 with longer rows, -DQ_STORE)
         acc = self._zero_scratch("qacc", n_slots * max(nU, abl) * 4, torch.float64)
