@@ -699,6 +699,8 @@ def main():
             "alterego_profiles_per_s": res["n_profiles"] / (t_b + t_c) if (t_b + t_c) > 0 else 0.0,
             "alterego_rows": res["n_rows"], "profiles": res["n_profiles"],
             "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,       # torch's allocations (the library's arenas: < 0.5 GB more)
+            # accumulator rows of the enumeration: one per resident wave, sized from the HBM the device can spare
+            "accumulator_rows": getattr(res["E"], "row_info", None),
             "stage_ms": {"A_item_sim": stage["stage_a"], "B_extend": stage["stage_b"], "C_generate": stage["stage_c"]},
             "kernel_ms": {n: float(np.mean(v)) for n, v in sorted(tm.items())},
             # the dominant kernel of the step (90 % of it): the path enumeration of stage B.  Its compulsory HBM bytes

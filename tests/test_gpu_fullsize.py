@@ -151,11 +151,16 @@ def test_stage_b_against_the_oracle_at_full_size(c2):
     bridge flags and the classified top-k lists of EVERY item, the attach lists derived from them, and -- for a sample
     of starts, whose paths the oracle can enumerate -- the exact path counts, the candidate counts and the ten best
     candidates with their X-Sim values, bit for bit."""
-    from oracle import xmap_oracle as xo
     r, eng = c2
-    I, k, method = r.n_items, 50, "adjust_cosine"
-    S = eng.item_sim(method, CAP)
-    E = eng.extend(S, k)
+    S = eng.item_sim("adjust_cosine", CAP)
+    E = eng.extend(S, 50)
+    stage_b_against_the_oracle(r, S, E, 50, "adjust_cosine", n_small=90, n_mid=6, at_least=40)
+
+
+def stage_b_against_the_oracle(r, S, E, k, method, n_small, n_mid, at_least):
+    """(shared with tests/test_gpu_s1.py) S, E: the engine's similarity matrix and extension of r at list length k"""
+    from oracle import xmap_oracle as xo
+    I = r.n_items
     T = xo.Train(r.user_ptr, r.item, r.rating, r.time, r.n_items, *r.item_attrs())
     So = xo.item_sim(T, method, CAP, nthreads=16)
     assert So.n_eval == S.n_eval and int(So.row_ptr[-1]) == S.n_kept
@@ -190,9 +195,9 @@ def test_stage_b_against_the_oracle_at_full_size(c2):
     rng = np.random.default_rng(11)
     small = np.nonzero((P > 0) & (P <= 2000000))[0]
     mid = np.nonzero((P > 2000000) & (P <= 30000000))[0]
-    sample = np.sort(np.concatenate([rng.choice(small, size=min(90, len(small)), replace=False),
-                                     rng.choice(mid, size=min(6, len(mid)), replace=False)]))
-    assert len(sample) >= 40
+    sample = np.sort(np.concatenate([rng.choice(small, size=min(n_small, len(small)), replace=False),
+                                     rng.choice(mid, size=min(n_mid, len(mid)), replace=False)]))
+    assert len(sample) >= at_least
     Xs = xo.extend(T, So, k, starts=sample)
     assert Xs.n_paths == int(P[sample].sum())
     n_cand = E.n_cand.cpu().numpy()[:I]

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from test_gpu_fullsize import CAP, _candidate_properties
+from test_gpu_fullsize import CAP, _candidate_properties, stage_b_against_the_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +37,10 @@ def test_s1_shape_full_size():
     assert np.array_equal(E1.top_val.cpu().numpy(), E2.top_val.cpu().numpy())
     del E2
     _candidate_properties(r, E1, I)
+    # against the CPU oracle at this shape (round 4; configs[1] has had this since round 3): bridge flags and classified
+    # top-k lists of every item, the attach lists, and a sample of starts -- exact path counts, candidate counts, the ten
+    # best candidates and their X-Sim values, bit for bit
+    stage_b_against_the_oracle(r, S, E1, 10, "adjust_cosine", n_small=40, n_mid=4, at_least=40)
     n_top, choice, mp = eng.select(E1, True)
     G = eng.alterego(mp)
     flags = r.item_attrs()[3]

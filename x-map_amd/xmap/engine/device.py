@@ -128,6 +128,14 @@ class Engine(object):
             self._scratch[name] = t
         return t
 
+    def hbm_available(self, *own):
+        """bytes this process could allocate now: free on the device + unused blocks of torch's caching allocator + the
+        scratch buffers named in `own` (about to be re-used or replaced)"""
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        cached = torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+        held = sum(t.numel() * t.element_size() for n, t in self._scratch.items() if n in own)
+        return int(free + max(cached, 0) + held)
+
     def _drop_scratch(self, *names):
         """forget persistent zero-filled scratch (after a failed pass its rows may hold partial sums)"""
         for n in names:
@@ -858,6 +866,7 @@ class Engine(object):
         lo, hi = (0, I) if start_range is None else (int(start_range[0]), int(start_range[1]))
         row_bytes = 36 * max(I, 1)
         row_budget = int(float(os.environ.get("XMAP_ROW_BUDGET_GB", row_budget / (1 << 30))) * (1 << 30))
+        row_budget = min(row_budget, int(0.15 * self.hbm_available("qhacc", "hacc")))      # (the rows of the split heavy starts)
         max_rows = max(row_budget // row_bytes, 2)
         cap_units = max(I, 1) + max_rows
         U = ExtResult()
@@ -972,7 +981,11 @@ class Engine(object):
         with self.timed("paths_prep"):
             self.end_universe(E)
         nU = max(E.n_ends, 1)
-        slot_budget = int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "120")) * (1 << 30))
+        # the accumulator rows (36 B x ends each: one per resident wave) take what the device can spare: 45 % of the HBM this
+        # process could still get (free + what its caching allocator holds unused + the rows of an earlier pass), at most
+        # XMAP_SLOT_BUDGET_GB -- fewer rows only mean fewer waves in flight (the S1 shape of the reference's report, 5.3e5
+        # ends, peaked at 129 GB with a fixed 120 GB allowance)
+        slot_budget = min(int(float(os.environ.get("XMAP_SLOT_BUDGET_GB", "120")) * (1 << 30)), int(0.45 * self.hbm_available("qacc")))
         if "XMAP_N_SLOTS" in os.environ:
             n_slots = int(os.environ["XMAP_N_SLOTS"])
         else:       # one row per wave the kernel keeps resident (4 per SIMD since round 4)
@@ -1017,6 +1030,8 @@ class Engine(object):
                 raise
             break
         E.n_out, E.n_paths, E.n_updates = int(h_cnt[0]), int(h_cnt[1]), int(h_cnt[4])
+        E.row_info = dict(n_slots=n_slots, ends=nU, slot_rows_gb=n_slots * nU * 36 / 1e9, heavy_rows=int(U.n_rows),
+                          heavy_rows_gb=int(U.n_rows) * nU * 36 / 1e9, slot_budget_gb=slot_budget / 1e9)
         E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val
         E.start_range = (0, I) if start_range is None else tuple(start_range)
         return E
