@@ -145,6 +145,27 @@ def cpu_baseline(r, attrs, method, target_s=15.0, threads=4, k=0):
                               sample="oracle extend (k=%d), source records in item order until 8 s have passed: %d paths in %.1f s, 1 thread"
                                      % (k, X.n_paths, X.path_seconds))
         xo.ext_free(X)
+        # the same on `threads` threads: disjoint ranges of source items, one oracle call each (the calls share nothing;
+        # ctypes releases the GIL), paths summed over the slowest call's enumeration time
+        import threading
+        res = [None] * threads
+        cuts = [I * t // threads for t in range(threads + 1)]
+
+        def leg(t):
+            res[t] = xo.extend(T, S, k, s_range=(cuts[t], cuts[t + 1]), max_seconds=8.0)
+        th = [threading.Thread(target=leg, args=(t,)) for t in range(threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if all(x is not None for x in res):
+            sec = max(x.path_seconds for x in res)
+            out["stage_b"]["threads"] = dict(value=sum(x.n_paths for x in res) / max(sec, 1e-9), unit="paths/s", cores=threads, kind="port",
+                                             sample="%d oracle calls side by side, each on a quarter of the source items for 8 s: %d paths in %.1f s"
+                                                    % (threads, sum(x.n_paths for x in res), sec))
+        for x in res:
+            if x is not None:
+                xo.ext_free(x)
     xo.sim_free(S)
     return out
 

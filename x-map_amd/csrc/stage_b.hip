@@ -1247,7 +1247,7 @@ __device__ __forceinline__ double quad_swap(double v) {
 //     comment in heads_Q; division and sums as in k_paths3.
 constexpr int Q_CAP = 128;                 // prepared records per round
 struct QLds {
-    double bsm[Q_CAP], bc[Q_CAP], bmu[Q_CAP];
+    double bsm[Q_CAP + 1], bc[Q_CAP + 1], bmu[Q_CAP + 1];      // (entry Q_CAP: the neutral record (0, 0, 1) of heads_Q's record loop)
     double e_sm[64], e_mu[64], e_f[64];
     int e_u[64];                           // universe rank of the end, -1 = none
 };
@@ -1312,8 +1312,10 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     // this lane's head
     const long long h = h0 + lane;
     const bool hv = h < nH;
-    double sm1 = 0.0, mu1 = 0.0, f1 = 1.0;
+    double sm1 = 0.0, mu1 = 0.0, f1 = 1.0;      // (the neutral first edge: the start itself as head)
+#ifdef Q_HE1
     bool has_e1 = false;
+#endif
     long long dpos = 0, dend = 0;
     if (hv) {
         int xp = start;
@@ -1322,7 +1324,9 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             xp = A.rnn_idx[rp];
             const double sv = A.rnn_val[rp * 3], mu = A.rnn_val[rp * 3 + 1];
             sm1 = sv * mu; mu1 = mu; f1 = A.rnn_val[rp * 3 + 2];
+#ifdef Q_HE1
             has_e1 = true;
+#endif
         }
         const int xpid = B.nb_id[xp];
         dpos = B.dir_ptr[xpid];
@@ -1344,6 +1348,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
 #else
     const int nloc = (nH - h0) < 64 ? (int)(nH - h0) : 64;      // heads of this batch (lanes 0 .. nloc-1)
 #endif
+    if (lane == 0) { L.bsm[Q_CAP] = 0.0; L.bc[Q_CAP] = 0.0; L.bmu[Q_CAP] = 1.0; }       // the neutral record of the record loop
     for (;;) {
         // smallest column among the heads: xor butterfly inside each half of the wave (ds_swizzle: no address registers),
         // then the two halves
@@ -1402,13 +1407,21 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             };
             // prepared form of a record: first edge of its head (from the head's lane) + the three middle edges
             auto prepare = [&](const MidX &m, int fill) {
-                const bool he1 = __shfl((int)has_e1, my_h, 64) != 0;
                 const double hsm1 = __shfl(sm1, my_h, 64), hmu1 = __shfl(mu1, my_h, 64), hf1 = __shfl(f1, my_h, 64);
                 asm volatile("" :: "v"(m.sm2), "v"(m.sm3), "v"(m.sm4), "v"(m.f2), "v"(m.f3), "v"(m.f4), "v"(m.mu));
+#ifdef Q_HE1        // (rounds 2-3: separate formulas for a head without a first edge, picked by a flag from the head's lane)
+                const bool he1 = __shfl((int)has_e1, my_h, 64) != 0;
                 double bsm, bc;
                 if (he1) { bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4; bc = ((hf1 * m.f2) * m.f3) * m.f4; }
                 else { bsm = (m.sm2 + m.sm3) + m.sm4; bc = (m.f2 * m.f3) * m.f4; }
                 const double bmu = m.mu + (he1 ? hmu1 : 0.0);
+#else
+                // a head without a first edge (the start itself) carries the NEUTRAL edge (0, 0, 1): 0 + x and 1 * x are exact,
+                // so one formula serves both kinds of head with the same bits (sim * mutu is never a zero: the zero filter)
+                const double bsm = ((hsm1 + m.sm2) + m.sm3) + m.sm4;
+                const double bc = ((hf1 * m.f2) * m.f3) * m.f4;
+                const double bmu = m.mu + hmu1;
+#endif
                 if (lane < set_n) { L.bsm[fill + lane] = bsm; L.bc[fill + lane] = bc; L.bmu[fill + lane] = bmu; }
             };
             assign();
@@ -1454,12 +1467,10 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 asm volatile("" ::: "memory");
                 double a_sh = 0.0, a_sl = 0.0, a_ch = 0.0, a_cl = 0.0;
                 const int steps = (fill + ns - 1) >> sh;
-#ifdef Q_NOCOMPUTE
+#if defined(Q_NOCOMPUTE)
                 if (ok && slice < fill) { a_sh = 1.0; a_ch = 1.0; }
-                for (int it = 0; it < 0; it++) {
-#else
+#elif defined(Q_STEPLOOP1)      // (the record loop of rounds 2-3: one record per iteration, lanes without a record masked)
                 for (int it = 0; it < steps; it++) {
-#endif
                     const int r = (it << sh) + slice;
                     if (ok && r < fill) {
                         const double sm = L.bsm[r] + sm5;
@@ -1472,6 +1483,38 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                         acc2(a_ch, a_cl, c);
                     }
                 }
+#else
+                // The record loop without a branch and two records per iteration (round 4).  A lane whose slice has no
+                // record in a step takes the NEUTRAL record (0, 0, 1): its path weight c = 0 * f is zero, so both sums get
+                // + 0 -- exact, no effect -- and the compare / mask / skip-branch instructions of a step are gone; lanes beyond
+                // the column's ends compute on the last end's record (never stored).  Two records per iteration: no
+                // loop-carried register copies, one LDS round trip for both.
+                auto step = [&](double rsm, double rc, double rmu) {
+                    const double sm = rsm + sm5;
+                    const double c = rc * f5;
+                    const double mu = rmu + mu5;
+                    double sp;
+                    if (FASTDIV) sp = div_mid(sm, mu);
+                    else sp = (mu != 0.0) ? 1.0 * sm / mu : 0.0;          // calculate_path_confidence (extender.py:83-89)
+                    acc2(a_sh, a_sl, sp * c);
+                    acc2(a_ch, a_cl, c);
+                };
+                int it = 0;
+                for (; it + 1 < steps; it += 2) {
+                    const int ra = (it << sh) + slice, rb = ra + ns;      // ra < fill in every step but a round's last
+                    const int rbc = rb < fill ? rb : Q_CAP;
+                    const double s0 = L.bsm[ra], c0 = L.bc[ra], u0 = L.bmu[ra];
+                    const double s1 = L.bsm[rbc], c1 = L.bc[rbc], u1 = L.bmu[rbc];
+                    asm volatile("" :: "v"(s0), "v"(c0), "v"(u0), "v"(s1), "v"(c1), "v"(u1));      // (both records: one LDS round trip)
+                    step(s0, c0, u0);
+                    step(s1, c1, u1);
+                }
+                if (it < steps) {
+                    const int ra = (it << sh) + slice;
+                    const int rc_ = ra < fill ? ra : Q_CAP;
+                    step(L.bsm[rc_], L.bc[rc_], L.bmu[rc_]);
+                }
+#endif
                 // the slices of an end sit in adjacent lanes
                 if (sh >= 1) {
                     const double o_sh = quad_swap<0xB1>(a_sh), o_sl = quad_swap<0xB1>(a_sl);      // lane ^ 1

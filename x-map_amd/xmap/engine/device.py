@@ -1331,17 +1331,25 @@ class Engine(object):
                                       vp(n_top), vp(choice), vp(mp)))
         return n_top, choice, mp
 
-    def alterego(self, mp):
+    def alterego(self, mp, users=None):
+        """build_alterEgo (core/generator.py:113-157) over all users, or over the users [users[0], users[1])"""
         R = self.R
         st = _stream(self.dev)
         U = R.n_users
+        Rc = R.c
+        if users is not None:       # a share of the users (an item-sharded rank's part of stage C): rows carry GLOBAL user indices
+            u_lo, u_hi = int(users[0]), int(users[1])
+            U = u_hi - u_lo
+            Rc = abi.Ratings.from_buffer_copy(R.c)
+            Rc.n_users = U
+            Rc.user_ptr = R.user_ptr.data_ptr() + 8 * u_lo
         cnt_t = self._empty(max(U, 1), torch.int32)
         cnt_m = self._empty(max(U, 1), torch.int32)
         if U == 0:
             cnt_t.zero_(); cnt_m.zero_()
         d_prof = self._zeros(64, torch.int64)            # sharded counter of the users with output rows
         with self.timed("c_count"):
-            check(lib.xmap_alterego_count(st, C.byref(R.c), vp(mp), vp(cnt_t), vp(cnt_m), vp(d_prof)))
+            check(lib.xmap_alterego_count(st, C.byref(Rc), vp(mp), vp(cnt_t), vp(cnt_m), vp(d_prof)))
             off_t = self._empty(U + 1, torch.int64)
             off_m = self._empty(U + 1, torch.int64)
             check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(cnt_t), vp(off_t), i64(U), None))
@@ -1360,8 +1368,10 @@ class Engine(object):
         G.rating = self._empty(max(n, 1), torch.float64)      # pass-through ratings and np.mean of the merged ones (fp64)
         G.time = self._empty(max(n, 1), torch.int64)
         with self.timed("c_fill"):
-            check(lib.xmap_alterego_fill(st, C.byref(R.c), vp(mp), vp(off_t), vp(off_m), i64(nt),
+            check(lib.xmap_alterego_fill(st, C.byref(Rc), vp(mp), vp(off_t), vp(off_m), i64(nt),
                                          vp(G.user), vp(G.item), vp(G.rating), vp(G.time)))
+            if users is not None and u_lo:
+                G.user += u_lo
         G.n_rows, G.n_target_rows = n, nt
         G.cnt_t, G.cnt_m = cnt_t, cnt_m
         G.n_profiles = n_prof

@@ -235,11 +235,28 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         it = L.uq_item[lo:hi].long()           # a partitioned item's contributions are split over its Q units
         light_local = 2 * int((L.Wp[it].double() / L.Q[it].clamp(min=1).double()).sum().item()) if hi > lo else 0
     S, E, pt = _stage_b(eng, comm, coo, (own, mir), stats[2], L, k, rank, world, n)
-    # ---- stage C: replicated (a few ms)
+    # ---- stage C: the replacement map on every rank (one pass over the candidate arrays), the AlterEgo rows of a share of
+    # the USERS (contiguous shares of equal ratings), gathered kind by kind -- pass-through rows, then merged rows -- so that
+    # the result is row for row the one-rank output
     with eng.timed("stage_c"):
         n_top, choice, mp = eng.select(E, private)
-        G = eng.alterego(mp)
-        n_prof = eng.n_profiles(G)
+        nU = eng.R.n_users
+        ucut = torch.searchsorted(eng.R.user_ptr, (eng.R.user_ptr[nU] * torch.arange(1, world, device=dev)) // world).tolist()
+        ucut = [0] + [min(max(int(x), 0), nU) for x in ucut] + [nU]
+        ucut = np.maximum.accumulate(np.asarray(ucut))
+        Gl = eng.alterego(mp, users=(int(ucut[rank]), int(ucut[rank + 1])))
+        with eng.timed("rows_gather"):
+            nt = Gl.n_target_rows
+            rec = torch.stack([Gl.user.long() | (Gl.item.long() << 32), Gl.rating.view(torch.int64), Gl.time], dim=1)
+            parts = [comm.all_gather_var(rec[:nt].reshape(-1)).view(-1, 3), comm.all_gather_var(rec[nt:].reshape(-1)).view(-1, 3)]
+            allr = torch.cat(parts)
+            G = _Rows()
+            G.user, G.item = (allr[:, 0] & 0xffffffff).int(), (allr[:, 0] >> 32).int()
+            G.rating, G.time = allr[:, 1].contiguous().view(torch.float64), allr[:, 2].contiguous()
+            G.n_rows, G.n_target_rows = int(allr.shape[0]), int(parts[0].shape[0])
+            prof = torch.tensor([eng.n_profiles(Gl)], dtype=torch.int64, device=dev)
+            comm.all_reduce(prof)
+        n_prof = int(prof.item())
     return dict(n_eval=2 * int(tot[0].item()), n_kept=2 * int(tot[1].item()), n_contrib=2 * L.half_contrib,
                 n_contrib_light=light_local, n_kept_local=2 * n, n_paths=int(pt[0].item()), n_out=int(pt[1].item()),
                 n_rows=G.n_rows, n_profiles=n_prof, knn_entries=int(E.kcnt.sum().item()),
@@ -338,23 +355,44 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
         # compacted parts (one index list for the five columns) sent as ONE variable-length all-gather of 24-byte
         # records (i | j << 32, sim bits, mutu | n_ij << 32) -- and every rank mirrors the full COO into the CSR.
         split = isinstance(rowcnt, tuple)          # (own, mirrored) counts of the round-3 mirror, or one combined array
+        I = eng.R.n_items
+        share = None
         with eng.timed("exchange"):
-            comm.all_reduce(rowcnt[0] if split else rowcnt)                     # (own counts; the mirrored ones: below)
-            rec = eng.pack_pairs(coo, n_local)                                  # library kernels, no torch arithmetic
-            rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
+            rec = eng.pack_pairs(coo, n_local)                                  # 24-byte records (i | j << 32, sim bits, mutu | n_ij << 32)
+            if split and I > 0:
+                # Round 4: every kept pair goes to the (at most two) ranks that own its rows, not to everybody.  Row counts
+                # first -- own entries (the pair kernels counted them) and mirrored entries (one count over the rank's own
+                # records) all-reduced: 2 x 4 B x I --, contiguous row shares of equal entries cut from them on every rank
+                # alike, then ONE all-to-all of the records grouped by destination (a record whose two rows have the same
+                # owner travels once).  A rank receives 2 D' / N records instead of the D' of the all-gather it replaces
+                # (0.64 GB per rank at configs[1]); S4 / S6 of SURVEY 2.3, the shuffle behind get_item_sim
+                # (core/baselinerSim.py:218-233).
+                ri, rj = rec[:, 0] & 0xffffffff, rec[:, 0] >> 32
+                rowcnt[1].zero_()
+                if n_local:
+                    rowcnt[1] += torch.bincount(rj, minlength=rowcnt[1].numel())[:rowcnt[1].numel()].to(rowcnt[1].dtype)
+                comm.all_reduce(rowcnt[0])
+                comm.all_reduce(rowcnt[1])
+                cuts = eng.row_shares(rowcnt[0] + rowcnt[1], world)
+                share = (int(cuts[rank]), int(cuts[rank + 1]))
+                inner = torch.as_tensor(cuts[1:-1], dtype=torch.int64, device=dev)
+                oi, oj = torch.bucketize(ri, inner, right=True), torch.bucketize(rj, inner, right=True)
+                second = torch.nonzero(oj != oi).reshape(-1)
+                dest = torch.cat([oi, oj[second]])
+                src = torch.cat([torch.arange(n_local, dtype=torch.int64, device=dev), second])
+                order = torch.argsort(dest, stable=True)
+                send_cuts = np.concatenate([[0], np.cumsum(torch.bincount(dest, minlength=world).cpu().numpy())])
+                rec = comm.all_to_all_rows(rec[src[order]].contiguous(), send_cuts)
+            else:
+                comm.all_reduce(rowcnt[0] if split else rowcnt)
+                rec = comm.all_gather_var(rec.reshape(-1)).view(-1, 3)
             n_all = int(rec.shape[0])
             coo = eng.unpack_pairs(rec)
         # No collective sits between a possible raise and the agree() that follows it: the local phases run in try blocks,
         # the all-gathers of the knn tables (ext_gather) run outside any of them.
-        err, S, E, bb, share = None, None, None, None, None
+        err, S, E, bb = None, None, None, None
         try:
-            if split and eng.R.n_items > 0:
-                # mirrored entries per row, counted from the gathered COO (the pair kernels take no such counts); then the rows
-                # of the matrix this rank builds: its knn and reverse-list shares read nothing else (every rank had mirrored
-                # the whole COO, 1.3 ms replicated)
-                eng.mir_counts(coo, n_all, rowcnt[1])
-                cuts = eng.row_shares(rowcnt[0] + rowcnt[1], world)
-                share = (int(cuts[rank]), int(cuts[rank + 1]))
+            # the rows of the matrix this rank builds: its knn and reverse-list shares read nothing else
             S = eng.tri_mirror(coo, rowcnt[0], rowcnt[1], info, n_all, rows=share, counted=True) if split else eng.tri_scatter(coo, rowcnt, info, None, L)
             if share is not None:
                 bb = eng.bridge_flags(S).to(torch.int32)      # of this rank's rows; a list entry is classified by its
