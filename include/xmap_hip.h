@@ -458,7 +458,10 @@ int xmap_end_universe(void *stream, const xmap_ext_tables *T, int32_t *mark /*[I
 int xmap_extend_cols(void *stream, const xmap_ext_tables *T, const xmap_path_units *U, const xmap_path_rows *R,
                       const xmap_path_out *O, int fast_div, int64_t *d_counters /*[8] device*/,
                       int64_t *h_counters /*[8]: candidates, paths, -, -, row updates (read-modify-writes of row entries)*/);
-/* accumulator rows xmap_extend_cols can keep busy: one per wavefront resident on the device (compute units x SIMDs x the
+/* Size limits of the extension live in the HOST layer, not here: the Python engine refuses an extension of more than
+ * XMAP_MAX_PATHS paths (5e12) before calling xmap_extend_cols and enumerates path by path (xmap_extend_paths) when the middle
+ * lists would exceed XMAP_MID_BUDGET_GB (100 GB); xmap_ctx_extend refuses both.  INTEGRATION.md, "Limits a caller can hit".
+ * accumulator rows xmap_extend_cols can keep busy: one per wavefront resident on the device (compute units x SIMDs x the
  * kernel's waves per SIMD); what a caller sizes xmap_path_rows.n_slots with (more rows are never touched). */
 int xmap_extend_cols_slots(int32_t *h_n_slots);
 

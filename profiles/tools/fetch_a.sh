@@ -7,8 +7,8 @@ for n in $2; do
   lib=$GRAFT_REPO_ROOT/x-map_amd/_variants/libxmap_$n.so; [ "$n" = BASE ] && lib=$GRAFT_REPO_ROOT/x-map_amd/libxmap_hip.so
   export XMAP_HIP_LIB=$lib
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${T}_f_$n_$c -- python3 profiles/tools/run_a.py 1 > gpurun_out/${T}_f.txt 2> gpurun_out/${T}_f.err || exit 1
-    python3 - $n $c gpurun_out/${T}_f_$n_$c <<'PY'
+    timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${T}_f_${n}_${c} -- python3 profiles/tools/run_a.py 1 > gpurun_out/${T}_f.txt 2> gpurun_out/${T}_f.err || exit 1
+    python3 - $n $c gpurun_out/${T}_f_${n}_${c} <<'PY'
 import csv, glob, collections, sys, re
 tot = collections.defaultdict(float)
 for fn in glob.glob(sys.argv[3] + "/*/*counter_collection.csv"):
@@ -20,6 +20,6 @@ f = 2.0 if sys.argv[2] == "FETCH_SIZE" else 1.0      # KB; the guide's gfx950 co
 print(sys.argv[1], sys.argv[2], "pair kernels %.3f GB (guide's formula; x1: %.3f GB);" % (pair * 1024 * f / 1e9, pair * 1024 / 1e9),
       " ".join("%s %.3f" % (k[:28], v * 1024 * f / 1e9) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:8]))
 PY
-    rm -rf gpurun_out/${T}_f_$n_$c
+    rm -rf gpurun_out/${T}_f_${n}_${c}
   done
 done

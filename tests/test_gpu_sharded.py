@@ -17,6 +17,21 @@ def _free_port():
     return p
 
 
+def _collect(q, procs, n, limit=600):
+    """n results from the workers' queue; fails at once when a worker has died (instead of waiting out the limit)"""
+    import queue
+    import time
+    got, t0 = [], time.time()
+    while len(got) < n:
+        try:
+            got.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, "a worker exited with %s before delivering its result" % dead
+            assert time.time() - t0 < limit, "workers silent for %d s" % limit
+    return got
+
+
 def _summary(res):
     S, E, G = res["S"], res["E"], res["G"]
     rp = S.row_ptr.cpu().numpy()
@@ -97,7 +112,7 @@ def _check_world_equals_world1(world, backend):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=600) for _ in range(world)]
+    got = _collect(q, procs, world)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -173,7 +188,7 @@ def _check_multidomain(world, backend):
     procs = [ctx.Process(target=_md_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=600) for _ in range(world)]
+    got = _collect(q, procs, world)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -233,7 +248,7 @@ def _check_user_sharded(world, method, backend):
     procs = [ctx.Process(target=_users_worker, args=(r, world, port, method, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=600) for _ in range(world)]
+    got = _collect(q, procs, world)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

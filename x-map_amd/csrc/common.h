@@ -1,5 +1,10 @@
 // common.h -- shared device/host helpers of libxmap_hip.so (gfx950 only; wave = 64 lanes).
 #pragma once
+// The kernels are written for gfx950 (MI355X): 160 KB of LDS per CU (k_cbs_scatter holds 147 KB, k_ts_bin 76 KB), wave64, its
+// DPP / MFMA / LDS-DMA forms.  A device pass for another target is refused here rather than failing late in a kernel.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libxmap_hip is written for gfx950 (MI355X): build with --offload-arch=gfx950"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -464,6 +464,9 @@ struct ATraceEnd { long long u; long long t0;
 // at that place).  The finalisation needs seventeen pointers the walk never touches; as plain uses of A they are all loaded
 // at the kernel's entry and kept -- 101 SGPRs, i.e. 7 waves per SIMD, or ~100 v_writelane / v_readlane spill moves per unit
 // (a sixth of its vector instructions) when the kernel is held to 8.
+// KARG reads at offsetof(TriArgs, field) from the kernarg base: correct only while the struct is the kernel's FIRST and ONLY
+// parameter (k_pair_tri(TriArgs A), k_pair_heavy(TriArgs A)): keep it so.
+static_assert(std::is_standard_layout<TriArgs>::value, "KARG() addresses TriArgs fields by offsetof");
 #ifdef EXP_NOKARG
 #define KARG(field) (A.field)
 #else

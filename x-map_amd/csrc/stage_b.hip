@@ -662,15 +662,16 @@ __device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, doub
         if (act) {
             e = touched[b];
             double *a = acc + ((size_t)e * gs + mem) * 4;
-            if (A.uitem) e = A.uitem[e];
             v = 1.0 * (a[0] + a[1]) / (a[2] + a[3]);     // pairs of k_paths4 are not renormalised; a renormalised pair is its own sum
             a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
             key = xsim_key(v);
-            if (full) { A.xs_end[off + b] = e; A.xs_val[off + b] = v; }
+            if (full) { A.xs_end[off + b] = A.uitem ? A.uitem[e] : e; A.xs_val[off + b] = v; }
         }
+        // (rows of k_paths4 are indexed by end RANK; the item behind a rank -- a random 4-byte gather, a third of the pass's
+        //  memory requests -- is looked up only for the candidates that pass the running threshold: ~10 ln(n / 10) per start)
         const bool q = act && key >= thr;
         const unsigned long long m = __ballot(q);
-        if (q) { const int p = nbuf + __popcll(m & lanemask_lt()); bv[p] = v; be[p] = e; }
+        if (q) { const int p = nbuf + __popcll(m & lanemask_lt()); bv[p] = v; be[p] = A.uitem ? A.uitem[e] : e; }
         nbuf += __popcll(m);
         if (nbuf > FIN_CAP) {
             const int ns = fin_cut(F, nbuf, F.oe, F.ov);

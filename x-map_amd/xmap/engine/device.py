@@ -883,6 +883,9 @@ class Engine(object):
                                      vp(U.heavy_unit0), h))
         U.n_units, U.n_heavy, U.n_rows, U.total, U.chunk = int(h[0]), int(h[1]), int(h[2]), int(h[3]), int(h[4])
         U.P = P          # exact path count per start (B5d / B5e)
+        # all starts, not only this call's range: what the refusal of extend_tables goes by, so that the ranks of a sharded
+        # step decide alike and the message carries the whole problem's count
+        U.total_all = int(P[:I].sum().item()) if (I and (start_range is not None or start_split is not None)) else U.total
         U.unit_nt = self._zeros(max(U.n_units, 1), torch.int32)
         return U
 
@@ -1205,9 +1208,9 @@ class Engine(object):
         # of the reference's report has 2.9e10 paths at its own k = 10 and 5.8e13 at k = 50).  Refuse up front what would
         # take hours, instead of dying in an allocation.
         max_paths = float(os.environ.get("XMAP_MAX_PATHS", "5e12"))
-        if U.total > max_paths:
+        if U.total_all > max_paths:
             raise abi.XmapError(abi.ERR_CAPACITY, "the extension has %.3g paths at top_k = %d (limit XMAP_MAX_PATHS = %.3g): "
-                                "use a shorter list" % (U.total, E.k, max_paths))
+                                "use a shorter list" % (U.total_all, E.k, max_paths))
         M = getattr(E, "mid", None)
         if M is None:
             M = self.mid_lists(E) if algo in ("mid", "cols") else None

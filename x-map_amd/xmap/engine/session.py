@@ -44,14 +44,14 @@ class TrainState(object):
 
 
 def _fingerprint(records):
-    """content key of a record list that cannot be weak-referenced: every (uid, iid, rating) takes part, so ratings edited
+    """content key of a record list that cannot be weak-referenced: every (uid, iid, rating, time) takes part, so ratings edited
     in place -- or a new list of the same shape behind a recycled id(), such as a CV fold with perturbed ratings -- never
     hit the cache of the previous upload.  O(ratings) of host work per call, paid by plain-list inputs only (an RDD
     object is keyed by identity through a weak reference)."""
     h, n = 1469598103934665603, 0
     for rec in records:
         uid, prof = rec[0], rec[1]
-        ph = hash((uid, len(prof), tuple((e[0], float(e[1])) for e in prof)))
+        ph = hash((uid, len(prof), tuple((e[0], float(e[1]), e[2]) for e in prof)))      # (times too: AlterEgo rows and the decay read them)
         h = ((h ^ (ph & 0xFFFFFFFFFFFFFFFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         n += len(prof)
     return (len(records), n, h)

@@ -368,9 +368,10 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
                 # (0.64 GB per rank at configs[1]); S4 / S6 of SURVEY 2.3, the shuffle behind get_item_sim
                 # (core/baselinerSim.py:218-233).
                 ri, rj = rec[:, 0] & 0xffffffff, rec[:, 0] >> 32
-                rowcnt[1].zero_()
+                mirc = rowcnt[1]
+                mirc.zero_()
                 if n_local:
-                    rowcnt[1] += torch.bincount(rj, minlength=rowcnt[1].numel())[:rowcnt[1].numel()].to(rowcnt[1].dtype)
+                    mirc.add_(torch.bincount(rj, minlength=mirc.numel())[:mirc.numel()].to(mirc.dtype))
                 comm.all_reduce(rowcnt[0])
                 comm.all_reduce(rowcnt[1])
                 cuts = eng.row_shares(rowcnt[0] + rowcnt[1], world)
