@@ -1246,11 +1246,28 @@ __device__ __forceinline__ double quad_swap(double v) {
 //     2.5 dependent trips per column), requested together with the end records; the row entries are requested next, before
 //     the records are prepared.  Loads are unconditional (clamped indices) and consumed at unconditional places -- see the
 //     comment in heads_Q; division and sums as in k_paths3.
+// Round 4: heads_Q reads both tables of a column as 16-byte pieces, one per lane (profiles/r04d_paths_pieces.txt: -2.7 %);
+// -DQ_WHOLE: whole records per lane as in rounds 2-3 (also what the pipelined experiment heads_P uses)
+#if !defined(Q_WHOLE) && !defined(Q_PIPE)
+#define Q_RPIECE 1
+#define Q_EPIECE 1
+#endif
+#ifdef Q_RPIECE
+constexpr int Q_CAP = 64;                  // prepared records per round (the head records take the LDS of the other 64)
+#else
 constexpr int Q_CAP = 128;                 // prepared records per round
+#endif
 struct QLds {
     double bsm[Q_CAP + 1], bc[Q_CAP + 1], bmu[Q_CAP + 1];      // (entry Q_CAP: the neutral record (0, 0, 1) of heads_Q's record loop)
+#ifdef Q_RPIECE
+    double hd[3][64];                      // first edge of every head of the batch: [0] sim * mutu, [1] frac, [2] mutu
+#endif
+#ifdef Q_EPIECE
+    uint4 ep[128];                         // the chunk's end records as loaded: 16-byte pieces, two per end (the table's own layout)
+#else
     double e_sm[64], e_mu[64], e_f[64];
     int e_u[64];                           // universe rank of the end, -1 = none
+#endif
 };
 
 struct QAcc {
@@ -1301,6 +1318,16 @@ __device__ unsigned long long g_ptrace[16];
 #endif
 constexpr int END_HOME = 1 << 30;
 
+// the value of lane SRC of every quad, in all four lanes of the quad (DPP quad_perm: no LDS traffic)
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int CTRL = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <bool FASTDIV>
 __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi,
                                         bool fresh) {
@@ -1350,6 +1377,15 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     const int nloc = (nH - h0) < 64 ? (int)(nH - h0) : 64;      // heads of this batch (lanes 0 .. nloc-1)
 #endif
     if (lane == 0) { L.bsm[Q_CAP] = 0.0; L.bc[Q_CAP] = 0.0; L.bmu[Q_CAP] = 1.0; }       // the neutral record of the record loop
+#ifdef Q_RPIECE
+    // Merged records as 16-byte PIECES (record r = the four lanes 4r .. 4r+3 = {sm2, sm3}, {sm4, f2}, {f3, f4}, {mu, -}): one
+    // load instruction per group of 16 records instead of four over the same lines; the first edge of a record's head comes
+    // from a 24-byte LDS record per head (one ds_read_b64 per lane: lane 0 of a quad needs sim * mutu, lane 2 frac, lane 3 mutu)
+    L.hd[0][lane] = sm1; L.hd[1][lane] = f1; L.hd[2][lane] = mu1;
+    const uint4 *recp = reinterpret_cast<const uint4 *>(B.midX);
+    const int pq = lane & 3, prec = lane >> 2;
+    const int pfield = pq == 0 ? 0 : (pq == 2 ? 1 : 2);
+#endif
     for (;;) {
         // smallest column among the heads: xor butterfly inside each half of the wave (ds_swizzle: no address registers),
         // then the two halves
@@ -1382,11 +1418,52 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             // (under the preparation and reduction of the records).  Every load is unconditional (clamped index) and is
             // consumed at one unconditional place: a load whose use sits behind a branch stays "pending" on the other
             // path, and the compiler then waits for ALL outstanding loads at the next join, which serialises the trips.
+#ifdef Q_EPIECE
+            // the end records as 16-byte PIECES, one per lane (two per end): ONE load instruction for up to 32 ends where the
+            // whole-record form needs two over the same lines; the pieces go to LDS as they come and are read back per (end, slice)
+            const int np = 2 * nact;
+            const uint4 *cep = reinterpret_cast<const uint4 *>(ce) + 2 * b;
+            const uint4 e0 = cep[lane < np ? lane : np - 1];
+#else
             const ColEnd e = ce[(b + lane < ne) ? b + lane : ne - 1];      // one 32-byte record per end (k_col_ends)
+#endif
             unsigned long long pm = part;
             int pos = 0;                      // records of the current head already staged
             int set_n, my_h;
             long long my_rec;
+#ifdef Q_RPIECE
+            // a group = up to 16 records, four lanes each, of whichever participating heads they fall to
+            auto assign = [&]() {
+                set_n = 0; my_h = 0;
+                my_rec = rl64(cur.off, __ffsll((long long)pm) - 1) * 4;     // lanes beyond the group: any piece
+                for (;;) {
+                    pm = ((unsigned long long)(unsigned)uniform((int)(pm >> 32)) << 32) | (unsigned)uniform((int)pm);
+                    pos = uniform(pos); set_n = uniform(set_n);
+                    if (pm == 0 || set_n >= 16) break;
+                    const int l = __ffsll((long long)pm) - 1;
+                    const int cnt = rl32(cur.cnt, l);
+                    const long long off = rl64(cur.off, l);
+                    int n = cnt - pos;
+                    if (n > 16 - set_n) n = 16 - set_n;
+                    if (lane >= 4 * set_n && lane < 4 * (set_n + n)) { my_rec = (off + pos) * 4 + (lane - 4 * set_n); my_h = l; }
+                    set_n += n; pos += n;
+                    if (pos == cnt) { pm &= pm - 1; pos = 0; }
+                }
+            };
+            // prepared form of a group's records, computed inside the quad (same operations in the same order)
+            auto prepare = [&](const uint4 &v, int fill) {
+                const double H = L.hd[pfield][my_h];
+                const double X = __longlong_as_double(((long long)v.y << 32) | v.x), Y = __longlong_as_double(((long long)v.w << 32) | v.z);
+                const double X1 = quad_bcast<1>(X), Y1 = quad_bcast<1>(Y);      // sm4, f2 of the record
+                const double v_sm = ((H + X) + Y) + X1;                           // lane 0: ((sm1 + sm2) + sm3) + sm4
+                const double v_c = ((H * Y1) * X) * Y;                            // lane 2: ((f1 * f2) * f3) * f4
+                const double v_mu = X + H;                                        // lane 3: mu + mu1
+                const double val = pq == 0 ? v_sm : (pq == 2 ? v_c : v_mu);
+                if (pq != 1 && prec < set_n) { if (pq == 0) L.bsm[fill + prec] = val; else if (pq == 2) L.bc[fill + prec] = val; else L.bmu[fill + prec] = val; }
+            };
+            assign();
+            uint4 m0 = recp[my_rec];
+#else
             // a set = up to 64 records, one per lane, of whichever participating head the lane falls to
             auto assign = [&]() {
                 set_n = 0; my_h = 0;
@@ -1427,6 +1504,18 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             };
             assign();
             MidX m0 = B.midX[my_rec];
+#endif
+#ifdef Q_EPIECE
+            if (nact > 32) L.ep[64 + lane] = cep[64 + lane < np ? 64 + lane : np - 1];
+            L.ep[lane] = e0;
+            asm volatile("" ::: "memory");
+            const bool ok = q < nact;
+            const uint4 ea = L.ep[2 * (ok ? q : 0)], eb = L.ep[2 * (ok ? q : 0) + 1];
+            const double sm5 = __longlong_as_double(((long long)ea.y << 32) | ea.x), mu5 = __longlong_as_double(((long long)ea.w << 32) | ea.z);
+            const double f5 = __longlong_as_double(((long long)eb.y << 32) | eb.x);
+            const int eur = (int)eb.z;
+            const int eu = eur & (END_HOME - 1);
+#else
             // ends: natural layout -> LDS -> (end, slice) layout
             {
                 int eu_ = e.u;
@@ -1438,6 +1527,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             const bool ok = eur >= 0;
             const int eu = eur & (END_HOME - 1);
             const double sm5 = L.e_sm[q], mu5 = L.e_mu[q], f5 = L.e_f[q];
+#endif
             const bool fl_ = ok && slice == 0;
 #ifdef Q_STORE      // (ablation: every (column, end) a slot of its own -- a column visit is one contiguous run of stores, no load;
             //  the rows of the split heavy starts keep their U entries: the usual place there)
@@ -1457,6 +1547,22 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 h0_ = la[0]; l0_ = la[1]; h1_ = la[2]; l1_ = la[3];     // requested before the records are prepared and reduced
                 la = a;                                                 // (a second round of the same column finds the first one's sums)
 #endif
+#ifdef Q_RPIECE
+                int fill = 0;
+                {   // up to four groups requested together (one trip for up to 64 records), then prepared
+                    const int h0g = my_h, g0 = uniform(set_n);
+                    uint4 m1 = m0, m2 = m0, m3 = m0;
+                    int h1g = 0, h2g = 0, h3g = 0, g1 = 0, g2 = 0, g3 = 0;
+                    if (pm) { assign(); m1 = recp[my_rec]; h1g = my_h; g1 = uniform(set_n); }
+                    if (pm) { assign(); m2 = recp[my_rec]; h2g = my_h; g2 = uniform(set_n); }
+                    if (pm) { assign(); m3 = recp[my_rec]; h3g = my_h; g3 = uniform(set_n); }
+                    my_h = h0g; set_n = g0; prepare(m0, fill); fill += g0;
+                    if (g1) { my_h = h1g; set_n = g1; prepare(m1, fill); fill += g1; }
+                    if (g2) { my_h = h2g; set_n = g2; prepare(m2, fill); fill += g2; }
+                    if (g3) { my_h = h3g; set_n = g3; prepare(m3, fill); fill += g3; }
+                    fill = uniform(fill);
+                }
+#else
                 prepare(m0, 0);
                 int fill = set_n;
                 while (pm && fill < Q_CAP) {
@@ -1465,6 +1571,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                     prepare(m, fill);
                     fill += set_n;
                 }
+#endif
                 asm volatile("" ::: "memory");
                 double a_sh = 0.0, a_sl = 0.0, a_ch = 0.0, a_cl = 0.0;
                 const int steps = (fill + ns - 1) >> sh;
@@ -1550,7 +1657,11 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 W.updates += (unsigned long long)nact;
                 if (!pm) break;
                 assign();
+#ifdef Q_RPIECE
+                m0 = recp[my_rec];
+#else
                 m0 = B.midX[my_rec];
+#endif
             }
         }
         if (mine) {    // advance the heads that took part
