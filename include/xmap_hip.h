@@ -93,6 +93,7 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
                     int32_t *ua_item /*[nnz] or NULL*/, int32_t *ia_user /*[nnz] or NULL*/,
                     int32_t item_lo, int32_t item_hi /*items [lo, hi): a rank's share when items are sharded (0, n_items: all)*/);
 
+#ifdef XMAP_CROSSCHECK   /* test formulation: exported by libxmap_hip_xcheck.so only (csrc/Makefile), never by the product library */
 /* Work decomposition for the pair kernel: unit = (item i, hash partition q of its partner space),
  * Q[i] = ceil(min(W_i, I-1) / slot_target), W_i = sum over raters of (profile length - 1).
  * Writes Q[I], W[I], unit_ptr[I+1] (exclusive scan of Q); *h_n_units, *h_contrib (= sum W_i = P). Syncs. */
@@ -121,6 +122,7 @@ int xmap_sim_fill(void *stream, const xmap_ratings *R, int method, int cap, cons
  * item are contiguous, so its partitions concatenate into its row). */
 int xmap_sim_row_ptr(void *stream, int32_t n_items, const int64_t *unit_ptr, const int64_t *unit_off /*[n_units+1]*/,
                      int64_t *row_ptr /*[I+1]*/);
+#endif /* XMAP_CROSSCHECK */
 
 /* ---- stage A, second formulation (stage_a2.hip): each unordered pair is computed once, in the row of its lighter
  * item (weight = (rater count, index)), appended to a half COO and mirrored into the CSR.  Same results as
@@ -380,6 +382,7 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *c
  * heads of a start are merged by x, a lane keeps its end's double-double sums in registers across all tiles (x', x)
  * of the start's heads, so a start's row is touched once per (start, x) instead of once per path.  Same results
  * (the sums are exact). */
+#ifdef XMAP_CROSSCHECK   /* test formulation: exported by libxmap_hip_xcheck.so only (csrc/Makefile), never by the product library */
 int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                    const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
@@ -391,6 +394,7 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
                    const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
                    int32_t *tile_cnt, const int64_t *tile_off /*[n_nb*n_nb+1]*/, const int64_t *dir_ptr /*[n_nb+1]*/,
                    void *dir /*24 B per tile*/, void *midX /*64 B per record*/);
+#endif /* XMAP_CROSSCHECK */
 /* Row-wise construction of the same lists (default, any n_nb): one block per x' keeps the tile sizes of its row in LDS --
  * XMAP_MID_ROWS_SPAN columns at a time; a row with more non-bridge items is built in column ranges, one after the
  * other -- so there is no n_nb x n_nb table and no global atomic:
@@ -410,6 +414,7 @@ int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t 
                         const uint8_t *src_flag, int32_t n_nb, const int32_t *nb_list, const int32_t *nb_id,
                         const int64_t *dir_ptr /*[n_nb+1]*/, const int64_t *rec_ptr /*[n_nb+1]*/, void *dir /*24 B per tile*/,
                         void *midX /*64 B per record*/);
+#ifdef XMAP_CROSSCHECK   /* test formulation: exported by libxmap_hip_xcheck.so only (csrc/Makefile), never by the product library */
 int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
                        const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
                        const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
@@ -421,6 +426,7 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
                        int64_t *xs_off, int32_t *xs_end, double *xs_val, int64_t *d_counters, int64_t *h_counters,
                        const int32_t *nb_id, const int32_t *nb_list, int32_t n_nb, const void *midX, const void *dir,
                        const int64_t *dir_ptr, const int32_t *ng);
+#endif /* XMAP_CROSSCHECK */
 
 /* ---- extension, column form (default) ----------------------------------------------------------------------------
  * Same work units and results as xmap_extend_paths2 (units = starts, heavy starts cut into unit_G chunks with dedicated

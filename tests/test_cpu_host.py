@@ -11,14 +11,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_abi_exports_every_declared_symbol():
+    """the PRODUCT library exports exactly what the header declares outside #ifdef XMAP_CROSSCHECK; the cross-check library
+    (same sources + the test formulations) exports those and the guarded ones; the product does not carry the latter"""
     import ctypes
     hdr = open(os.path.join(ROOT, "include", "xmap_hip.h")).read()
+    guarded = "".join(re.findall(r"#ifdef XMAP_CROSSCHECK.*?#endif /\* XMAP_CROSSCHECK \*/", hdr, flags=re.S))
     names = set(re.findall(r"\b(xmap_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 19
+    xnames = set(re.findall(r"\b(xmap_[a-z0-9_]+)\s*\(", guarded))
+    assert len(names) >= 19 and len(xnames) >= 8 and xnames < names
     from xmap.engine import hipabi      # loads libxmap_hip.so (no compute call is made without a GPU)
-    for n in sorted(names):
+    for n in sorted(names - xnames):
         assert hasattr(hipabi.lib, n), n
-    assert set(hipabi.EXPORTS) == names
+    assert set(hipabi.EXPORTS) == names - xnames and set(hipabi.XCHECK_EXPORTS) == xnames
+    for n in sorted(xnames):
+        assert not hasattr(hipabi.lib, n), "test formulation %s in the product library" % n
+    X = hipabi.xlib()
+    for n in sorted(names):
+        assert hasattr(X, n), n
     assert hipabi.lib.xmap_version() >= 100
     # struct layouts match the header (field order / count)
     assert [f[0] for f in hipabi.Ratings._fields_] == re.findall(
@@ -27,7 +36,7 @@ def test_abi_exports_every_declared_symbol():
     # every export carries argtypes generated from the header: a mis-typed or missing argument raises in ctypes
     assert set(hipabi.PROTOTYPES) == names
     for n in sorted(names):
-        f = getattr(hipabi.lib, n)
+        f = getattr(X if n in xnames else hipabi.lib, n)
         assert f.argtypes is not None and len(f.argtypes) == len(hipabi.PROTOTYPES[n]), n
     assert hipabi.PROTOTYPES["xmap_exclusive_scan_i64"] == [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                             ctypes.c_void_p]

@@ -20,11 +20,13 @@
 
 namespace xmap {
 
+#ifdef XMAP_CROSSCHECK      // (constants of the complete-rows pair kernel)
 constexpr int A_THREADS = 64;   // one wave = one unit = one workgroup (no block-level barrier is used)
 constexpr int A_WAVES = A_THREADS / 64;
 constexpr int LOG_SLOTS = 10;
 constexpr int SLOTS = 1 << LOG_SLOTS;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+#endif
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_user_stats(long long U, const long long *ptr, const float *rating,
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(256) void k_item_merge(int I, int n_parts, const do
     norms[(size_t)I + i] = sqrt(a2);
 }
 
+#ifdef XMAP_CROSSCHECK      // ---- the complete-rows formulation of round 1 (algo="rows"): a test formulation, built into libxmap_hip_xcheck.so only
 __global__ __launch_bounds__(256) void k_pack_user_side(long long nnz, const int *uitem, const float *urating,
                                                         const double *info, int *ua_item) {
     long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -419,6 +422,8 @@ static PairArgs make_args(const xmap_ratings *R, int cap, const double *u_avg, c
     return A;
 }
 
+#endif  // XMAP_CROSSCHECK
+
 }  // namespace xmap
 
 using namespace xmap;
@@ -468,11 +473,15 @@ int xmap_item_stats(void *stream, const xmap_ratings *R, const double *u_avg, do
             R->n_items, item_lo, item_hi, (const long long *)R->item_ptr, R->item_user, R->item_rating, u_avg, info, norms, ia_user);
         XM_LAUNCH_CHECK();
     }
+#ifdef XMAP_CROSSCHECK      // (the packed per-rating arrays are read by the complete-rows formulation only)
     if (R->nnz > 0 && ua_item) {
         k_pack_user_side<<<dim3((unsigned)((R->nnz + 255) / 256)), dim3(256), 0, st>>>(
             R->nnz, R->user_item, R->user_rating, info, ua_item);
         XM_LAUNCH_CHECK();
     }
+#else
+    XM_ARG(ua_item == nullptr);
+#endif
     return XMAP_OK;
 }
 
@@ -497,6 +506,7 @@ int xmap_item_merge(void *stream, int32_t n_items, int32_t n_parts, const double
     return XMAP_OK;
 }
 
+#ifdef XMAP_CROSSCHECK
 int xmap_sim_plan(void *stream, const xmap_ratings *R, int32_t slot_target, int32_t *Q, int64_t *W, int64_t *unit_ptr,
                   int64_t *h_n_units, int64_t *h_contrib) {
     XM_SCOPE(stream);
@@ -587,4 +597,5 @@ int xmap_sim_fill(void *stream, const xmap_ratings *R, int method, int cap, cons
     XM_HIP(xm_free_async(dummy, st));
     return rc;
 }
+#endif  // XMAP_CROSSCHECK
 }

@@ -801,6 +801,7 @@ struct MidArgs {
     MidX *midX;
 };
 
+#ifdef XMAP_CROSSCHECK      // the dense-table form of the middle lists (XMAP_MID_TABLE=1): a test formulation, libxmap_hip_xcheck.so only
 // one wave per (x', position q in NB_BB(x')): lanes over the joint (t,s), each walks attach(s)
 template <bool PLACE>
 __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
@@ -839,6 +840,7 @@ __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
 // the dense table without the table).  PHASE 0 counts the row's records and non-empty tiles; PHASE 1 repeats the tally,
 // turns it into offsets (block scan), writes the row's tile directory in x order and places the records with LDS cursors.
 // No global atomics (the table form spends 1.6e8 of them per pass, twice, on a 3 GB table) and no n_nb^2 memory.
+#endif  // XMAP_CROSSCHECK
 // The LDS holds the counters of `span` columns (<= XMAP_MID_ROWS_SPAN): a row with more non-bridge items than that is
 // built in column ranges [x0, x0 + span), one after the other -- every range walks the row's (t, s, x) again and keeps the
 // x of its range, the directory and the records of the ranges follow each other (x order is kept).  Rounds 1-2 fell back
@@ -933,6 +935,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
     if (PHASE == 0 && threadIdx.x == 0) { ng[xpid] = (int)(done >> 40); nrec[xpid] = (long long)(done & ((1ull << 40) - 1)); }
 }
 
+#ifdef XMAP_CROSSCHECK      // (k_mid_dir: directory of the dense-table form)
 // directory of the non-empty tiles of every x' (row of the dense table): count, then fill
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, const long long *tile_off,
@@ -959,6 +962,7 @@ __global__ __launch_bounds__(256) void k_mid_dir(int n_nb, const int *tile_cnt, 
     if (!FILL && lane == 0) ng[xpid] = total;
 }
 
+#endif  // XMAP_CROSSCHECK
 struct ColEnd { double sm, mu, f; int u; int pad; };     // one end of a column x: last edge (sim * mutu, mutu, frac; 0, 0, 1 for x itself), universe rank
 struct Path2Args {
     PathArgs P;
@@ -967,6 +971,7 @@ struct Path2Args {
     const MidX *midX; const MidDir *dir; const long long *dir_ptr; const int *ng;
 };
 
+#ifdef XMAP_CROSSCHECK      // (flush_end: row update of k_paths2)
 // merge a lane's register sums into the start's row (distinct ends per call)
 __device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, double s_hi, double s_lo, double c_hi, double c_lo) {
     bool first = false;
@@ -983,6 +988,7 @@ __device__ __forceinline__ void flush_end(WaveAcc &W, bool active, int end, doub
     W.nt += __popcll(m);
 }
 
+#endif  // XMAP_CROSSCHECK
 // paths [start -] x' - t - s of one head (end s): lanes over the joint (t,s) of each t in NB_BB(x')
 template <class ACC>
 __device__ __forceinline__ void head_S(const PathArgs &A, ACC &W, int xp, bool has_e1, Carry e1) {
@@ -1009,6 +1015,7 @@ __device__ __forceinline__ void head_S(const PathArgs &A, ACC &W, int xp, bool h
     }
 }
 
+#ifdef XMAP_CROSSCHECK      // k_paths2 (round 1's tile-major enumeration, algo="mid"): a test formulation, libxmap_hip_xcheck.so only
 // Tile-major reduction over the heads of one start.  Up to 64 heads (one per lane) are merged by item x: every
 // head's tile directory is sorted by x, so the smallest current x over the lanes is the next tile column; all heads
 // that own a tile (x', x) for it are reduced into the SAME register sums before the start's row is touched -- one
@@ -1196,6 +1203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WAVES, B_
         atomicAdd(&A.counters[1], W.paths);
     }
 }
+
+#endif  // XMAP_CROSSCHECK
 
 // ---- helpers of k_paths4 -------------------------------------------------------------------------------------
 // a / b rounded to nearest for b > 0 and operands far from the ends of the exponent range: v_rcp_f64 + two Newton steps
@@ -2498,11 +2507,14 @@ static int extend_paths_impl(const Path2Args *mid, void *stream, int32_t n_items
         A.U = n_items; A.urank = nullptr; A.uitem = nullptr; A.row_stride = n_items;
         int slots = n_slots < n_units ? n_slots : n_units;
         A.n_slots = slots;
+#ifdef XMAP_CROSSCHECK
         if (mid) {
             Path2Args B = *mid;
             B.P = A;
             k_paths2<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(B);
-        } else {
+        } else
+#endif
+        {
             k_paths<<<dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st>>>(A);
         }
         XM_LAUNCH_CHECK();
@@ -2537,6 +2549,7 @@ int xmap_extend_paths(void *stream, int32_t n_items, int top_k, const uint8_t *c
     return extend_paths_impl(nullptr, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
 }
 
+#ifdef XMAP_CROSSCHECK
 int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt,
                       const int32_t *kcol, const double *kval, const uint8_t *flags, const int64_t *att_ptr,
                       const int32_t *att_idx, const double *att_val, const int64_t *src_ptr, const int32_t *src_idx,
@@ -2555,6 +2568,8 @@ int xmap_extend_paths2(void *stream, int32_t n_items, int top_k, const uint8_t *
     B.dir_ptr = (const long long *)dir_ptr; B.ng = ng;
     return extend_paths_impl(&B, stream, n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val, src_flag, rnn_ptr, rnn_idx, rnn_val, n_units, unit_start, unit_c, unit_G, unit_row, unit_nt, n_heavy, heavy_unit0, n_slots, acc, touched, hacc, htouched, n_cand, top_end, top_val, xs_cap, xs_off, xs_end, xs_val, d_counters, h_counters);
 }
+
+#endif  // XMAP_CROSSCHECK
 
 static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                         const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
@@ -2635,6 +2650,7 @@ int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t 
     return XMAP_OK;
 }
 
+#ifdef XMAP_CROSSCHECK
 int xmap_mid_tally(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                    const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                    const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,
@@ -2678,6 +2694,8 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
+
+#endif  // XMAP_CROSSCHECK
 
 int xmap_edge_ranges(void *stream, const xmap_sim *S, int32_t *h_fast_ok) {
     XM_SCOPE(stream);

@@ -186,7 +186,10 @@ class Engine(object):
         ua_item = self._empty(max(R.nnz, 1), torch.int32) if packed else None
         ia_user = self._empty(max(R.nnz, 1), torch.int32) if packed else None
         lo, hi = (0, R.n_items) if item_range is None else (int(item_range[0]), int(item_range[1]))
-        check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user), i32(lo), i32(hi)))
+        if packed:      # (the flag-packed copies are filled by the cross-check library: only the complete-rows test formulation reads them)
+            abi.xcheck(abi.xlib().xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user), i32(lo), i32(hi)))
+        else:
+            check(lib.xmap_item_stats(st, C.byref(R.c), vp(u_avg), vp(info), vp(self.norms), vp(ua_item), vp(ia_user), i32(lo), i32(hi)))
         return u_avg, u_norm, info, ua_item, ia_user
 
     def stats_partial(self):
@@ -280,12 +283,12 @@ class Engine(object):
         Pn.unit_ptr = self._zeros(I + 1, torch.int64)
         n_units, contrib = C.c_int64(0), C.c_int64(0)
         with self.timed("plan"):
-            check(lib.xmap_sim_plan(st, C.byref(R.c), i32(slot_target), vp(Pn.Q), vp(Pn.W), vp(Pn.unit_ptr),
+            abi.xcheck(abi.xlib().xmap_sim_plan(st, C.byref(R.c), i32(slot_target), vp(Pn.Q), vp(Pn.W), vp(Pn.unit_ptr),
                                     C.byref(n_units), C.byref(contrib)))
         Pn.nu, Pn.contrib = int(n_units.value), int(contrib.value)
         Pn.unit_item = self._empty(max(Pn.nu, 1), torch.int32)
         Pn.unit_q = self._empty(max(Pn.nu, 1), torch.int32)
-        check(lib.xmap_sim_units(st, i32(I), vp(Pn.Q), vp(Pn.unit_ptr), vp(Pn.unit_item), vp(Pn.unit_q)))
+        abi.xcheck(abi.xlib().xmap_sim_units(st, i32(I), vp(Pn.Q), vp(Pn.unit_ptr), vp(Pn.unit_item), vp(Pn.unit_q)))
         return Pn
 
     def item_weights(self, Pn):
@@ -296,7 +299,8 @@ class Engine(object):
 
     def item_sim(self, method, cap, slot_target=SLOT_TARGET, item_range=None, stats=None, plan=None, algo="tri"):
         """baseliner_calculate_sim_pipeline.  algo "tri" (default): each unordered pair once + mirror
-        (stage_a2.hip); algo "rows": complete rows per unit (stage_a.hip), supports item_range."""
+        (stage_a2.hip); algo "rows": complete rows per unit (stage_a.hip), supports item_range -- a TEST formulation: its
+        kernels live in libxmap_hip_xcheck.so (abi.xlib()), not in the product library."""
         if algo == "tri" and item_range is None and plan is None:
             return self.item_sim_tri(method, cap, slot_target)
         R = self.R
@@ -319,10 +323,10 @@ class Engine(object):
             d_cnt = self._zeros(4, torch.int64)
             h_cnt = [0, 0, 0, 0]
             with self.timed("pair_count"):
-                rc = lib.xmap_sim_count(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item),
+                rc = abi.xlib().xmap_sim_count(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item),
                                         vp(ia_user), vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi),
                                         vp(unit_cnt), vp(d_cnt), None)
-            check(rc)
+            abi.xcheck(rc)
             h_cnt = d_cnt.tolist()  # synchronises the stream
             if h_cnt[2]:
                 if slot_target > 32:
@@ -335,13 +339,13 @@ class Engine(object):
         unit_off = self._zeros(nu + 1, torch.int64)
         check(lib.xmap_exclusive_scan_i32_to_i64(st, vp(unit_cnt), vp(unit_off), i64(nu), None))
         row_ptr = self._empty(I + 1, torch.int64)
-        check(lib.xmap_sim_row_ptr(st, i32(I), vp(unit_ptr), vp(unit_off), vp(row_ptr)))
+        abi.xcheck(abi.xlib().xmap_sim_row_ptr(st, i32(I), vp(unit_ptr), vp(unit_off), vp(row_ptr)))
         col = self._empty(max(kept, 1), torch.int32)
         sim = self._empty(max(kept, 1), torch.float64)
         mutu = self._empty(max(kept, 1), torch.int32)
         nij = self._empty(max(kept, 1), torch.int32)
         with self.timed("pair_fill"):
-            check(lib.xmap_sim_fill(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
+            abi.xcheck(abi.xlib().xmap_sim_fill(st, C.byref(R.c), m, int(cap), vp(u_avg), vp(info), vp(ua_item), vp(ia_user),
                                     vp(Q), vp(unit_item), vp(unit_q), i64(lo), i64(hi), vp(unit_off),
                                     vp(col), vp(sim), vp(mutu), vp(nij)))
         S = SimResult()
@@ -964,7 +968,7 @@ class Engine(object):
         with self.timed("mid_build"):
             tile_cnt = self._empty(n_nb * n_nb, torch.int32)
             M.ng = self._zeros(n_nb, torch.int32)
-            check(lib.xmap_mid_tally(st, *common, vp(tile_cnt), vp(M.ng)))
+            abi.xcheck(abi.xlib().xmap_mid_tally(st, *common, vp(tile_cnt), vp(M.ng)))
             tile_off = self._empty(n_nb * n_nb + 1, torch.int64)
             M.dir_ptr = self._zeros(n_nb + 1, torch.int64)
             tx, tg = C.c_int64(0), C.c_int64(0)
@@ -973,7 +977,7 @@ class Engine(object):
             M.n_records, M.n_tiles = int(tx.value), int(tg.value)
             M.dir = self._empty(max(M.n_tiles, 1) * 3, torch.int64)
             M.midX = self._empty(max(M.n_records, 1) * 8, torch.float64)
-            check(lib.xmap_mid_place(st, *common, vp(tile_cnt), vp(tile_off), vp(M.dir_ptr), vp(M.dir), vp(M.midX)))
+            abi.xcheck(abi.xlib().xmap_mid_place(st, *common, vp(tile_cnt), vp(tile_off), vp(M.dir_ptr), vp(M.dir), vp(M.midX)))
         return M
 
     def _extend_cols(self, E, U, M, full, xs_cap, start_range, n_slots):
@@ -1251,7 +1255,7 @@ class Engine(object):
                     i64(cap), vp(xs_off), vp(xs_end), vp(xs_val), vp(d_cnt), h_cnt)
             with self.timed("paths"):
                 if M is not None:
-                    rc = lib.xmap_extend_paths2(*args, vp(M.nb_id), vp(M.nb_list), i32(M.n_nb), vp(M.midX), vp(M.dir),
+                    rc = abi.xlib().xmap_extend_paths2(*args, vp(M.nb_id), vp(M.nb_list), i32(M.n_nb), vp(M.midX), vp(M.dir),
                                                 vp(M.dir_ptr), vp(M.ng))
                 else:
                     rc = lib.xmap_extend_paths(*args)
@@ -1260,7 +1264,7 @@ class Engine(object):
                 continue
             if rc != 0:
                 self._drop_scratch("acc", "hacc")
-            check(rc)
+            (abi.xcheck if M is not None else check)(rc)
             break
         E.n_out, E.n_paths = int(h_cnt[0]), int(h_cnt[1])
         E.xs_off, E.xs_end, E.xs_val = xs_off, xs_end, xs_val

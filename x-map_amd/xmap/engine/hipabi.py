@@ -9,6 +9,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XMAP_HIP_LIB") or os.path.normpath(os.path.join(HERE, "..", "..", "libxmap_hip.so"))
+# the same sources + the TEST formulations (-DXMAP_CROSSCHECK): loaded on demand by xlib(), by tests and tuning tools only
+XLIB_PATH = os.environ.get("XMAP_HIP_XLIB") or os.path.normpath(os.path.join(HERE, "..", "..", "libxmap_hip_xcheck.so"))
 
 COSINE, ADJUST_COSINE = 0, 1
 METHODS = {"cosine": COSINE, "adjust_cosine": ADJUST_COSINE}
@@ -65,12 +67,12 @@ class PathOut(C.Structure):
 
 EXPORTS = [
     "xmap_last_error", "xmap_version", "xmap_trim", "xmap_debug_arena", "xmap_debug_arena_call", "xmap_exclusive_scan_i64", "xmap_exclusive_scan_i32_to_i64",
-    "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", "xmap_sim_plan", "xmap_sim_units", "xmap_sim_count",
-    "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
+    "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", 
+    "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
     "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_sim3_layout", "xmap_sim3_plan", "xmap_sim3_mircount", "xmap_sim3_mirror", "xmap_item_partials", "xmap_item_merge", "xmap_sim2_pack_partials",
     "xmap_sim2_sort_partials", "xmap_sim2_merge_partials", "xmap_sim2_pack_pairs", "xmap_sim2_unpack_pairs", "xmap_bridge_flags", "xmap_knn_classify", "xmap_knn_thresholds", "xmap_reverse_count",
-    "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", "xmap_mid_tally", "xmap_mid_place",
-    "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_extend_paths2", "xmap_edge_ranges", "xmap_end_universe", "xmap_extend_cols", "xmap_extend_cols_slots", "xmap_nb_index", "xmap_path_plan", "xmap_end_order", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_predict", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
+    "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", 
+    "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_edge_ranges", "xmap_end_universe", "xmap_extend_cols", "xmap_extend_cols_slots", "xmap_nb_index", "xmap_path_plan", "xmap_end_order", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_predict", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
     "xmap_feed_text", "xmap_feed_texts", "xmap_feed_merge", "xmap_feed_sizes", "xmap_feed_arrays", "xmap_feed_ids", "xmap_feed_free",
     "xmap_ctx_upload_feed", "xmap_feed_format", "xmap_ctx_create", "xmap_ctx_destroy", "xmap_ctx_upload_ratings", "xmap_ctx_item_sim", "xmap_ctx_sim_download", "xmap_ctx_extend",
     "xmap_ctx_ext_download", "xmap_ctx_ext_lists", "xmap_ctx_candidates", "xmap_ctx_generate", "xmap_ctx_gen_download",
@@ -82,6 +84,10 @@ lib = C.CDLL(LIB_PATH)
 lib.xmap_last_error.restype = C.c_char_p
 for _n in EXPORTS:
     getattr(lib, _n)  # every symbol the header declares must be exported
+# declared under #ifdef XMAP_CROSSCHECK in the header: the test formulations (stage A by complete rows, the round-1 tile-major
+# enumeration, the dense-table form of the middle lists) -- exported by libxmap_hip_xcheck.so only
+XCHECK_EXPORTS = ["xmap_sim_plan", "xmap_sim_units", "xmap_sim_count", "xmap_sim_fill", "xmap_sim_row_ptr", "xmap_extend_paths2",
+                  "xmap_mid_tally", "xmap_mid_place"]
 
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "..", "..", "include", "xmap_hip.h"))
 
@@ -92,6 +98,7 @@ def header_prototypes(path=HEADER_PATH):
     import re
     with open(path) as f:
         text = f.read()
+    text = re.sub(r"#\s*ifdef\s+XMAP_CROSSCHECK[^\n]*\n", "\n", text)      # (the guarded prototypes are parsed too: XCHECK_EXPORTS)
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
     out = {}
@@ -115,18 +122,44 @@ def header_prototypes(path=HEADER_PATH):
 
 # argtypes of every export: a mis-ordered or mis-typed argument raises in ctypes instead of corrupting device memory
 PROTOTYPES = header_prototypes()
-for _n, _t in PROTOTYPES.items():
-    _f = getattr(lib, _n)
-    _f.argtypes = _t
-    if _n in ("xmap_ctx_destroy", "xmap_feed_free"):
-        _f.restype = None
-    elif _n != "xmap_last_error":
-        _f.restype = C.c_int
+
+
+def _bind(L, names):
+    for _n in names:
+        _f = getattr(L, _n)
+        _f.argtypes = PROTOTYPES[_n]
+        if _n in ("xmap_ctx_destroy", "xmap_feed_free"):
+            _f.restype = None
+        elif _n != "xmap_last_error":
+            _f.restype = C.c_int
+
+
+_bind(lib, [n for n in PROTOTYPES if n not in XCHECK_EXPORTS])
+_xlib = None
+
+
+def xlib():
+    """libxmap_hip_xcheck.so: every product entry point + the test formulations.  Loaded on first use (tests, tuning tools:
+    Engine.item_sim(algo="rows"), extend(algo="mid"), XMAP_MID_TABLE=1); the pipelines never call it."""
+    global _xlib
+    if _xlib is None:
+        if not os.path.exists(XLIB_PATH):
+            raise ImportError("libxmap_hip_xcheck.so not built (%s): make -C x-map_amd/csrc" % XLIB_PATH)
+        L = C.CDLL(XLIB_PATH)
+        L.xmap_last_error.restype = C.c_char_p
+        _bind(L, list(PROTOTYPES))
+        _xlib = L
+    return _xlib
 
 
 def check(rc):
     if rc != 0:
         raise XmapError(rc, (lib.xmap_last_error() or b"").decode())
+
+
+def xcheck(rc):
+    if rc != 0:
+        raise XmapError(rc, (xlib().xmap_last_error() or b"").decode())
 
 
 def vp(t):
