@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   mkdir -p $V
   make -C $C -j8 >/dev/null
   for n in $2; do
-    flags=""; for f in ${n//+/ }; do if [ "$f" = ATRACE ]; then flags="$flags -DA_TRACE"; elif [ "$f" = P_TRACE ]; then flags="$flags -DP_TRACE -DQ_PIPE"; elif [[ "$f" == Q_* ]]; then flags="$flags -D$f"; elif [[ "$f" == *=* ]]; then flags="$flags -DEXP_$f"; else flags="$flags -DEXP_$f"; fi; done
+    flags=""; for f in ${n//+/ }; do if [ "$f" = ATRACE ]; then flags="$flags -DA_TRACE"; elif [ "$f" = P_TRACE ]; then flags="$flags -DP_TRACE -DQ_PIPE"; elif [[ "$f" == Q_* || "$f" == P_WAVES=* ]]; then flags="$flags -D$f"; elif [[ "$f" == *=* ]]; then flags="$flags -DEXP_$f"; else flags="$flags -DEXP_$f"; fi; done
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $flags -c $C/${FILE:-stage_a2}.hip -o $V/a2_$n.o &
   done
   wait
