@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void k_bridge_flags(int I, const long long *ro
 // =============================================================================================
 constexpr int K_THREADS = 256;
 constexpr int K_CH = 2048;  // entries sorted per chunk (32 KB of LDS)
+constexpr int K_CH_SMALL = 512;   // rows up to this length: the 8 KB instance of k_knn_classify
 constexpr int K_WIN = 1024;  // entries streamed against the thresholds per step (rows longer than one chunk)
 
 __device__ __forceinline__ bool before(unsigned long long ka, int ca, unsigned long long kb, int cb) {
@@ -81,10 +82,14 @@ struct KnnArgs {
     double *kval;
 };
 
+// CH = entries sorted per chunk = the block's LDS (16 B each).  Two instances share the rows: rows of at most CH_SMALL
+// entries (nearly all of them) run with 8 KB of LDS -- eight blocks per CU instead of five: a block is a chain of dependent
+// gathers (row, class predicates, list values), and more blocks in flight is what hides them --, the long rows with 32 KB.
+template <int CH, int MODE>      // MODE 0: every row; 1: rows of at most CH entries; 2: rows of more than K_CH_SMALL
 __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
-    __shared__ unsigned long long skey[K_CH];
-    __shared__ int scol[K_CH];
-    __shared__ int spos[K_CH];
+    __shared__ unsigned long long skey[CH];
+    __shared__ int scol[CH];
+    __shared__ int spos[CH];
     __shared__ long long sscan[4];
     __shared__ unsigned long long s_thrk[2];
     __shared__ int s_thrc[2], s_has[2], s_fill;
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
     const int tid = threadIdx.x;
     const long long lo = A.row_ptr[i];
     const int n = (int)(A.row_ptr[i + 1] - lo);
+    if ((MODE == 1 && n > CH) || (MODE == 2 && n <= K_CH_SMALL)) return;      // (the other instance's row)
     const int k = A.k;
     // the unused tail of a list is zero (the tables come uninitialised: a fill of the ~1 GB they take at k = 50 cost
     // more than the lists of the few short rows)
@@ -119,8 +125,8 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
     int nc = 0, consumed = 0;
     for (;;) {
         int total;
-        if (consumed == 0 || K_CH - nc < K_WIN) {
-            const int take = (K_CH - nc) < (n - consumed) ? (K_CH - nc) : (n - consumed);
+        if (consumed == 0 || CH - nc < K_WIN) {
+            const int take = (CH - nc) < (n - consumed) ? (CH - nc) : (n - consumed);
             for (int t = tid; t < take; t += K_THREADS) {
                 int p = consumed + t;
                 double s = A.sim[lo + p];
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
             for (;;) {
                 const int f = s_fill;      // the same value for every thread: nobody is past the barrier below yet
                 __syncthreads();
-                if (consumed >= n || K_CH - f < K_WIN) break;
+                if (consumed >= n || CH - f < K_WIN) break;
 #pragma unroll
                 for (int u = 0; u < K_WIN / K_THREADS; u++) {
                     const int p = consumed + tid + K_THREADS * u;
@@ -175,7 +181,37 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
             spos[t] = -1;
         }
         __syncthreads();
-        // bitonic sort by (|sim| desc, col asc); pads (|sim| = 0) end up last
+        // bitonic sort by (|sim| desc, col asc); pads (|sim| = 0) end up last.
+        // Up to 128 entries (two thirds of the rows): ONE wave runs the whole network -- 64 compare-exchanges per step, the
+        // LDS operations of a wave execute in order, so the 28 steps need no block barrier (a barrier per step, 36 of them
+        // for 256 entries, was most of a short row's time: 400 000 blocks x ~17 us).
+        if (N <= 128) {
+            if (tid < 64) {
+                for (int k2 = 2; k2 <= N; k2 <<= 1) {
+                    for (int j = k2 >> 1; j > 0; j >>= 1) {
+                        const int t = tid;
+                        if (t < (N >> 1)) {
+                            int a = 2 * t - (t & (j - 1));
+                            int b = a + j;
+                            bool up = (a & k2) == 0;
+                            unsigned long long ka = skey[a], kb = skey[b];
+                            int ca = scol[a], cb = scol[b];
+                            bool sw = up ? before(kb, cb, ka, ca) : before(ka, ca, kb, cb);
+                            if (sw) {
+                                skey[a] = kb; skey[b] = ka;
+                                scol[a] = cb; scol[b] = ca;
+                                int pa = spos[a], pb = spos[b];
+                                spos[a] = pb; spos[b] = pa;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                }
+            }
+            __syncthreads();
+        } else
         for (int k2 = 2; k2 <= N; k2 <<= 1) {
             for (int j = k2 >> 1; j > 0; j >>= 1) {
                 for (int t = tid; t < (N >> 1); t += K_THREADS) {
@@ -253,8 +289,8 @@ __global__ __launch_bounds__(K_THREADS) void k_knn_classify(KnnArgs A) {
             return;
         }
         // carry the selected <= 2k entries to the front (sorted order kept), then take the next chunk
-        unsigned long long rk[K_CH / K_THREADS];
-        int rc[K_CH / K_THREADS], rp[K_CH / K_THREADS];
+        unsigned long long rk[CH / K_THREADS];
+        int rc[CH / K_THREADS], rp[CH / K_THREADS];
         int nk = 0;
         for (int t = s0; t < s0 + per && t < total; t++) {
             int c = scol[t];
@@ -357,7 +393,8 @@ __device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, 
         b = A.col[p];
         sv = A.sim[p];
         double ab = fabs(sv);
-        int cb = A.cls[b];
+        int cb = A.cls[b];     // (a 1-byte gather from a 400 KB table; the 16-byte threshold record only for the entries that pass it --
+                               //  packing the class into that record made EVERY entry gather it: 6.7 -> 8.3 ms, round 4)
         if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
             ok = (cb == 2) && in_list(A, b, 0, a, ab);
         } else if (A.mode == 1) {    // src(t = a): s = b
@@ -845,6 +882,16 @@ __global__ __launch_bounds__(256) void k_mid_build(MidArgs A) {
 // built in column ranges [x0, x0 + span), one after the other -- every range walks the row's (t, s, x) again and keeps the
 // x of its range, the directory and the records of the ranges follow each other (x order is kept).  Rounds 1-2 fell back
 // to the dense n_nb x n_nb table beyond 40 000 non-bridge items (120 GB at 1e5) and the coarse ABI refused.
+// the value of lane SRC of every quad, in all four lanes of the quad (DPP quad_perm: no LDS traffic)
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int CTRL = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 constexpr int MIDROW_WAVES = 16;
 template <int PHASE, bool ONE_RANGE>
 __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int span, int *ng, long long *nrec, const long long *dir_ptr,
@@ -1326,16 +1373,6 @@ __device__ unsigned long long g_ptrace[16];
 #define PT(i)
 #endif
 constexpr int END_HOME = 1 << 30;
-
-// the value of lane SRC of every quad, in all four lanes of the quad (DPP quad_perm: no LDS traffic)
-template <int SRC>
-__device__ __forceinline__ double quad_bcast(double v) {
-    constexpr int CTRL = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 template <bool FASTDIV>
 __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi,
@@ -2369,7 +2406,13 @@ int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t 
     A.row_ptr = (const long long *)S->row_ptr; A.col = S->col; A.sim = S->sim; A.mutu = S->mutu; A.nij = S->nij;
     A.info = S->info; A.frac = S->frac; A.bb = bb; A.suffix_cls = suffix_cls; A.contains_mask = contains_mask;
     A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
-    k_knn_classify<<<dim3((unsigned)(row_hi - row_lo)), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+    if (2 * top_k <= K_CH_SMALL / 2) {
+        k_knn_classify<K_CH_SMALL, 1><<<dim3((unsigned)(row_hi - row_lo)), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+        XM_LAUNCH_CHECK();
+        k_knn_classify<K_CH, 2><<<dim3((unsigned)(row_hi - row_lo)), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+    } else {      // (lists too long for the small instance's carry-over: every row on the large one)
+        k_knn_classify<K_CH, 0><<<dim3((unsigned)(row_hi - row_lo)), dim3(K_THREADS), 0, (hipStream_t)stream>>>(A);
+    }
     XM_LAUNCH_CHECK();
     return XMAP_OK;
 }
