@@ -903,6 +903,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int n_nb = A.n_nb;
     const int nq = A.kcnt[(size_t)xp * 2];
+#ifdef EXP_MID_WALK1     // (rounds 2-4a: a serial loop over the row's neighbours t, one joint (t, s) per wave step -- kept for the ablation)
     // the joint (t,s) of the row are dealt round-robin to the waves (every wave scans the flags, 64 at a time); the
     // lanes of a wave walk attach(s) together (coalesced, distinct x: no two lanes meet on a counter)
     auto walk = [&](int x0, int x1, auto &&body) {
@@ -930,6 +931,75 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
             }
         }
     };
+#else
+    // The walk, round 4: a row of configs[1] has 10 000 records behind ~50 neighbours t and ~500 joint (t, s), and ONE block
+    // builds it -- what the block takes is the chain of dependent memory trips of its slowest wave.  The first form ran the
+    // neighbours as a serial loop (three dependent trips per t: list entry -> flag, source range -> joint flags) and gave a
+    // wave one joint per step (attach lists hold ~20 entries: a third of the lanes, four more trips per step): ~270 trips per
+    // wave and walk.  Now (a) the row's neighbours sit one per LANE: their three trips are taken once for all of them;
+    // (b) the 64-entry chunks of the source lists are dealt to the waves, and a chunk's joints are walked FLAT: lane l of
+    // round r0 takes record r0 + l of the chunk (inclusive scan of the attach-list lengths over the lanes, the record's joint
+    // found by a six-step search over the starts in LDS) -- every lane of every round but the last is busy and the rounds
+    // of a chunk are independent.  ~50 trips per wave and walk.
+    __shared__ int s_off[MIDROW_WAVES][64];
+    __shared__ long long s_a0[MIDROW_WAVES][64];
+    volatile int *w_off = s_off[w];
+    volatile long long *w_a0 = s_a0[w];
+    auto walk = [&](int x0, int x1, auto &&body) {
+        int ctr = 0;
+        for (int qb = 0; qb < nq; qb += 64) {
+            const int ql = qb + lane;
+            long long s0l = 0, s1l = 0;
+            double v2l = 0.0, m2l = 0.0, f2l = 0.0;
+            bool tok = false;
+            if (ql < nq) {
+                const size_t o = ((size_t)xp * 2) * A.k + ql;
+                const int t = A.kcol[o];
+                tok = (A.flags[t] & 2) != 0;
+                s0l = A.src_ptr[t]; s1l = A.src_ptr[t + 1];
+                v2l = A.kval[o * 3]; m2l = A.kval[o * 3 + 1]; f2l = A.kval[o * 3 + 2];              // edge (x', t)
+            }
+            unsigned long long qm = __ballot(tok && s1l > s0l);
+            while (qm) {
+                const int l = __ffsll((long long)qm) - 1;
+                qm &= qm - 1;
+                const long long s0 = rl64(s0l, l), s1 = rl64(s1l, l);
+                const double v2 = __longlong_as_double(rl64(__double_as_longlong(v2l), l));
+                const double m2 = __longlong_as_double(rl64(__double_as_longlong(m2l), l));
+                const double f2 = __longlong_as_double(rl64(__double_as_longlong(f2l), l));
+                for (long long base = s0; base < s1; base += 64) {
+                    if ((ctr++ % MIDROW_WAVES) != w) continue;
+                    const long long pl = (base + lane < s1) ? base + lane : s0;
+                    const bool joint = (base + lane < s1) && (A.src_flag[pl] & 1);
+                    const int s = A.src_idx[pl];
+                    long long a0 = 0;
+                    int len = 0;
+                    if (joint) { a0 = A.att_ptr[s]; len = (int)(A.att_ptr[s + 1] - a0); }
+                    int incl = len;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+                    const int T = rl32(incl, 63);
+                    if (T == 0) continue;
+                    __builtin_amdgcn_wave_barrier();
+                    w_off[lane] = incl - len;            // first record of the lane's joint (lanes without records: their successor's)
+                    w_a0[lane] = a0;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int r0 = 0; r0 < T; r0 += 64) {
+                        const int r = r0 + lane;
+                        int j = 0;                       // the last lane whose joint starts at or before record r
+#pragma unroll
+                        for (int st = 32; st >= 1; st >>= 1) if (w_off[j + st] <= r) j += st;
+                        if (r < T) {
+                            const long long ap = w_a0[j] + (r - w_off[j]);
+                            const int xid = A.nb_id[A.att_idx[ap]];
+                            if (ONE_RANGE || (xid >= x0 && xid < x1)) body(xid, v2, m2, f2, base + j, ap);
+                        }
+                    }
+                }
+            }
+        }
+    };
+#endif
     unsigned long long done = 0;                        // (non-empty tiles << 40 | records) of the ranges before this one
     const long long rbase = PHASE ? rec_ptr[xpid] : 0, dbase = PHASE ? dir_ptr[xpid] : 0;
     for (int x0 = 0; x0 < n_nb; x0 += ONE_RANGE ? n_nb : span) {
@@ -1314,6 +1384,8 @@ constexpr int Q_CAP = 64;                  // prepared records per round (the he
 constexpr int Q_CAP = 128;                 // prepared records per round
 #endif
 struct QLds {
+    // (three arrays, not one record of four words per quad as the quad leaves them: that layout -- one 512-byte store, b64 +
+    //  b128 reads at a 32-byte stride in the record loop -- measured 515 ms against 475, profiles/r04h_paths_columns.txt)
     double bsm[Q_CAP + 1], bc[Q_CAP + 1], bmu[Q_CAP + 1];      // (entry Q_CAP: the neutral record (0, 0, 1) of heads_Q's record loop)
 #ifdef Q_RPIECE
     double hd[3][64];                      // first edge of every head of the batch: [0] sim * mutu, [1] frac, [2] mutu
@@ -1373,6 +1445,9 @@ __device__ unsigned long long g_ptrace[16];
 #define PT(i)
 #endif
 constexpr int END_HOME = 1 << 30;
+#ifdef Q_HIST                              // (probe build, profiles/tools/col_hist.py: column visits by heads / ends / records)
+__device__ unsigned long long g_qhist[128];
+#endif
 
 template <bool FASTDIV>
 __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi,
@@ -1455,9 +1530,22 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
         const int first_l = __ffsll((long long)part) - 1;
         const int ne = rl32(cur.ne, first_l);
         const ColEnd *ce = B.cend + (size_t)rl32(cur.pad, first_l) * (k + 1);
+#ifdef Q_SHN
+        // (-DQ_SHN, the review's lever 2a) slices from the RECORDS as well as from the ends: a slice level more is an exchange
+        // (22 instructions) and saves steps (28 each) only from three records on; the count is at hand when one head has the
+        // column.  30 % of the column visits have one or two records (profiles/r04h_paths_columns.txt) -- and the kernel takes
+        // 478 ms with it against 475 without: not the default
+        const int n1col = (part & (part - 1)) == 0 ? rl32(cur.cnt, first_l) : Q_CAP;
+        const int shn = n1col <= 1 ? 0 : (n1col <= 2 ? 1 : 2);
+#endif
         for (int b = 0; b < ne; b += 64) {
             const int nact = (ne - b) < 64 ? (ne - b) : 64;
+#ifdef Q_SHN
+            const int she = nact <= 16 ? 2 : (nact <= 32 ? 1 : 0);
+            const int sh = she < shn ? she : shn;
+#else
             const int sh = nact <= 16 ? 2 : (nact <= 32 ? 1 : 0);     // log2 of the record slices per end
+#endif
             const int ns = 1 << sh;
             const int q = lane >> sh, slice = lane & (ns - 1);
             // Memory round trips of a column: {end records, first set of merged records} together, then the row entries
@@ -1619,6 +1707,14 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
                 }
 #endif
                 asm volatile("" ::: "memory");
+#ifdef Q_HIST
+                if (lane == 0) {
+                    const int c_n = fill <= 1 ? 0 : (fill <= 2 ? 1 : (fill <= 4 ? 2 : (fill <= 8 ? 3 : (fill <= 16 ? 4 : (fill <= 32 ? 5 : 6)))));
+                    const int c_e = nact <= 4 ? 0 : (nact <= 8 ? 1 : (nact <= 16 ? 2 : (nact <= 32 ? 3 : 4)));
+                    const int c_h = nloc == 1 ? 0 : (__popcll(part) == 1 ? 1 : 2);
+                    atomicAdd(&g_qhist[(c_h * 5 + c_e) * 7 + c_n], 1ull);
+                }
+#endif
                 double a_sh = 0.0, a_sl = 0.0, a_ch = 0.0, a_cl = 0.0;
                 const int steps = (fill + ns - 1) >> sh;
 #if defined(Q_NOCOMPUTE)
@@ -2373,6 +2469,12 @@ __global__ __launch_bounds__(256) void k_w_starts(int I, const uint8_t *flags, c
 using namespace xmap;
 
 extern "C" {
+#ifdef Q_HIST
+int xmap_debug_qhist(unsigned long long *host, int reset) {
+    if (reset) { unsigned long long z[128] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(xmap::g_qhist), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xmap::g_qhist), 128 * sizeof(unsigned long long));
+}
+#endif
 #ifdef P_TRACE
 int xmap_debug_ptrace(unsigned long long *host, int reset) {
     if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(xmap::g_ptrace), z, sizeof(z)); }
@@ -2628,6 +2730,8 @@ static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const in
 }
 
 // row-wise construction (k_mid_rows); the tile counters of a column range of the row live in LDS
+static_assert((size_t)XMAP_MID_ROWS_SPAN * 4 + (size_t)MIDROW_WAVES * 64 * 12 + 256 <= 160 * 1024,
+              "k_mid_rows: tile counters + the waves' walk state must fit the LDS of a gfx950 CU");
 static int mid_rows_lds(int32_t n_nb, size_t *bytes, int *span) {
     int cap = XMAP_MID_ROWS_SPAN;
     if (const char *e = getenv("XMAP_MID_ROWS_SPAN")) {      // tests: several column ranges on small inputs

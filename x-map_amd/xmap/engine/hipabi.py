@@ -15,7 +15,7 @@ XLIB_PATH = os.environ.get("XMAP_HIP_XLIB") or os.path.normpath(os.path.join(HER
 COSINE, ADJUST_COSINE = 0, 1
 METHODS = {"cosine": COSINE, "adjust_cosine": ADJUST_COSINE}
 TOPC = 10
-MID_ROWS_SPAN = 40000     # XMAP_MID_ROWS_SPAN: columns of a middle-list row per LDS pass
+MID_ROWS_SPAN = 36864     # XMAP_MID_ROWS_SPAN: columns of a middle-list row per LDS pass
 ERR_HIP, ERR_ARG, ERR_OVERFLOW, ERR_CAPACITY = -1, -2, -3, -4     # XMAP_ERR_* of include/xmap_hip.h
 
 
