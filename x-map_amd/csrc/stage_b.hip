@@ -1039,12 +1039,20 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
             __syncthreads();
             walk(x0, x1, [&](int xid, double v2, double m2, double f2, long long p, long long ap) {
                 const long long pos = rbase + atomicAdd(&bins[xid - x0], 1);
+#ifdef EXP_MID_NOVAL      // (ablation: no gathers of the edge values -- wrong records, timing only)
+                const double v3 = 1.0, m3 = 1.0, f3 = 1.0, v4 = 1.0, m4 = (double)(p + ap), f4 = 1.0;
+#else
                 const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];      // edge (t, s)
                 const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
+#endif
                 MidX r;
                 r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
                 r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
+#ifdef EXP_MID_NOSTORE    // (ablation: the records are not written -- timing only)
+                if (r.mu == -1.5) A.midX[pos] = r;
+#else
                 A.midX[pos] = r;
+#endif
             });
         }
         done += total;
