@@ -100,6 +100,42 @@ def test_native_feeder_matches_reference(gold, tmp_path, monkeypatch):
     assert rdd.collect() == want
 
 
+def test_native_feeder_reads_tokens_like_the_reference():
+    """parse_line (baselinerClean.py:46-52) converts the timestamp of every line and float(rating) only of the lines inside
+    the period; float() takes '1_0', 'inf', '1e1' and refuses hex floats; remove_invalid keeps one rating per (user, item),
+    the strictly later one in place -- also for a profile far longer than any scan per rating could take."""
+    from xmap.engine import feeder
+    T = 1356998400 + 86400 * 40            # inside 2013 (UTC)
+    OUT = 1262304000 + 86400 * 40          # inside 2010
+    ok = feeder.Feed.from_text("u1 i1 4.0 %d\nu1 i2 bad %d\nu1 i3 1_0 %d\nu1 i4 1e1 %d\n" % (T, OUT, T, T), 2012, 2013, "S:", 1)
+    assert [(i, r) for (i, r, _) in ok.records()[0][1]] == [("i1S:", 4.0), ("i3S:", 10.0), ("i4S:", 10.0)]
+    assert ok.n_lines == 4
+    for bad in ("u1 i1 bad %d\n" % T, "u1 i1 0x10 %d\n" % T, "u1 i1 1__0 %d\n" % T, "u1 i1 _1 %d\n" % T,
+                "u1 i1 nan(1) %d\n" % T, "u1 i1 4.0 0x5\n", "u1 i1 4.0 later\n"):
+        with pytest.raises(Exception):
+            feeder.Feed.from_text(bad, 2012, 2013, "S:", 1)
+    inf = feeder.Feed.from_text("u1 i1 -Infinity %d\n" % T, 2012, 2013, "S:", 1).records()[0][1][0][1]
+    assert inf == float("-inf")
+    # a crawler account: 40 000 ratings over 5 000 items, every item rated eight times -- the latest (strictly) wins in place
+    rng = np.random.default_rng(5)
+    it = rng.integers(0, 5000, 40000)
+    when = T + rng.integers(0, 86400 * 200, 40000)
+    val = rng.integers(1, 6, 40000).astype(float)
+    text = "".join("crawler i%d %.1f %d\n" % (a, v, w) for a, v, w in zip(it, val, when)) + "u2 i1 3.0 %d\n" % T
+    best, order = {}, []
+    for a, v, w in zip(it, val, when):
+        k = "i%dS:" % a
+        if k not in best:
+            order.append(k); best[k] = (v, w)
+        elif w > best[k][1]:
+            best[k] = (v, w)
+    t0 = time.time()
+    rec = feeder.Feed.from_text(text, 2012, 2014, "S:", 1).records()
+    assert time.time() - t0 < 5.0
+    assert rec[0][0] == "crawler" and [(i, r) for (i, r, _) in rec[0][1]] == [(k, best[k][0]) for k in order]
+    assert [w for (_, _, w) in rec[0][1]] == [dt(best[k][1]) for k in order]
+
+
 def test_split_protocol():
     from xmap.core.baselinerSplit import BaselinerSplit
     from xmap.utils.assist import baseliner_split_data_pipeline

@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <new>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -118,13 +120,39 @@ bool to_double(std::string_view t, double &v) {
             return true;
         }
     }
+    // the rest as Python's float() reads it: decimal digits with single underscores BETWEEN digits ("1_0" is 10.0), one
+    // '.', an exponent, a sign -- or inf / infinity / nan in any case; no hex floats, no "nan(...)" (strtod takes both)
     if (t.empty() || t.size() > 63) return false;
     char buf[64];
-    memcpy(buf, t.data(), t.size());
-    buf[t.size()] = 0;
+    size_t n = 0, i = 0;
+    if (t[0] == '+' || t[0] == '-') buf[n++] = t[i++];
+    auto word = [&](const char *w) {
+        const size_t L = strlen(w);
+        if (t.size() - i != L) return false;
+        for (size_t k = 0; k < L; k++) if ((t[i + k] | 0x20) != w[k]) return false;
+        return true;
+    };
+    if (word("inf") || word("infinity") || word("nan")) {
+        memcpy(buf + n, t.data() + i, t.size() - i);
+        n += t.size() - i;
+    } else {
+        for (; i < t.size(); i++) {
+            const char c = t[i];
+            const bool dig = c >= '0' && c <= '9';
+            if (c == '_') {
+                const bool before = i > 0 && t[i - 1] >= '0' && t[i - 1] <= '9';
+                const bool after = i + 1 < t.size() && t[i + 1] >= '0' && t[i + 1] <= '9';
+                if (!before || !after) return false;
+                continue;
+            }
+            if (!(dig || c == '.' || c == 'e' || c == 'E' || c == '+' || c == '-')) return false;
+            buf[n++] = c;
+        }
+    }
+    buf[n] = 0;
     char *end = nullptr;
     v = strtod(buf, &end);
-    return end == buf + t.size();
+    return n > 0 && end == buf + n;
 }
 
 void predicates(Feed &F) {
@@ -162,12 +190,9 @@ struct xmap_feed { Feed F; };
 /* n_parts texts (the domains of one problem, each with its label) -> ONE feed: users in first-seen order over the parts in
  * the order given, a user's entries of an earlier part in front of those of a later one (= xmap_feed_merge of the parts'
  * feeds, without building them) */
-int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *lens, const char *const *labels, int32_t year_from,
-                    int32_t year_to, int32_t min_ratings, xmap_feed **out) {
-    XM_ARG(out && n_parts >= 1 && n_parts <= 30 && texts && lens && labels);
-    for (int q = 0; q < n_parts; q++) XM_ARG((texts[q] || lens[q] == 0) && lens[q] >= 0 && labels[q]);
-    *out = nullptr;
-    xmap_feed *H = new xmap_feed();
+static int feed_texts_impl(int32_t n_parts, const char *const *texts, const int64_t *lens, const char *const *labels,
+                           int32_t year_from, int32_t year_to, int32_t min_ratings, xmap_feed **out) {
+    std::unique_ptr<xmap_feed> H(new xmap_feed());
     Feed &F = H->F;
     // the period as a range of seconds: local-time year in [year_from, year_to]  <=>  t0 <= floor(t) < t1 (one mktime per
     // bound instead of one localtime per line)
@@ -235,11 +260,14 @@ int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *le
                 while (p < eol && is_ws(text[p])) p++;
             }
             if (nt < 4 || eol == pos) { bad_line[k] = ln; bad_kind[k] = 1; return; }      // [''] / short line: IndexError
-            double t, r;
-            if (!to_double(tok[3], t) || !to_double(tok[2], r)) { bad_line[k] = ln; bad_kind[k] = 2; return; }
+            // parse_line: the timestamp of every line is converted, the rating only of the lines inside the period
+            // (baselinerClean.py:46-52: float(rating) sits behind the year test -- a bad rating outside the period is skipped)
+            double t, r = 0.0;
+            if (!to_double(tok[3], t)) { bad_line[k] = ln; bad_kind[k] = 2; return; }
             n_lines[k]++;
             const double fl = floor(t);
             if (fl >= t0 && fl < t1) {
+                if (!to_double(tok[2], r)) { bad_line[k] = ln; bad_kind[k] = 2; return; }
                 Rec q;
                 q.uid = tok[0]; q.iid = tok[1]; q.rating = r; q.when = t; q.uh = hash_bytes(tok[0]); q.ih = hash_bytes(tok[1]);
                 out_.push_back(q);
@@ -249,7 +277,12 @@ int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *le
     };
     {
         std::atomic<int> next(0);
-        auto worker = [&]() { for (int k = next++; k < npc; k = next++) parse_piece(k); };
+        auto worker = [&]() {
+            for (int k = next++; k < npc; k = next++) {
+                try { parse_piece(k); }
+                catch (...) { bad_line[k] = 0; bad_kind[k] = 3; }      // (out of memory inside a piece: reported below)
+            }
+        };
         std::vector<std::thread> th;
         for (int k = 1; k < nth && k < npc; k++) th.emplace_back(worker);
         worker();
@@ -262,7 +295,7 @@ int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *le
             if (pieces[k].part != part) { part = pieces[k].part; before = 0; }
             if (bad_line[k] >= 0) {
                 const long long ln = (long long)(before + bad_line[k]);
-                delete H;
+                if (bad_kind[k] == 3) { set_error("feeder: out of host memory while parsing text %d", part); return XMAP_ERR_CAPACITY; }
                 if (bad_kind[k] == 1) set_error("text %d, line %lld has fewer than 4 fields", part, ln);
                 else set_error("text %d, line %lld: rating / timestamp is not a number", part, ln);
                 return XMAP_ERR_ARG;
@@ -327,21 +360,25 @@ int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *le
             for (const Tmp &t : tmp) tmp2[at[local[t.u]]++] = t;
             tmp.swap(tmp2);
         }
+        // one rating per (user, item): where the current user's entry of an item sits (-1: none yet) -- O(1) per rating
+        // whatever the length of the profile (a scan of the user's entries per rating made a crawler account of 10^5
+        // ratings 5*10^9 comparisons); the table is reset through the entries the user touched
+        std::vector<int64_t> at_item(inames.size(), -1);
         size_t y = 0;
         while (y < tmp.size()) {
             const int32_t u = tmp[y].u;
             const size_t first = ent.size();
             for (; y < tmp.size() && tmp[y].u == u; y++) {
                 const Tmp &t = tmp[y];
-                bool seen = false;
-                for (size_t z = first; z < ent.size(); z++)
-                    if (ent[z].item == t.it) {
-                        if (t.when > ent[z].when) { ent[z].rating = t.rating; ent[z].when = t.when; }
-                        seen = true;
-                        break;
-                    }
-                if (!seen) ent.push_back(Entry{t.it, t.rating, t.when});
+                const int64_t z = at_item[t.it];
+                if (z >= 0) {
+                    if (t.when > ent[z].when) { ent[z].rating = t.rating; ent[z].when = t.when; }
+                } else {
+                    at_item[t.it] = (int64_t)ent.size();
+                    ent.push_back(Entry{t.it, t.rating, t.when});
+                }
             }
+            for (size_t z = first; z < ent.size(); z++) at_item[ent[z].item] = -1;
             runs[q].push_back(Run{u, (int64_t)first, (int64_t)ent.size()});
         }
     }
@@ -384,7 +421,6 @@ int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *le
         remap[order[k]] = (int32_t)k;
         F.iids.push_back(std::string(inames[order[k]]) + labs[ipart[order[k]]]);
         if (k && !(F.iids[k - 1] < F.iids[k])) {
-            delete H;
             set_error("the item id %s occurs in two of the texts", F.iids[k].c_str());
             return XMAP_ERR_ARG;
         }
@@ -409,12 +445,25 @@ int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *le
     predicates(F);
     lap("predicates");
     if (F.iids.size() && *std::max_element(F.suffix_cls.begin(), F.suffix_cls.end()) >= 32) {
-        delete H;
         set_error("more than 32 distinct 2-char id suffixes (domain labels)");
         return XMAP_ERR_ARG;
     }
-    *out = H;
+    *out = H.release();
     return XMAP_OK;
+}
+
+/* no C++ exception crosses the C ABI: running out of host memory is XMAP_ERR_CAPACITY */
+#define XM_FEED_GUARD(call)                                                                         \
+    try { return call; }                                                                            \
+    catch (const std::bad_alloc &) { set_error("feeder: out of host memory"); return XMAP_ERR_CAPACITY; } \
+    catch (const std::exception &e) { set_error("feeder: %s", e.what()); return XMAP_ERR_CAPACITY; }
+
+int xmap_feed_texts(int32_t n_parts, const char *const *texts, const int64_t *lens, const char *const *labels, int32_t year_from,
+                    int32_t year_to, int32_t min_ratings, xmap_feed **out) {
+    XM_ARG(out && n_parts >= 1 && n_parts <= 30 && texts && lens && labels);
+    for (int q = 0; q < n_parts; q++) XM_ARG((texts[q] || lens[q] == 0) && lens[q] >= 0 && labels[q]);
+    *out = nullptr;
+    XM_FEED_GUARD(feed_texts_impl(n_parts, texts, lens, labels, year_from, year_to, min_ratings, out))
 }
 
 int xmap_feed_text(const char *text, int64_t len, int32_t year_from, int32_t year_to, const char *label, int32_t min_ratings,
@@ -425,11 +474,9 @@ int xmap_feed_text(const char *text, int64_t len, int32_t year_from, int32_t yea
 
 /* the union of two feeds (source + target domain of one problem): users of a in a's order, then the users only b has;
  * a user both have gets a's entries followed by b's; item ids must be disjoint (different domain labels) */
-int xmap_feed_merge(const xmap_feed *a, const xmap_feed *b, xmap_feed **out) {
-    XM_ARG(a && b && out);
-    *out = nullptr;
+static int feed_merge_impl(const xmap_feed *a, const xmap_feed *b, xmap_feed **out) {
     const Feed &A = a->F, &B = b->F;
-    xmap_feed *H = new xmap_feed();
+    std::unique_ptr<xmap_feed> H(new xmap_feed());
     Feed &F = H->F;
     F.n_lines = A.n_lines + B.n_lines; F.n_in_period = A.n_in_period + B.n_in_period;
     // items: merge of the two sorted tables
@@ -439,7 +486,7 @@ int xmap_feed_merge(const xmap_feed *a, const xmap_feed *b, xmap_feed **out) {
         while (i < A.iids.size() || j < B.iids.size()) {
             if (j == B.iids.size() || (i < A.iids.size() && A.iids[i] < B.iids[j])) { ra[i] = (int32_t)F.iids.size(); F.iids.push_back(A.iids[i++]); }
             else if (i == A.iids.size() || B.iids[j] < A.iids[i]) { rb[j] = (int32_t)F.iids.size(); F.iids.push_back(B.iids[j++]); }
-            else { delete H; set_error("the two feeds share the item id %s", A.iids[i].c_str()); return XMAP_ERR_ARG; }
+            else { set_error("the two feeds share the item id %s", A.iids[i].c_str()); return XMAP_ERR_ARG; }
         }
     }
     size_t cap = 1 << 10;
@@ -472,12 +519,17 @@ int xmap_feed_merge(const xmap_feed *a, const xmap_feed *b, xmap_feed **out) {
     }
     predicates(F);
     if (F.iids.size() && *std::max_element(F.suffix_cls.begin(), F.suffix_cls.end()) >= 32) {
-        delete H;
         set_error("more than 32 distinct 2-char id suffixes (domain labels)");
         return XMAP_ERR_ARG;
     }
-    *out = H;
+    *out = H.release();
     return XMAP_OK;
+}
+
+int xmap_feed_merge(const xmap_feed *a, const xmap_feed *b, xmap_feed **out) {
+    XM_ARG(a && b && out);
+    *out = nullptr;
+    XM_FEED_GUARD(feed_merge_impl(a, b, out))
 }
 
 int xmap_feed_sizes(const xmap_feed *f, int64_t *sizes /*[7]*/) {
