@@ -33,7 +33,11 @@ def _worker(rank, world, port, q):
     top[rank * 2:(rank + 1) * 2] = rank + 7
     comm.all_reduce(top, "max")
     w = np.array([4, 1, 1, 1, 1, 4, 2, 2])
-    q.put((rank, allp.tolist(), val.tolist(), cnt.tolist(), top.tolist(), balanced_ranges(w, world)))
+    # several tensors of different types and lengths in ONE exchange (odd byte counts, an empty part, nothing at all from rank 0)
+    multi = comm.all_gather_multi([torch.arange(5 * rank, dtype=torch.uint8) + rank, torch.full((3 - rank,), 0.5 + rank, dtype=torch.float64),
+                                   torch.arange(7 * rank, dtype=torch.int32) * (rank + 1), torch.zeros(0, dtype=torch.int64)])
+    q.put((rank, allp.tolist(), val.tolist(), cnt.tolist(), top.tolist(), balanced_ranges(w, world),
+           [(str(m.dtype), m.tolist()) for m in multi]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +53,9 @@ def test_comm_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, allp, val, cnt, top, ranges in got:
+    for rank, allp, val, cnt, top, ranges, multi in got:
+        assert multi == [("torch.uint8", [1, 2, 3, 4, 5]), ("torch.float64", [0.5, 0.5, 0.5, 1.5, 1.5]),
+                         ("torch.int32", [0, 2, 4, 6, 8, 10, 12]), ("torch.int64", [])]
         assert allp == [100, 101, 102]            # rank 0 contributed nothing, rank 1 three entries
         assert val == [0.0, 0.0, 1.0]
         assert cnt == [3, 6, 9]

@@ -818,11 +818,12 @@ class Engine(object):
         check(lib.xmap_reverse_count(_stream(self.dev), *st8.args, vp(st8.rcnt), i32(st8.rows[0]), i32(st8.rows[1])))
         return st8
 
-    def reverse_gather_counts(self, st8, comm):
-        """collective: every rank's counts of its rows -> the counts of all rows"""
+    def reverse_gather_counts(self, sts, comm):
+        """collective: every rank's counts of its rows -> the counts of all rows (of several lists in one exchange)"""
         I = self.R.n_items
-        lo, hi = st8.rows
-        st8.rcnt[:I] = comm.all_gather_var(st8.rcnt[lo:hi].contiguous())
+        lo, hi = sts[0].rows
+        for st8, c in zip(sts, comm.all_gather_multi([st8.rcnt[lo:hi] for st8 in sts])):
+            st8.rcnt[:I] = c
 
     def reverse_fill(self, st8):
         """offsets of all rows (scan of the complete counts), then the entries of this device's rows"""
@@ -838,17 +839,23 @@ class Engine(object):
         check(lib.xmap_reverse_fill(st, *st8.args, vp(rptr), vp(ridx), vp(rval), vp(rflag), i32(st8.rows[0]), i32(st8.rows[1])))
         st8.out = (rptr, ridx, rval, rflag, n)
 
-    def reverse_gather(self, st8, comm):
-        """collective: the ranks' pieces of the lists, in rank (= row) order"""
-        rptr, ridx, rval, rflag, n = st8.out
-        lo, hi = st8.rows
-        ends = rptr[[lo, hi]].tolist()
-        a, b = int(ends[0]), int(ends[1])
-        if n:
-            ridx[:n] = comm.all_gather_var(ridx[a:b].contiguous())
-            rval[:n] = comm.all_gather_var(rval[a:b].reshape(-1)).view(n, 3)
-            rflag[:n] = comm.all_gather_var(rflag[a:b].contiguous())
-        return st8.out
+    def reverse_gather(self, sts, comm):
+        """collective: the ranks' pieces of the lists, in rank (= row) order -- ONE exchange for all the lists given"""
+        send = []
+        for st8 in sts:
+            rptr, ridx, rval, rflag, n = st8.out
+            lo, hi = st8.rows
+            ends = rptr[[lo, hi]].tolist()
+            a, b = int(ends[0]), int(ends[1])
+            send += [ridx[a:b], rval[a:b].reshape(-1), rflag[a:b]]
+        got = comm.all_gather_multi(send)
+        for j, st8 in enumerate(sts):
+            rptr, ridx, rval, rflag, n = st8.out
+            if n:
+                ridx[:n] = got[3 * j]
+                rval[:n] = got[3 * j + 1].view(n, 3)
+                rflag[:n] = got[3 * j + 2]
+        return [st8.out for st8 in sts]
 
     def path_units(self, E, start_range=None, chunk=None, row_budget=48 << 30, start_split=None):
         """Work units of the path enumeration from the exact per-start path counts: starts with more than
@@ -1099,10 +1106,12 @@ class Engine(object):
             fd = torch.tensor([E.fast_div], dtype=torch.int64, device=self.dev)      # (every rank checked its own rows' edges)
             comm.all_reduce(fd, "min")
             E.fast_div = int(fd.item())
-            E.cls[:I] = comm.all_gather_var(E.cls[lo:hi].contiguous())
-            E.kcnt[:I] = comm.all_gather_var(E.kcnt[lo:hi].reshape(-1)).view(I, 2)
-            E.kcol[:I] = comm.all_gather_var(E.kcol[lo:hi].reshape(-1)).view(I, 2, k)
-            E.kval[:I] = comm.all_gather_var(E.kval[lo:hi].reshape(-1)).view(I, 2, k, 3)
+            cls, kcnt, kcol, kval = comm.all_gather_multi([E.cls[lo:hi], E.kcnt[lo:hi].reshape(-1), E.kcol[lo:hi].reshape(-1),
+                                                           E.kval[lo:hi].reshape(-1)])       # (one exchange for the four tables)
+            E.cls[:I] = cls
+            E.kcnt[:I] = kcnt.view(I, 2)
+            E.kcol[:I] = kcol.view(I, 2, k)
+            E.kval[:I] = kval.view(I, 2, k, 3)
         E.rows = None
         return E
 

@@ -106,6 +106,38 @@ class Comm(object):
         return out.to(dev)
 
 
+    def all_gather_multi(self, ts):
+        """Several 1-D tensors per rank (any dtypes, any lengths) -> for each of them the concatenation over the ranks, in
+        rank order -- TWO collectives whatever the number of tensors (the table of byte counts, then one padded byte buffer
+        per rank), where all_gather_var takes two per tensor."""
+        dev = ts[0].device
+        parts = []
+        for t in ts:
+            b = t.contiguous().view(-1).view(torch.uint8)
+            if b.numel() % 8:                                   # (every part starts 8-byte aligned inside the buffer)
+                b = torch.cat([b, torch.zeros(8 - b.numel() % 8, dtype=torch.uint8, device=b.device)])
+            parts.append(b)
+        table = self.all_gather_fixed(torch.tensor([t.numel() * t.element_size() for t in ts], dtype=torch.int64, device=dev)).cpu()
+        padded = (table + 7) // 8 * 8                           # [world, len(ts)] bytes incl. alignment
+        mine = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+        m = max(int(padded.sum(dim=1).max()), 8)
+        src = mine.cpu() if self.host else mine
+        pad = torch.zeros(m, dtype=torch.uint8, device=src.device)
+        pad[:src.numel()] = src
+        bufs = [torch.empty(m, dtype=torch.uint8, device=src.device) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad, group=self.group)
+        out = []
+        for j, t in enumerate(ts):
+            pieces = []
+            for r in range(self.world):
+                at = int(padded[r, :j].sum())
+                pieces.append(bufs[r][at:at + int(table[r, j])])
+            cat = torch.cat(pieces)
+            if cat.numel() % 8 == 0 and t.element_size() > 1:
+                cat = cat.clone()                               # (fresh storage: offset 0, viewable as any dtype)
+            out.append(cat.view(t.dtype).to(dev))
+        return out
+
     def all_gather_fixed(self, t):
         """[world, *t.shape]: the same-shaped tensor of every rank, in rank order"""
         src = t.contiguous().cpu() if self.host else t.contiguous()
@@ -188,9 +220,10 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
             # ONE exchange of the 32-byte item records and the two dense norm columns (S3 of SURVEY 2.3: the reference
             # collects and broadcasts item_info, utils/assist.py:71-73) -- the all-gather of per-item norms
             with eng.timed("stats_gather"):
-                info[:I] = comm.all_gather_var(info[ilo:ihi].reshape(-1)).view(I, 4)
-                for c0 in (0, nI):
-                    norms[c0:c0 + I] = comm.all_gather_var(norms[c0 + ilo:c0 + ihi].contiguous())
+                gi, g0, g1 = comm.all_gather_multi([info[ilo:ihi].reshape(-1), norms[ilo:ihi], norms[nI + ilo:nI + ihi]])
+                info[:I] = gi.view(I, 4)
+                norms[:I] = g0
+                norms[nI:nI + I] = g1
         # (no collective between a possible raise and the agree() that follows it)
         err, stats, L = None, None, None
         try:
@@ -248,7 +281,7 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
         with eng.timed("rows_gather"):
             nt = Gl.n_target_rows
             rec = torch.stack([Gl.user.long() | (Gl.item.long() << 32), Gl.rating.view(torch.int64), Gl.time], dim=1)
-            parts = [comm.all_gather_var(rec[:nt].reshape(-1)).view(-1, 3), comm.all_gather_var(rec[nt:].reshape(-1)).view(-1, 3)]
+            parts = [g.view(-1, 3) for g in comm.all_gather_multi([rec[:nt].reshape(-1), rec[nt:].reshape(-1)])]
             allr = torch.cat(parts)
             G = _Rows()
             G.user, G.item = (allr[:, 0] & 0xffffffff).int(), (allr[:, 0] >> 32).int()
@@ -329,10 +362,7 @@ def run_step_users(eng, user_lo, method, cap, k, private, dist, group=None, slot
         n_top, choice, mp = eng.select(E, private)
         Gl = eng.alterego(mp)
         G = _Rows()
-        G.user = comm.all_gather_var(Gl.user.long() + int(user_lo))
-        G.item = comm.all_gather_var(Gl.item)
-        G.rating = comm.all_gather_var(Gl.rating)
-        G.time = comm.all_gather_var(Gl.time)
+        G.user, G.item, G.rating, G.time = comm.all_gather_multi([Gl.user.long() + int(user_lo), Gl.item, Gl.rating, Gl.time])
         G.n_rows = int(G.user.numel())
         prof = torch.tensor([eng.n_profiles(Gl)], dtype=torch.int64, device=dev)
         comm.all_reduce(prof)
@@ -419,22 +449,28 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
             except Exception as e:
                 err = e
             comm.agree(err, "stage B (list thresholds)")
-            for mode, name in ((0, "att"), (1, "src"), (2, "rnn")):
-                err, st8 = None, None
+            # attach and rnn lists together (one count phase, one agreement, one exchange each way), then the src lists, whose
+            # predicate reads the attach offsets
+            for group in (((0, "att"), (2, "rnn")), ((1, "src"),)):
+                err, sts = None, []
                 try:
-                    st8 = eng.reverse_count(S, E, mode, E.att[0] if mode == 1 else None, rows)
+                    for mode, _ in group:
+                        sts.append(eng.reverse_count(S, E, mode, E.att[0] if mode == 1 else None, rows))
                 except Exception as e:
                     err = e
                 comm.agree(err, "stage B (reverse lists: count)")
                 if rows is not None:
-                    eng.reverse_gather_counts(st8, comm)
+                    eng.reverse_gather_counts(sts, comm)
                 err = None
                 try:
-                    eng.reverse_fill(st8)
+                    for st8 in sts:
+                        eng.reverse_fill(st8)
                 except Exception as e:
                     err = e
                 comm.agree(err, "stage B (reverse lists: fill)")
-                setattr(E, name, eng.reverse_gather(st8, comm) if rows is not None else st8.out)
+                outs = eng.reverse_gather(sts, comm) if rows is not None else [st8.out for st8 in sts]
+                for (_, name), out in zip(group, outs):
+                    setattr(E, name, out)
         err = None
         try:
             E = eng.extend_tables(E, False, None, start_split=(rank, world))
