@@ -402,7 +402,7 @@ int xmap_mid_place(void *stream, int32_t n_items, int top_k, const uint8_t *cls,
  *   (caller: exclusive scans ng -> dir_ptr [n_nb+1], nrec -> rec_ptr [n_nb+1]; allocates dir, midX)
  *   xmap_mid_rows_place : the tile directory (in x order) and the records of every x'.
  * Output identical to xmap_mid_tally / xmap_mid_place up to the order of the records inside a tile. */
-#define XMAP_MID_ROWS_SPAN 36864   /* columns of a row whose counters fit the LDS of a block (4 B each; 160 KB per CU on gfx950, 12 KB of it the waves' walk state) */
+#define XMAP_MID_ROWS_SPAN 36864   /* columns of a row whose counters fit the LDS of a block (4 B each; 160 KB per CU on gfx950, 7 KB of it the walk's tables) */
 int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol,
                         const double *kval, const uint8_t *flags, const int64_t *att_ptr, const int32_t *att_idx,
                         const double *att_val, const int64_t *src_ptr, const int32_t *src_idx, const double *src_val,

@@ -833,6 +833,7 @@ struct MidArgs {
     const long long *att_ptr; const int *att_idx; const double *att_val;
     const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
     int n_nb; const int *nb_list; const int *nb_id;
+    const long long *jptr; const int *joff;     // joint (t, s) of every t, compacted: offsets into src(t) (k_joint_list; k_mid_rows)
     int *tile_cnt;                 // [n_nb * n_nb] tally, then placement cursor
     const long long *tile_off;     // [n_nb * n_nb + 1]
     MidX *midX;
@@ -892,9 +893,31 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// joint (t, s) of every source list, compacted in list order: joff[jptr[t] .. jptr[t+1]) = the offsets inside src(t) of the
+// entries with the joint flag (2.3 % of them at BASELINE configs[1]: the walk of k_mid_rows reads these instead of scanning the
+// lists of a row's neighbours once per row).  One wave per t; joff == NULL: the counts (jcnt) only.
+__global__ __launch_bounds__(256) void k_joint_list(int I, const long long *src_ptr, const uint8_t *src_flag, int *jcnt,
+                                                    const long long *jptr, int *joff) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= I) return;
+    const int lane = lane_id();
+    const long long s0 = src_ptr[t], s1 = src_ptr[t + 1];
+    long long out = joff ? jptr[t] : 0;
+    int total = 0;
+    for (long long base = s0; base < s1; base += 64) {
+        const long long p = base + lane;
+        const bool ok = p < s1 && (src_flag[p] & 1);
+        const unsigned long long m = __ballot(ok);
+        if (joff && ok) joff[out + __popcll(m & lanemask_lt())] = (int)(p - s0);
+        out += __popcll(m);
+        total += __popcll(m);
+    }
+    if (!joff && lane == 0) jcnt[t] = total;
+}
+
 constexpr int MIDROW_WAVES = 16;
 template <int PHASE, bool ONE_RANGE>
-__global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int span, int *ng, long long *nrec, const long long *dir_ptr,
+__global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mid_rows(MidArgs A, int span, int *ng, long long *nrec, const long long *dir_ptr,
                                                                 const long long *rec_ptr, MidDir *dir) {
     extern __shared__ int bins[];                      // [span]
     __shared__ unsigned long long s_wave[MIDROW_WAVES];
@@ -932,68 +955,94 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) void k_mid_rows(MidArgs A, int s
         }
     };
 #else
-    // The walk, round 4: a row of configs[1] has 10 000 records behind ~50 neighbours t and ~500 joint (t, s), and ONE block
-    // builds it -- what the block takes is the chain of dependent memory trips of its slowest wave.  The first form ran the
-    // neighbours as a serial loop (three dependent trips per t: list entry -> flag, source range -> joint flags) and gave a
-    // wave one joint per step (attach lists hold ~20 entries: a third of the lanes, four more trips per step): ~270 trips per
-    // wave and walk.  Now (a) the row's neighbours sit one per LANE: their three trips are taken once for all of them;
-    // (b) the 64-entry chunks of the source lists are dealt to the waves, and a chunk's joints are walked FLAT: lane l of
-    // round r0 takes record r0 + l of the chunk (inclusive scan of the attach-list lengths over the lanes, the record's joint
-    // found by a six-step search over the starts in LDS) -- every lane of every round but the last is busy and the rounds
-    // of a chunk are independent.  ~50 trips per wave and walk.
-    __shared__ int s_off[MIDROW_WAVES][64];
-    __shared__ long long s_a0[MIDROW_WAVES][64];
-    volatile int *w_off = s_off[w];
-    volatile long long *w_a0 = s_a0[w];
+    // The walk, round 4.  A row of configs[1] has 10 000 records on average (median 12, p90 33 000, maximum 93 000:
+    // profiles/r04m_mid_walk.txt) behind <= 50 neighbours t and their joint (t, s), and ONE block builds it: what the block
+    // takes is the chain of dependent memory trips of its slowest wave.  The first form ran the neighbours as a serial loop
+    // (three trips per t), scanned their source lists for the joint flag (2.3 % of the entries have it) and gave a wave one
+    // joint per step: ~300 trips per wave and walk in the big rows.  Now:
+    //  * the joint entries of every source list are compacted once per call (k_joint_list: jptr / joff), and the row's
+    //    neighbours are loaded one per LANE into a block-shared table with the prefix sums of their joint counts: the row's
+    //    joints are ONE flat list, taken 64 at a time by every wave alike (three trips: offset -> s -> attach range);
+    //  * the records of a chunk of 64 joints are a flat list too (scan of the attach-list lengths over the lanes; a record's
+    //    joint by a six-step search over the starts in LDS), dealt to the waves in rounds of 64 and walked MID_UNROLL rounds
+    //    at a time, so that the two trips of a round (attach entry -> its column) overlap with those of its neighbours.
+    // ~100 trips per wave and walk in the biggest row, and every lane of every round but a chunk's last is busy.
+    constexpr int MID_UNROLL = PHASE == 0 ? 4 : 2;      // (the placement keeps a record's values live: two rounds fit 64 VGPRs)
+    __shared__ long long q_s0[64], q_jlo[64];
+    __shared__ double q_v2[64], q_m2[64], q_f2[64];
+    __shared__ int q_joff[65];
+    __shared__ int s_off[MIDROW_WAVES][64];          // (what else a record needs of its joint comes from the joint's LANE by
+    volatile int *w_off = s_off[w];                  //  ds_bpermute: with 64.5 KB of counters at configs[1], two blocks per CU need the rest small)
     auto walk = [&](int x0, int x1, auto &&body) {
-        int ctr = 0;
         for (int qb = 0; qb < nq; qb += 64) {
-            const int ql = qb + lane;
-            long long s0l = 0, s1l = 0;
-            double v2l = 0.0, m2l = 0.0, f2l = 0.0;
-            bool tok = false;
-            if (ql < nq) {
-                const size_t o = ((size_t)xp * 2) * A.k + ql;
-                const int t = A.kcol[o];
-                tok = (A.flags[t] & 2) != 0;
-                s0l = A.src_ptr[t]; s1l = A.src_ptr[t + 1];
-                v2l = A.kval[o * 3]; m2l = A.kval[o * 3 + 1]; f2l = A.kval[o * 3 + 2];              // edge (x', t)
-            }
-            unsigned long long qm = __ballot(tok && s1l > s0l);
-            while (qm) {
-                const int l = __ffsll((long long)qm) - 1;
-                qm &= qm - 1;
-                const long long s0 = rl64(s0l, l), s1 = rl64(s1l, l);
-                const double v2 = __longlong_as_double(rl64(__double_as_longlong(v2l), l));
-                const double m2 = __longlong_as_double(rl64(__double_as_longlong(m2l), l));
-                const double f2 = __longlong_as_double(rl64(__double_as_longlong(f2l), l));
-                for (long long base = s0; base < s1; base += 64) {
-                    if ((ctr++ % MIDROW_WAVES) != w) continue;
-                    const long long pl = (base + lane < s1) ? base + lane : s0;
-                    const bool joint = (base + lane < s1) && (A.src_flag[pl] & 1);
-                    const int s = A.src_idx[pl];
-                    long long a0 = 0;
-                    int len = 0;
-                    if (joint) { a0 = A.att_ptr[s]; len = (int)(A.att_ptr[s + 1] - a0); }
-                    int incl = len;
+            __syncthreads();                            // (nobody reads the previous table any more)
+            if (w == 0) {
+                const int ql = qb + lane;
+                long long s0 = 0, jlo = 0;
+                int jn = 0;
+                double v2 = 0.0, m2 = 0.0, f2 = 0.0;
+                if (ql < nq) {
+                    const size_t o = ((size_t)xp * 2) * A.k + ql;
+                    const int t = A.kcol[o];
+                    if (A.flags[t] & 2) {
+                        s0 = A.src_ptr[t]; jlo = A.jptr[t]; jn = (int)(A.jptr[t + 1] - jlo);
+                        v2 = A.kval[o * 3]; m2 = A.kval[o * 3 + 1]; f2 = A.kval[o * 3 + 2];          // edge (x', t)
+                    }
+                }
+                int incl = jn;
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-                    const int T = rl32(incl, 63);
-                    if (T == 0) continue;
-                    __builtin_amdgcn_wave_barrier();
-                    w_off[lane] = incl - len;            // first record of the lane's joint (lanes without records: their successor's)
-                    w_a0[lane] = a0;
-                    __builtin_amdgcn_wave_barrier();
-                    for (int r0 = 0; r0 < T; r0 += 64) {
-                        const int r = r0 + lane;
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+                q_s0[lane] = s0; q_jlo[lane] = jlo; q_v2[lane] = v2; q_m2[lane] = m2; q_f2[lane] = f2;
+                q_joff[lane] = incl - jn;               // joints of the neighbours in front (a neighbour without joints: its successor's)
+                if (lane == 63) q_joff[64] = incl;
+            }
+            __syncthreads();
+            const int J = q_joff[64];
+            for (int g0 = 0; g0 < J; g0 += 64) {        // 64 joints of the row; every wave takes every chunk, the ROUNDS are dealt
+                const int g = g0 + lane;
+                int q = 0;                              // the last neighbour whose joints start at or before g
+#pragma unroll
+                for (int st = 32; st >= 1; st >>= 1) if (q_joff[q + st] <= g) q += st;
+                int jo = 0, len = 0;
+                long long a0 = 0;
+                if (g < J) {
+                    jo = A.joff[q_jlo[q] + (g - q_joff[q])];
+                    const int s = A.src_idx[q_s0[q] + jo];
+                    a0 = A.att_ptr[s];
+                    len = (int)(A.att_ptr[s + 1] - a0);
+                }
+                int incl = len;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+                const int T = rl32(incl, 63);
+                if (T == 0) continue;
+                __builtin_amdgcn_wave_barrier();
+                w_off[lane] = incl - len;                // first record of the lane's joint (lanes without records: their successor's)
+                __builtin_amdgcn_wave_barrier();
+                const int a0_lo = (int)(a0 & 0xffffffffll), a0_hi = (int)(a0 >> 32);
+                for (int r0 = 64 * w; r0 < T; r0 += 64 * MIDROW_WAVES * MID_UNROLL) {
+                    int jj[MID_UNROLL], ai[MID_UNROLL], xi[MID_UNROLL];
+                    long long ap[MID_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < MID_UNROLL; u++) {
+                        const int r = r0 + u * 64 * MIDROW_WAVES + lane;
                         int j = 0;                       // the last lane whose joint starts at or before record r
 #pragma unroll
                         for (int st = 32; st >= 1; st >>= 1) if (w_off[j + st] <= r) j += st;
-                        if (r < T) {
-                            const long long ap = w_a0[j] + (r - w_off[j]);
-                            const int xid = A.nb_id[A.att_idx[ap]];
-                            if (ONE_RANGE || (xid >= x0 && xid < x1)) body(xid, v2, m2, f2, base + j, ap);
-                        }
+                        jj[u] = r < T ? j : -1;
+                        const long long ja0 = ((long long)__shfl(a0_hi, j, 64) << 32) | (unsigned int)__shfl(a0_lo, j, 64);
+                        ap[u] = r < T ? ja0 + (r - w_off[j]) : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < MID_UNROLL; u++) ai[u] = jj[u] >= 0 ? A.att_idx[ap[u]] : 0;
+#pragma unroll
+                    for (int u = 0; u < MID_UNROLL; u++) xi[u] = jj[u] >= 0 ? A.nb_id[ai[u]] : -1;
+#pragma unroll
+                    for (int u = 0; u < MID_UNROLL; u++) {
+                        const int jl = jj[u] >= 0 ? jj[u] : 0;
+                        const int qq = __shfl(q, jl, 64), jjo = __shfl(jo, jl, 64);      // (all lanes take part in the exchange)
+                        if (jj[u] >= 0 && (ONE_RANGE || (xi[u] >= x0 && xi[u] < x1)))
+                            body(xi[u], q_v2[qq], q_m2[qq], q_f2[qq], q_s0[qq] + jjo, ap[u]);
                     }
                 }
             }
@@ -2738,8 +2787,30 @@ static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const in
 }
 
 // row-wise construction (k_mid_rows); the tile counters of a column range of the row live in LDS
-static_assert((size_t)XMAP_MID_ROWS_SPAN * 4 + (size_t)MIDROW_WAVES * 64 * 12 + 256 <= 160 * 1024,
-              "k_mid_rows: tile counters + the waves' walk state must fit the LDS of a gfx950 CU");
+static_assert((size_t)XMAP_MID_ROWS_SPAN * 4 + (size_t)MIDROW_WAVES * 64 * 4 + 3072 + 256 <= 160 * 1024,
+              "k_mid_rows: tile counters + the neighbour table + the waves' walk state must fit the LDS of a gfx950 CU");
+// the compacted joint lists of one call (temporaries of the caller's scope)
+static int mid_joints(hipStream_t st, MidArgs &A) {
+    int *jcnt = nullptr, *joff = nullptr;
+    long long *jptr = nullptr;
+    const int I = A.I;
+    XM_HIP(xm_malloc_async((void **)&jcnt, sizeof(int) * (size_t)(I > 0 ? I : 1), st));
+    XM_HIP(xm_malloc_async((void **)&jptr, sizeof(long long) * (size_t)(I + 1), st));
+    int64_t nj = 0;
+    if (I > 0) {
+        k_joint_list<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(I, A.src_ptr, A.src_flag, jcnt, nullptr, nullptr);
+        XM_LAUNCH_CHECK();
+    }
+    int rc = xmap_exclusive_scan_i32_to_i64(st, jcnt, (int64_t *)jptr, I, &nj);      // (one synchronisation: the size of joff)
+    if (rc) return rc;
+    XM_HIP(xm_malloc_async((void **)&joff, sizeof(int) * (size_t)(nj > 0 ? nj : 1), st));
+    if (I > 0) {
+        k_joint_list<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(I, A.src_ptr, A.src_flag, nullptr, jptr, joff);
+        XM_LAUNCH_CHECK();
+    }
+    A.jptr = jptr; A.joff = joff;
+    return XMAP_OK;
+}
 static int mid_rows_lds(int32_t n_nb, size_t *bytes, int *span) {
     int cap = XMAP_MID_ROWS_SPAN;
     if (const char *e = getenv("XMAP_MID_ROWS_SPAN")) {      // tests: several column ranges on small inputs
@@ -2764,6 +2835,10 @@ int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t 
     if (rc) return rc;
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
                          src_flag, n_nb, nb_list, nb_id);
+    XM_ARG(src_flag);
+    XM_SCOPE(stream);
+    rc = mid_joints((hipStream_t)stream, A);
+    if (rc) return rc;
     if (span >= n_nb) {
         XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_mid_rows<0, true><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(A, span, ng, (long long *)nrec,
@@ -2792,6 +2867,10 @@ int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t 
     MidArgs A = mid_args(n_items, top_k, cls, kcnt, kcol, kval, flags, att_ptr, att_idx, att_val, src_ptr, src_idx, src_val,
                          src_flag, n_nb, nb_list, nb_id);
     A.midX = (MidX *)midX;
+    XM_ARG(src_flag);
+    XM_SCOPE(stream);
+    rc = mid_joints((hipStream_t)stream, A);
+    if (rc) return rc;
     if (span >= n_nb) {
         XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_mid_rows<1, true><<<dim3((unsigned)n_nb), dim3(64 * MIDROW_WAVES), lds, (hipStream_t)stream>>>(
