@@ -328,6 +328,8 @@ int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, con
                        const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
                        const void *thr /*xmap_knn_thresholds or NULL*/,
                        int32_t *long_rows /*[I+1] scratch or NULL: written here, rows of > 4096 entries get 16 waves*/,
+                       uint8_t *eflag /*one byte per entry of the rows [row_lo, row_hi) or NULL: written here (bit 0 = listed,
+                       bit 1 = joint); xmap_reverse_fill given the same buffer reads it instead of testing every entry again*/,
                        int32_t *rcnt /*[I]*/, int32_t row_lo, int32_t row_hi /*the rows (= targets of the lists) of this
                        call: the list of a row is built from that row alone, so a rank's share of the rows gives a
                        contiguous share of the lists; [0, I) = all*/);
@@ -335,7 +337,8 @@ int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, cons
                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,
                       const void *thr /*xmap_knn_thresholds or NULL*/,
-                      int32_t *long_rows /*as left by xmap_reverse_count, or NULL*/, const int64_t *rptr /*[I+1]*/,
+                      int32_t *long_rows /*as left by xmap_reverse_count, or NULL*/,
+                      uint8_t *eflag /*as left by xmap_reverse_count of the same mode and rows, or NULL*/, const int64_t *rptr /*[I+1]*/,
                       int32_t *ridx, double *rval /*[n][3]*/, uint8_t *rflag, int32_t row_lo, int32_t row_hi);
 
 /* Scheduling weights of the path enumeration: paths[start] = number of paths that start at `start`

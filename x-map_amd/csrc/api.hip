@@ -92,6 +92,7 @@ static int d2h(T *host, const T *dev, size_t n, hipStream_t st) {
 
 // one reverse adjacency: count -> scan -> fill
 static int reverse_list(xmap_ctx *c, int mode, const uint8_t *bb, const int64_t *attach_ptr, const void *thr, int32_t *long_rows,
+                        uint8_t *eflag,
                         const int64_t **rptr, const int32_t **ridx, const double **rval, const uint8_t **rflag) {
     const int I = c->R.n_items, k = c->top_k;
     int32_t *rcnt;
@@ -99,7 +100,7 @@ static int reverse_list(xmap_ctx *c, int mode, const uint8_t *bb, const int64_t 
     XM_ALLOCZ(c->p_ext, rcnt, I);
     XM_ALLOCZ(c->p_ext, ptr, I + 1);
     XM_TRY(xmap_reverse_count(c->st, &c->S, mode, k, bb, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->R.suffix_cls,
-                              c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, rcnt, 0, I));
+                              c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, eflag, rcnt, 0, I));
     int64_t n = 0;
     XM_TRY(xmap_exclusive_scan_i32_to_i64(c->st, rcnt, ptr, I, &n));
     int32_t *idx;
@@ -109,7 +110,7 @@ static int reverse_list(xmap_ctx *c, int mode, const uint8_t *bb, const int64_t 
     XM_ALLOC(c->p_ext, val, 3 * (size_t)(n ? n : 1));
     XM_ALLOCZ(c->p_ext, flag, n);
     XM_TRY(xmap_reverse_fill(c->st, &c->S, mode, k, bb, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->R.suffix_cls,
-                             c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, ptr, idx, val, flag, 0, I));
+                             c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, eflag, ptr, idx, val, flag, 0, I));
     *rptr = ptr; *ridx = idx; *rval = val; *rflag = flag;
     return XMAP_OK;
 }
@@ -383,11 +384,13 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
     int32_t *long_rows;
     XM_ALLOC(c->p_ext, thr, (size_t)I * 4);
     XM_ALLOC(c->p_ext, long_rows, I + 1);
+    uint8_t *eflag;                         // one byte per entry of the matrix: what a count pass found, for its fill pass
+    XM_ALLOC(c->p_ext, eflag, (size_t)(c->n_kept > 0 ? c->n_kept : 1));
     XM_TRY(xmap_knn_thresholds(c->st, I, k, kcnt, kcol, kval, thr));
     const uint8_t *dummy;
-    XM_TRY(reverse_list(c, 0, bb, nullptr, thr, long_rows, &T.att_ptr, &T.att_idx, &T.att_val, &dummy));
-    XM_TRY(reverse_list(c, 1, bb, T.att_ptr, thr, long_rows, &T.src_ptr, &T.src_idx, &T.src_val, &T.src_flag));
-    XM_TRY(reverse_list(c, 2, bb, nullptr, thr, long_rows, &T.rnn_ptr, &T.rnn_idx, &T.rnn_val, &dummy));
+    XM_TRY(reverse_list(c, 0, bb, nullptr, thr, long_rows, eflag, &T.att_ptr, &T.att_idx, &T.att_val, &dummy));
+    XM_TRY(reverse_list(c, 1, bb, T.att_ptr, thr, long_rows, eflag, &T.src_ptr, &T.src_idx, &T.src_val, &T.src_flag));
+    XM_TRY(reverse_list(c, 2, bb, nullptr, thr, long_rows, eflag, &T.rnn_ptr, &T.rnn_idx, &T.rnn_val, &dummy));
     // exact per-start path counts -> work units
     int64_t *wtmp, *P;
     XM_ALLOCZ(c->p_ext, wtmp, (size_t)4 * I); XM_ALLOCZ(c->p_ext, P, I);

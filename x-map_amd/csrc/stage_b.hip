@@ -340,6 +340,8 @@ struct RevArgs {
     int row_lo, row_hi;          // the rows (= targets of the reverse lists) of this call: a rank's share, or [0, I)
     const KnnThr *thr;
     const int *long_rows;        // [0] = count, then the rows with more than rev_long entries (or NULL)
+    uint8_t *eflag;              // per entry of the rows [row_lo, row_hi) (index p - row_ptr[row_lo]), or NULL: the count pass leaves
+                                 // bit 0 = "b lists a", bit 1 = joint here and the fill pass reads it instead of testing again
     int rev_long;
     const long long *row_ptr;
     const int *col;
@@ -420,6 +422,29 @@ __device__ __forceinline__ void rev_write(const RevArgs &A, int a, long long p, 
     if (A.rflag) A.rflag[o] = fl;
 }
 
+// The test of one entry, once: the count pass evaluates it (a 1-byte class gather per entry, a 16-byte threshold gather for
+// those that pass: the passes run at the CU's rate of random gathers, not at the matrix's bandwidth) and, given A.eflag, leaves
+// the outcome as a byte per entry; the fill pass then streams the bytes and touches only the entries it writes.
+template <bool FILL>
+__device__ __forceinline__ bool rev_test(const RevArgs &A, int a, long long p, long long hi, long long p0, int &b, double &sv,
+                                         uint8_t &fl) {
+    if (!A.eflag) return rev_entry(A, a, p, hi, b, sv, fl);
+    if (!FILL) {
+        const bool ok = rev_entry(A, a, p, hi, b, sv, fl);
+        if (p < hi) A.eflag[p - p0] = (uint8_t)((ok ? 1 : 0) | (fl << 1));
+        return ok;
+    }
+    b = 0; sv = 0.0; fl = 0;
+    bool ok = false;
+    if (p < hi) {
+        const uint8_t e = A.eflag[p - p0];
+        ok = (e & 1) != 0;
+        fl = (uint8_t)(e >> 1);
+        if (ok) { b = A.col[p]; sv = A.sim[p]; }
+    }
+    return ok;
+}
+
 // Rows up to REV_LONG entries: one wave per row.  The rows of the popular items have 10^5 entries and more; walked by
 // one wave each they were the whole duration of the pass (5 ms per pass for 0.2 ms of streaming): those rows are listed
 // (k_rev_long_rows) and walked by blocks of 16 waves, 1024 entries per step, in the same (row) order.
@@ -436,11 +461,12 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     if (A.mode == 1) row_ok = (A.flags[a] & 2) != 0;  // "T:" in t
     long long out = FILL ? A.rptr[a] : 0;
     int total = 0;
+    const long long p0 = A.eflag ? A.row_ptr[A.row_lo] : 0;
     if (row_ok)
         for (long long base = lo; base < hi; base += 64) {
             long long p = base + lane;
             int b; double sv; uint8_t fl;
-            const bool ok = rev_entry(A, a, p, hi, b, sv, fl);
+            const bool ok = rev_test<FILL>(A, a, p, hi, p0, b, sv, fl);
             unsigned long long m = __ballot(ok);
             if (FILL && ok) rev_write(A, a, p, out + __popcll(m & lanemask_lt()), b, sv, fl);
             int c = __popcll(m);
@@ -461,6 +487,7 @@ __global__ __launch_bounds__(64 * REV_WAVES) void k_reverse_long(RevArgs A) {
     __shared__ int s_cnt[REV_WAVES];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int n_long = A.long_rows[0];
+    const long long p0 = A.eflag ? A.row_ptr[A.row_lo] : 0;
     for (int r = blockIdx.x; r < n_long; r += gridDim.x) {
         const int a = A.long_rows[1 + r];
         const long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
@@ -471,7 +498,7 @@ __global__ __launch_bounds__(64 * REV_WAVES) void k_reverse_long(RevArgs A) {
             for (long long base = lo; base < hi; base += 64 * REV_WAVES) {
                 const long long p = base + threadIdx.x;
                 int b; double sv; uint8_t fl;
-                const bool ok = rev_entry(A, a, p, hi, b, sv, fl);
+                const bool ok = rev_test<FILL>(A, a, p, hi, p0, b, sv, fl);
                 const unsigned long long m = __ballot(ok);
                 if (lane == 0) s_cnt[w] = __popcll(m);
                 __syncthreads();
@@ -834,6 +861,7 @@ struct MidArgs {
     const long long *src_ptr; const int *src_idx; const double *src_val; const uint8_t *src_flag;
     int n_nb; const int *nb_list; const int *nb_id;
     const long long *jptr; const int *joff;     // joint (t, s) of every t, compacted: offsets into src(t) (k_joint_list; k_mid_rows)
+    const int *axid;                            // column of every attach entry (k_att_columns)
     int *tile_cnt;                 // [n_nb * n_nb] tally, then placement cursor
     const long long *tile_off;     // [n_nb * n_nb + 1]
     MidX *midX;
@@ -913,6 +941,15 @@ __global__ __launch_bounds__(256) void k_joint_list(int I, const long long *src_
         total += __popcll(m);
     }
     if (!joff && lane == 0) jcnt[t] = total;
+}
+
+// the column (index among the non-bridge items) of every attach entry: nb_id[att_idx[ap]] gathered ONCE per call -- the walks of
+// k_mid_rows read it 1.6e8 times per walk, and a gather of 64 random lines costs the CU ~320 cycles per instruction
+// (profiles/ta_rate.hip): 1.3 ms per walk, three walks per call
+__global__ __launch_bounds__(256) void k_att_columns(long long bound, int I, const long long *att_ptr, const int *att_idx, const int *nb_id,
+                                                     int *axid) {
+    const long long ap = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (ap < bound && ap < att_ptr[I]) axid[ap] = nb_id[att_idx[ap]];
 }
 
 constexpr int MIDROW_WAVES = 16;
@@ -1021,7 +1058,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                 __builtin_amdgcn_wave_barrier();
                 const int a0_lo = (int)(a0 & 0xffffffffll), a0_hi = (int)(a0 >> 32);
                 for (int r0 = 64 * w; r0 < T; r0 += 64 * MIDROW_WAVES * MID_UNROLL) {
-                    int jj[MID_UNROLL], ai[MID_UNROLL], xi[MID_UNROLL];
+                    int jj[MID_UNROLL], xi[MID_UNROLL];
                     long long ap[MID_UNROLL];
 #pragma unroll
                     for (int u = 0; u < MID_UNROLL; u++) {
@@ -1034,9 +1071,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                         ap[u] = r < T ? ja0 + (r - w_off[j]) : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < MID_UNROLL; u++) ai[u] = jj[u] >= 0 ? A.att_idx[ap[u]] : 0;
-#pragma unroll
-                    for (int u = 0; u < MID_UNROLL; u++) xi[u] = jj[u] >= 0 ? A.nb_id[ai[u]] : -1;
+                    for (int u = 0; u < MID_UNROLL; u++) xi[u] = jj[u] >= 0 ? A.axid[ap[u]] : -1;
 #pragma unroll
                     for (int u = 0; u < MID_UNROLL; u++) {
                         const int jl = jj[u] >= 0 ? jj[u] : 0;
@@ -2579,15 +2614,15 @@ int xmap_knn_classify(void *stream, const xmap_sim *S, int top_k, const uint8_t 
 static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, int top_k, const uint8_t *bb,
                           const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
                           const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
-                          const int64_t *attach_ptr, const void *thr, int32_t *long_rows, int32_t *rcnt, const int64_t *rptr,
-                          int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo, int32_t row_hi) {
+                          const int64_t *attach_ptr, const void *thr, int32_t *long_rows, uint8_t *eflag, int32_t *rcnt,
+                          const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo, int32_t row_hi) {
     XM_ARG(S && bb && cls && kcnt && kcol && kval && suffix_cls && contains_mask && flags);
     XM_ARG(mode >= 0 && mode <= 2);
     XM_ARG(mode != 1 || attach_ptr);
     XM_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= S->n_items);
     if (row_hi == row_lo) return XMAP_OK;
     RevArgs A;
-    A.I = S->n_items; A.k = top_k; A.mode = mode; A.thr = (const KnnThr *)thr; A.long_rows = long_rows;
+    A.I = S->n_items; A.k = top_k; A.mode = mode; A.thr = (const KnnThr *)thr; A.long_rows = long_rows; A.eflag = eflag;
     A.row_lo = row_lo; A.row_hi = row_hi;
     const char *rl = getenv("XMAP_REV_LONG");
     A.rev_long = (rl && atoi(rl) > 0) ? atoi(rl) : REV_LONG;
@@ -2629,20 +2664,20 @@ int xmap_knn_thresholds(void *stream, int32_t n_items, int top_k, const int32_t 
 int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                        const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                        const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, const void *thr,
-                       int32_t *long_rows, int32_t *rcnt, int32_t row_lo, int32_t row_hi) {
+                       int32_t *long_rows, uint8_t *eflag, int32_t *rcnt, int32_t row_lo, int32_t row_hi) {
     XM_ARG(rcnt);
     return reverse_common(stream, false, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
-                          attach_ptr, thr, long_rows, rcnt, nullptr, nullptr, nullptr, nullptr, row_lo, row_hi);
+                          attach_ptr, thr, long_rows, eflag, rcnt, nullptr, nullptr, nullptr, nullptr, row_lo, row_hi);
 }
 
 int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr, const void *thr,
-                      int32_t *long_rows, const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo,
-                      int32_t row_hi) {
+                      int32_t *long_rows, uint8_t *eflag, const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag,
+                      int32_t row_lo, int32_t row_hi) {
     XM_ARG(rptr && ridx && rval);
     return reverse_common(stream, true, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
-                          attach_ptr, thr, long_rows, nullptr, rptr, ridx, rval, rflag, row_lo, row_hi);
+                          attach_ptr, thr, long_rows, eflag, nullptr, rptr, ridx, rval, rflag, row_lo, row_hi);
 }
 
 int xmap_topc_from_lists(void *stream, int32_t n_items, const int64_t *xs_ptr, const int32_t *xs_end, const double *xs_val,
@@ -2809,6 +2844,16 @@ static int mid_joints(hipStream_t st, MidArgs &A) {
         XM_LAUNCH_CHECK();
     }
     A.jptr = jptr; A.joff = joff;
+    {   // (attach lists belong to the non-bridge items' first lists: at most k entries each)
+        const long long bound = (long long)A.n_nb * A.k;
+        int *axid = nullptr;
+        XM_HIP(xm_malloc_async((void **)&axid, sizeof(int) * (size_t)(bound > 0 ? bound : 1), st));
+        if (bound > 0) {
+            k_att_columns<<<dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st>>>(bound, I, A.att_ptr, A.att_idx, A.nb_id, axid);
+            XM_LAUNCH_CHECK();
+        }
+        A.axid = axid;
+    }
     return XMAP_OK;
 }
 static int mid_rows_lds(int32_t n_nb, size_t *bytes, int *span) {

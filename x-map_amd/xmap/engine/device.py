@@ -811,9 +811,11 @@ class Engine(object):
         st8.S, st8.E, st8.mode = S, E, mode
         st8.rows = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
         st8.rcnt = self._zeros(max(I, 1), torch.int32)
+        # one byte per entry of these rows: what the count pass finds, for the fill pass (which then gathers nothing)
+        st8.eflag = self._empty(max(int(S.col.numel()), 1), torch.uint8)       # (indexed from the first entry of row lo)
         st8.args = (C.byref(S.c), mode, E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval),
                     vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(attach_ptr), vp(getattr(E, "thr", None)),
-                    vp(getattr(E, "long_rows", None)))
+                    vp(getattr(E, "long_rows", None)), vp(st8.eflag))
         st8.keep = attach_ptr
         check(lib.xmap_reverse_count(_stream(self.dev), *st8.args, vp(st8.rcnt), i32(st8.rows[0]), i32(st8.rows[1])))
         return st8
