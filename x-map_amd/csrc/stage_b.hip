@@ -340,6 +340,7 @@ struct RevArgs {
     int row_lo, row_hi;          // the rows (= targets of the reverse lists) of this call: a rank's share, or [0, I)
     const KnnThr *thr;
     const int *long_rows;        // [0] = count, then the rows with more than rev_long entries (or NULL)
+    const uint8_t *meta;         // mode 1: per item b, bit 0 = bridge record, bit 1 = "S:" item, bit 2 = has an attach list (k_rev_meta), or NULL
     uint8_t *eflag;              // per entry of the rows [row_lo, row_hi) (index p - row_ptr[row_lo]), or NULL: the count pass leaves
                                  // bit 0 = "b lists a", bit 1 = joint here and the fill pass reads it instead of testing again
     int rev_long;
@@ -395,13 +396,16 @@ __device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, 
         b = A.col[p];
         sv = A.sim[p];
         double ab = fabs(sv);
-        int cb = A.cls[b];     // (a 1-byte gather from a 400 KB table; the 16-byte threshold record only for the entries that pass it --
+        int cb = (A.mode == 1 && A.meta) ? 0 : A.cls[b];     // (a 1-byte gather from a 400 KB table; the 16-byte threshold record only for the entries that pass it --
                                //  packing the class into that record made EVERY entry gather it: 6.7 -> 8.3 ms, round 4)
         if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
             ok = (cb == 2) && in_list(A, b, 0, a, ab);
         } else if (A.mode == 1) {    // src(t = a): s = b
-            ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
-                 (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
+            // (the three per-item tests as ONE byte gather where the pass built it: nearly every entry reaches the second and
+            //  half of them the third, and a gather is what these passes are made of)
+            if (A.meta) ok = (A.meta[b] == 7) && (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
+            else ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
+                      (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
             if (ok) {
                 bool joint = (A.cls[a] == 1) && (A.attach_ptr[a + 1] > A.attach_ptr[a]) &&
                              (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
@@ -412,6 +416,11 @@ __device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, 
         }
     }
     return ok;
+}
+__global__ __launch_bounds__(256) void k_rev_meta(int I, const uint8_t *cls, const uint8_t *flags, const long long *attach_ptr,
+                                                  uint8_t *meta) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < I) meta[b] = (uint8_t)((cls[b] == 1 ? 1 : 0) | ((flags[b] & 1) ? 2 : 0) | (attach_ptr[b + 1] > attach_ptr[b] ? 4 : 0));
 }
 __device__ __forceinline__ void rev_write(const RevArgs &A, int a, long long p, long long o, int b, double sv, uint8_t fl) {
     double mu = (double)A.mutu[p];
@@ -923,24 +932,35 @@ __device__ __forceinline__ double quad_bcast(double v) {
 
 // joint (t, s) of every source list, compacted in list order: joff[jptr[t] .. jptr[t+1]) = the offsets inside src(t) of the
 // entries with the joint flag (2.3 % of them at BASELINE configs[1]: the walk of k_mid_rows reads these instead of scanning the
-// lists of a row's neighbours once per row).  One wave per t; joff == NULL: the counts (jcnt) only.
+// lists of a row's neighbours once per row).  joff == NULL: the counts (jcnt) only.
 __global__ __launch_bounds__(256) void k_joint_list(int I, const long long *src_ptr, const uint8_t *src_flag, int *jcnt,
                                                     const long long *jptr, int *joff) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= I) return;
+    // a wave takes 64 items: their ranges one per lane (most items have no source list), then the non-empty lists one by one
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (t0 >= I) return;
     const int lane = lane_id();
-    const long long s0 = src_ptr[t], s1 = src_ptr[t + 1];
-    long long out = joff ? jptr[t] : 0;
-    int total = 0;
-    for (long long base = s0; base < s1; base += 64) {
-        const long long p = base + lane;
-        const bool ok = p < s1 && (src_flag[p] & 1);
-        const unsigned long long m = __ballot(ok);
-        if (joff && ok) joff[out + __popcll(m & lanemask_lt())] = (int)(p - s0);
-        out += __popcll(m);
-        total += __popcll(m);
+    const int tl = t0 + lane;
+    long long s0l = 0, s1l = 0, outl = 0;
+    if (tl < I) { s0l = src_ptr[tl]; s1l = src_ptr[tl + 1]; if (joff) outl = jptr[tl]; }
+    int totl = 0;
+    unsigned long long todo = __ballot(s1l > s0l);
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long long s0 = rl64(s0l, l), s1 = rl64(s1l, l);
+        long long out = rl64(outl, l);
+        int total = 0;
+        for (long long base = s0; base < s1; base += 64) {
+            const long long p = base + lane;
+            const bool ok = p < s1 && (src_flag[p] & 1);
+            const unsigned long long m = __ballot(ok);
+            if (joff && ok) joff[out + __popcll(m & lanemask_lt())] = (int)(p - s0);
+            out += __popcll(m);
+            total += __popcll(m);
+        }
+        if (lane == l) totl = total;
     }
-    if (!joff && lane == 0) jcnt[t] = total;
+    if (!joff && tl < I) jcnt[tl] = totl;
 }
 
 // the column (index among the non-bridge items) of every attach entry: nb_id[att_idx[ap]] gathered ONCE per call -- the walks of
@@ -1541,6 +1561,9 @@ constexpr int END_HOME = 1 << 30;
 __device__ unsigned long long g_qhist[128];
 #endif
 
+// ONE (-DQ_ONE, the review's lever 2b): the batch is a start's only head (58.5 % of the column visits, profiles/r04h_paths_columns.txt)
+// -- no merge step (the head's next column IS the column), no lane assignment loop (its records are one run), the head's first
+// edge a per-lane constant instead of an LDS read per group
 template <bool FASTDIV>
 __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, long long h0, long long nH, int self, int xlo, int xhi,
                                         bool fresh) {
@@ -1589,6 +1612,11 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
 #else
     const int nloc = (nH - h0) < 64 ? (int)(nH - h0) : 64;      // heads of this batch (lanes 0 .. nloc-1)
 #endif
+#ifdef Q_ONE
+    const bool ONE = nloc == 1;         // (a wave-uniform branch in the same loop body: a second instantiation of the loop cost 30 %)
+#else
+    constexpr bool ONE = false;
+#endif
     if (lane == 0) { L.bsm[Q_CAP] = 0.0; L.bc[Q_CAP] = 0.0; L.bmu[Q_CAP] = 1.0; }       // the neutral record of the record loop
 #ifdef Q_RPIECE
     // Merged records as 16-byte PIECES (record r = the four lanes 4r .. 4r+3 = {sm2, sm3}, {sm4, f2}, {f3, f4}, {mu, -}): one
@@ -1598,14 +1626,19 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
     const uint4 *recp = reinterpret_cast<const uint4 *>(B.midX);
     const int pq = lane & 3, prec = lane >> 2;
     const int pfield = pq == 0 ? 0 : (pq == 2 ? 1 : 2);
+    // (ONE: the only head's first edge, the field this lane of a quad needs)
+    const double H1s = __longlong_as_double(rl64(__double_as_longlong(sm1), 0)), H1f = __longlong_as_double(rl64(__double_as_longlong(f1), 0));
+    const double H1m = __longlong_as_double(rl64(__double_as_longlong(mu1), 0));
+    const double H1 = pq == 0 ? H1s : (pq == 2 ? H1f : H1m);
 #endif
     for (;;) {
         // smallest column among the heads: xor butterfly inside each half of the wave (ds_swizzle: no address registers),
         // then the two halves
-        int xmin = cur.x;
+        int xmin = ONE ? rl32(cur.x, 0) : cur.x;
 #define XM_DPP_MIN(CTRL) { const int o = __builtin_amdgcn_update_dpp(INF, xmin, CTRL, 0xf, 0xf, false); xmin = o < xmin ? o : xmin; }
 #define XM_SWZ_MIN(PAT) { const int o = __builtin_amdgcn_ds_swizzle(xmin, PAT); xmin = o < xmin ? o : xmin; }
-        if (nloc <= 16) {      // the common batch of a few heads: DPP inside the first row of lanes, no LDS round trips
+        if (ONE) {
+        } else if (nloc <= 16) {      // the common batch of a few heads: DPP inside the first row of lanes, no LDS round trips
             XM_DPP_MIN(0xB1) XM_DPP_MIN(0x4E)                               // quad_perm [1,0,3,2], [2,3,0,1]
             if (nloc > 4) { XM_DPP_MIN(0x141) XM_DPP_MIN(0x140) }           // row_half_mirror, row_mirror
             xmin = rl32(xmin, 0);
@@ -1617,9 +1650,9 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
 #undef XM_SWZ_MIN
 #undef XM_DPP_MIN
         if (xmin == INF) break;
-        const bool mine = cur.x == xmin;
-        const unsigned long long part = __ballot(mine);
-        const int first_l = __ffsll((long long)part) - 1;
+        const bool mine = ONE ? lane == 0 : cur.x == xmin;
+        const unsigned long long part = ONE ? 1ull : __ballot(mine);
+        const int first_l = ONE ? 0 : __ffsll((long long)part) - 1;
         const int ne = rl32(cur.ne, first_l);
         const ColEnd *ce = B.cend + (size_t)rl32(cur.pad, first_l) * (k + 1);
 #ifdef Q_SHN
@@ -1660,6 +1693,17 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
 #ifdef Q_RPIECE
             // a group = up to 16 records, four lanes each, of whichever participating heads they fall to
             auto assign = [&]() {
+                if (ONE) {      // the head's records are one run: the next (up to) 16 of them
+                    const int cnt = rl32(cur.cnt, 0);
+                    const long long off = rl64(cur.off, 0);
+                    int n = cnt - pos;
+                    if (n > 16) n = 16;
+                    my_h = 0; set_n = n;
+                    my_rec = (off + pos) * 4 + (lane < 4 * n ? lane : 0);
+                    pos += n;
+                    if (pos == cnt) { pm = 0; pos = 0; }
+                    return;
+                }
                 set_n = 0; my_h = 0;
                 my_rec = rl64(cur.off, __ffsll((long long)pm) - 1) * 4;     // lanes beyond the group: any piece
                 for (;;) {
@@ -1678,7 +1722,7 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
             };
             // prepared form of a group's records, computed inside the quad (same operations in the same order)
             auto prepare = [&](const uint4 &v, int fill) {
-                const double H = L.hd[pfield][my_h];
+                const double H = ONE ? H1 : L.hd[pfield][my_h];
                 const double X = __longlong_as_double(((long long)v.y << 32) | v.x), Y = __longlong_as_double(((long long)v.w << 32) | v.z);
                 const double X1 = quad_bcast<1>(X), Y1 = quad_bcast<1>(Y);      // sm4, f2 of the record
                 const double v_sm = ((H + X) + Y) + X1;                           // lane 0: ((sm1 + sm2) + sm3) + sm4
@@ -2634,6 +2678,15 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     const int n_rows = row_hi - row_lo;
     dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    XM_SCOPE(stream);
+    A.meta = nullptr;
+    if (mode == 1 && !(fill && eflag)) {      // (a fill pass that reads eflag tests nothing)
+        uint8_t *meta = nullptr;
+        XM_HIP(xm_malloc_async((void **)&meta, (size_t)A.I, st));
+        k_rev_meta<<<dim3((unsigned)((A.I + 255) / 256)), dim3(256), 0, st>>>(A.I, cls, flags, (const long long *)attach_ptr, meta);
+        XM_LAUNCH_CHECK();
+        A.meta = meta;
+    }
     if (long_rows && !fill) {     // the count pass lists the long rows, the fill pass that follows reuses the list
         XM_HIP(hipMemsetAsync(long_rows, 0, sizeof(int32_t), st));
         k_rev_long_rows<<<dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st>>>(row_lo, row_hi, (const long long *)S->row_ptr,
@@ -2833,14 +2886,14 @@ static int mid_joints(hipStream_t st, MidArgs &A) {
     XM_HIP(xm_malloc_async((void **)&jptr, sizeof(long long) * (size_t)(I + 1), st));
     int64_t nj = 0;
     if (I > 0) {
-        k_joint_list<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(I, A.src_ptr, A.src_flag, jcnt, nullptr, nullptr);
+        k_joint_list<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, A.src_ptr, A.src_flag, jcnt, nullptr, nullptr);
         XM_LAUNCH_CHECK();
     }
     int rc = xmap_exclusive_scan_i32_to_i64(st, jcnt, (int64_t *)jptr, I, &nj);      // (one synchronisation: the size of joff)
     if (rc) return rc;
     XM_HIP(xm_malloc_async((void **)&joff, sizeof(int) * (size_t)(nj > 0 ? nj : 1), st));
     if (I > 0) {
-        k_joint_list<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(I, A.src_ptr, A.src_flag, nullptr, jptr, joff);
+        k_joint_list<<<dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st>>>(I, A.src_ptr, A.src_flag, nullptr, jptr, joff);
         XM_LAUNCH_CHECK();
     }
     A.jptr = jptr; A.joff = joff;
