@@ -90,6 +90,37 @@ def _worker(rank, world, port, q, backend="gloo"):
     dist.destroy_process_group()
 
 
+def _rccl_item_worker(port, q):
+    os.environ["XMAP_FORCE_DIST"] = "1"          # the sharded path with one rank
+    dist, dev = _init(0, 1, port, "nccl")
+    from xmap.engine import sharded
+    res = sharded.run_step(_engine(dev), "adjust_cosine", 50, 5, True, dist, 0, 1)
+    q.put((0, _summary(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_item_sharded_collectives_through_rccl():
+    """the item-sharded step with ONE share and RCCL as the backend (XMAP_FORCE_DIST=1): the exchange of the kept pairs to their
+    row owners (all_to_all_single), the packed all-gathers of the item statistics, knn tables, reverse lists and AlterEgo rows,
+    the agreements and all-reduces all run on device buffers; the result is the plain step's"""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    from xmap.engine import sharded
+    ref = _summary(sharded.run_step(_engine(), "adjust_cosine", 50, 5, True))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_item_worker, args=(_free_port(), q))
+    p.start()
+    (rank, out), = _collect(q, [p], 1)
+    p.join(120)
+    assert p.exitcode == 0
+    assert ref["n_kept"] > 0 and ref["n_paths"] > 0 and ref["n_rows"] > 0
+    for key, v in ref.items():
+        assert np.array_equal(out[key], v), key
+
+
 def test_item_sharded_over_rccl_equals_world1():
     """run_step on the nccl backend, one rank per visible GPU (BASELINE configs[2]); bit-equal to one rank"""
     _check_world_equals_world1(_rccl_world(), "nccl")

@@ -340,7 +340,6 @@ struct RevArgs {
     int row_lo, row_hi;          // the rows (= targets of the reverse lists) of this call: a rank's share, or [0, I)
     const KnnThr *thr;
     const int *long_rows;        // [0] = count, then the rows with more than rev_long entries (or NULL)
-    const uint8_t *meta;         // mode 1: per item b, bit 0 = bridge record, bit 1 = "S:" item, bit 2 = has an attach list (k_rev_meta), or NULL
     uint8_t *eflag;              // per entry of the rows [row_lo, row_hi) (index p - row_ptr[row_lo]), or NULL: the count pass leaves
                                  // bit 0 = "b lists a", bit 1 = joint here and the fill pass reads it instead of testing again
     int rev_long;
@@ -396,16 +395,14 @@ __device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, 
         b = A.col[p];
         sv = A.sim[p];
         double ab = fabs(sv);
-        int cb = (A.mode == 1 && A.meta) ? 0 : A.cls[b];     // (a 1-byte gather from a 400 KB table; the 16-byte threshold record only for the entries that pass it --
+        int cb = A.cls[b];     // (a 1-byte gather from a 400 KB table; the 16-byte threshold record only for the entries that pass it --
                                //  packing the class into that record made EVERY entry gather it: 6.7 -> 8.3 ms, round 4)
         if (A.mode == 0) {           // attach(a): x = b non-bridge record with a in NB_BB(x)
             ok = (cb == 2) && in_list(A, b, 0, a, ab);
         } else if (A.mode == 1) {    // src(t = a): s = b
-            // (the three per-item tests as ONE byte gather where the pass built it: nearly every entry reaches the second and
-            //  half of them the third, and a gather is what these passes are made of)
-            if (A.meta) ok = (A.meta[b] == 7) && (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
-            else ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
-                      (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
+            // (the three per-item tests packed into one byte table, one gather instead of up to three: 5.2 ms either way, round 4)
+            ok = (cb == 1) && (A.flags[b] & 1) && (A.attach_ptr[b + 1] > A.attach_ptr[b]) &&
+                 (in_list(A, b, 0, a, ab) || in_list(A, b, 1, a, ab));
             if (ok) {
                 bool joint = (A.cls[a] == 1) && (A.attach_ptr[a + 1] > A.attach_ptr[a]) &&
                              (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
@@ -416,11 +413,6 @@ __device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, 
         }
     }
     return ok;
-}
-__global__ __launch_bounds__(256) void k_rev_meta(int I, const uint8_t *cls, const uint8_t *flags, const long long *attach_ptr,
-                                                  uint8_t *meta) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < I) meta[b] = (uint8_t)((cls[b] == 1 ? 1 : 0) | ((flags[b] & 1) ? 2 : 0) | (attach_ptr[b + 1] > attach_ptr[b] ? 4 : 0));
 }
 __device__ __forceinline__ void rev_write(const RevArgs &A, int a, long long p, long long o, int b, double sv, uint8_t fl) {
     double mu = (double)A.mutu[p];
@@ -2678,15 +2670,7 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     const int n_rows = row_hi - row_lo;
     dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    XM_SCOPE(stream);
-    A.meta = nullptr;
-    if (mode == 1 && !(fill && eflag)) {      // (a fill pass that reads eflag tests nothing)
-        uint8_t *meta = nullptr;
-        XM_HIP(xm_malloc_async((void **)&meta, (size_t)A.I, st));
-        k_rev_meta<<<dim3((unsigned)((A.I + 255) / 256)), dim3(256), 0, st>>>(A.I, cls, flags, (const long long *)attach_ptr, meta);
-        XM_LAUNCH_CHECK();
-        A.meta = meta;
-    }
+
     if (long_rows && !fill) {     // the count pass lists the long rows, the fill pass that follows reuses the list
         XM_HIP(hipMemsetAsync(long_rows, 0, sizeof(int32_t), st));
         k_rev_long_rows<<<dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st>>>(row_lo, row_hi, (const long long *)S->row_ptr,

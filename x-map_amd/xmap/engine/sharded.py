@@ -21,6 +21,8 @@ the pair's owner): see its docstring.
 Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on the MI355X node; "gloo"
 (host staging) is used by the CPU-side tests and for rehearsals with several ranks on one GPU.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -192,7 +194,9 @@ def run_step(eng, method, cap, k, private, dist=None, rank=0, world=1, full=Fals
     I = eng.R.n_items
     if dist is not None and group is not None:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if dist is None or world == 1:
+    # (XMAP_FORCE_DIST=1: the sharded path also with ONE rank -- every collective of the step runs on the backend's device
+    #  buffers, which is how a one-GPU box rehearses the RCCL code path)
+    if dist is None or (world == 1 and os.environ.get("XMAP_FORCE_DIST") != "1"):
         with eng.timed("stage_a"):
             S = eng.item_sim(method, cap)
         with eng.timed("stage_b"):
