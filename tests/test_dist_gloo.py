@@ -110,12 +110,17 @@ def test_rank_groups_and_error_agreement_world4_gloo():
     assert [o for *_, o in got] == ["ok", "ok", "peer", "own"]
 
 
-def _worker_a2a(rank, world, port, q):
+def _worker_a2a(rank, world, port, q, native=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if native:
+        os.environ["XMAP_A2A_NATIVE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from xmap.engine.sharded import Comm
     comm = Comm(dist)
+    assert comm.a2a_native == native
+    if native:
+        comm.A2A_PIECE_BYTES = 16 * 3             # three rows of two int64 per piece: several rounds, the last ones ragged
     # rank s holds rows (key, s) with keys 0 .. 5+s, sorted; keys [2 r, 2 r + 2) belong to rank r, the rest to the last
     n = 6 + rank
     rows = torch.stack([torch.arange(n, dtype=torch.int64), torch.full((n,), rank, dtype=torch.int64)], dim=1)
@@ -127,14 +132,19 @@ def _worker_a2a(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_all_to_all_rows_world3_gloo():
-    """the exchange of the user-sharded step's partial-similarity records (Comm.all_to_all_rows; gloo has no all-to-all: the
-    all-gather form) and the fixed-size all-gather of the item sums: every rank receives exactly its key ranges, sender
-    after sender"""
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_all_to_all_rows_world3_gloo(native):
+    """the exchange of the sharded steps' records (Comm.all_to_all_rows) and the fixed-size all-gather of the item sums: every
+    rank receives exactly its key ranges, sender after sender.  native=False: the all-gather form the gloo rehearsals on one
+    GPU use; native=True: the branch RCCL takes -- all_to_all_single with split sizes, in pieces (3 rows each here: several
+    rounds, ragged last ones) -- run on gloo's own all-to-all with three ranks, which no one-GPU box can do on RCCL itself"""
     world, port = 3, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_a2a, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_a2a, args=(r, world, port, q, native)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=120) for _ in range(world))

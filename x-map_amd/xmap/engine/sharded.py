@@ -68,6 +68,9 @@ class Comm(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.host = dist.get_backend(group) == "gloo"
+        # gloo has an all-to-all for host tensors too: XMAP_A2A_NATIVE=1 sends all_to_all_rows down the RCCL branch on it (the
+        # piece / offset arithmetic of that branch under several ranks, which a one-GPU box cannot run on RCCL itself)
+        self.a2a_native = (not self.host) or os.environ.get("XMAP_A2A_NATIVE") == "1"
 
     def all_reduce(self, t, op="sum"):
         ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}
@@ -159,7 +162,7 @@ class Comm(object):
         tabs = [torch.zeros_like(table) for _ in range(self.world)]
         self.dist.all_gather(tabs, table, group=self.group)
         tabs = torch.stack(tabs).cpu()                     # tabs[s][r]: rows rank s sends to rank r
-        if self.host:
+        if not self.a2a_native:
             allrows = self.all_gather_var(rows.reshape(-1)).view(-1, w)
             start = torch.cumsum(tabs.sum(dim=1), 0) - tabs.sum(dim=1)      # first row of rank s in allrows
             inner = torch.cumsum(tabs, 1) - tabs                            # offset of the range for r inside s's rows
@@ -167,6 +170,9 @@ class Comm(object):
                      for s in range(self.world)]
             return torch.cat(parts) if parts else allrows[:0]
         recv = [int(tabs[s][self.rank]) for s in range(self.world)]
+        dev0 = rows.device
+        if self.host:
+            rows = rows.cpu()
         out = torch.empty((sum(recv), w), dtype=rows.dtype, device=rows.device)
         # In pieces of at most 256 MiB per peer: RCCL 2.26's all_to_all_single returned wrong data for pieces above 1 GiB
         # (measured with one rank: 1.28 GB of int64 rows came back wrong from byte 640 M on; all_gather / all_reduce of
@@ -184,7 +190,7 @@ class Comm(object):
             for s_ in range(self.world):
                 out[first[s_] + c * piece:first[s_] + c * piece + recv_c[s_]] = tmp[at:at + recv_c[s_]]
                 at += recv_c[s_]
-        return out
+        return out.to(dev0)
 
 
 # ----------------------------------------------------------------------------- the step
