@@ -2455,6 +2455,8 @@ constexpr int MERGE_WAVES = 16;
 constexpr int MERGE_GROUP = 12;
 
 // rows of one start: add row (acc_s, touched_s[0..nt_s)) into (acc_d, touched_d, *s_nt); all waves of the block
+// (four sets of 64 entries per wave and step with all their loads in flight -- 120 VGPRs, one block per CU -- made the two
+//  kernels slower: 5.35 + 6.07 ms against 4.23 + 5.45, round 4)
 __device__ __forceinline__ void merge_row(double *acc_d, int *touched_d, int *s_nt, double *acc_s, const int *touched_s, int nt_s) {
     const int lane = lane_id(), w = threadIdx.x >> 6;
     for (int b0 = 64 * w; b0 < nt_s; b0 += 64 * MERGE_WAVES) {
