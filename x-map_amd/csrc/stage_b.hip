@@ -1913,12 +1913,33 @@ __device__ __forceinline__ void heads_Q(const Path2Args &B, QAcc &W, int start, 
 #elif defined(Q_STORE) || defined(Q_STOREU)    // (Q_STOREU: the usual scattered places, stores only)
                 if (fl_) { a[0] = a_sh; a[1] = a_sl; a[2] = a_ch; a[3] = a_cl; }
 #else
+#ifndef Q_ST1
+                // The entry's two 16-byte halves leave from the end's first TWO slice lanes in ONE store instruction (round 4; -DQ_ST1:
+                // both from the first lane): the CU's memory path charges an instruction by the lines it touches
+                // (profiles/ta_rate.hip), and the two stores of the one-lane form touch the same ~15 lines twice: 490-492 -> 478-481 ms.
+                // (The two LOADS split the same way: no change -- the second load of the one-lane form hits L1.  The finalisation
+                //  with an entry per lane pair: +4 ms -- half as many line requests, but the division twice per entry.)
+                if (fl_) {
+                    first = (h1_ == 0.0);
+                    acc2(h0_, l0_, a_sh); l0_ += a_sl;
+                    acc2(h1_, l1_, a_ch); l1_ += a_cl;
+                }
+                if (sh >= 1) {
+                    const double p_h = quad_swap<0xB1>(h1_), p_l = quad_swap<0xB1>(l1_);      // (slice 1 <- slice 0)
+                    double *dst = a + (slice == 0 ? 0 : 2);
+                    const double v0 = slice == 0 ? h0_ : p_h, v1 = slice == 0 ? l0_ : p_l;
+                    if (ok && slice <= 1) { dst[0] = v0; dst[1] = v1; }
+                } else if (fl_) {
+                    a[0] = h0_; a[1] = l0_; a[2] = h1_; a[3] = l1_;
+                }
+#else
                 if (fl_) {
                     first = (h1_ == 0.0);
                     acc2(h0_, l0_, a_sh); l0_ += a_sl;
                     acc2(h1_, l1_, a_ch); l1_ += a_cl;
                     a[0] = h0_; a[1] = l0_; a[2] = h1_; a[3] = l1_;
                 }
+#endif
 #endif
                 const unsigned long long fm = __ballot(first);
                 if (first) W.touched[W.nt + __popcll(fm & lanemask_lt())] = eu;
@@ -2458,6 +2479,33 @@ constexpr int MERGE_GROUP = 12;
 // (four sets of 64 entries per wave and step with all their loads in flight -- 120 VGPRs, one block per CU -- made the two
 //  kernels slower: 5.35 + 6.07 ms against 4.23 + 5.45, round 4)
 __device__ __forceinline__ void merge_row(double *acc_d, int *touched_d, int *s_nt, double *acc_s, const int *touched_s, int nt_s) {
+#ifdef Q_MRG2     // (an entry per lane PAIR: the even lane adds the (value, error) pair of the sums, the odd lane that of the weights)
+    {
+        const int lane = lane_id(), w = threadIdx.x >> 6;
+        const int half = (lane & 1) * 2;
+        for (int b0 = 32 * w; b0 < nt_s; b0 += 32 * MERGE_WAVES) {
+            const int b = b0 + (lane >> 1);
+            bool first = false;
+            int e = 0;
+            if (b < nt_s) {
+                e = touched_s[b];
+                double *s = acc_s + (size_t)e * 4 + half, *d = acc_d + (size_t)e * 4 + half;
+                double hi = d[0], lo = d[1];
+                first = half == 2 && hi == 0.0;
+                dd_add(hi, lo, s[0]); dd_add(hi, lo, s[1]);
+                d[0] = hi; d[1] = lo;
+                s[0] = 0.0; s[1] = 0.0;
+            }
+            const unsigned long long m = __ballot(first);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(s_nt, __popcll(m));
+            base = rl32(base, 0);
+            if (first) touched_d[base + __popcll(m & lanemask_lt())] = e;
+        }
+        __syncthreads();
+        return;
+    }
+#endif
     const int lane = lane_id(), w = threadIdx.x >> 6;
     for (int b0 = 64 * w; b0 < nt_s; b0 += 64 * MERGE_WAVES) {
         const int b = b0 + lane;
