@@ -728,10 +728,25 @@ __device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, doub
             e = touched[b];
             double *a = acc + ((size_t)e * gs + mem) * 4;
             v = 1.0 * (a[0] + a[1]) / (a[2] + a[3]);     // pairs of k_paths4 are not renormalised; a renormalised pair is its own sum
+#ifndef Q_FIN3
             a[0] = 0.0; a[1] = 0.0; a[2] = 0.0; a[3] = 0.0;
+#endif
             key = xsim_key(v);
             if (full) { A.xs_end[off + b] = A.uitem ? A.uitem[e] : e; A.xs_val[off + b] = v; }
         }
+#ifdef Q_FIN3
+        {   // the entries are zeroed by lane PAIRS: both lanes of a pair write one half each of the even lane's entry, then of the
+            // odd lane's -- two store instructions over 32 lines each instead of two over 64 (the memory path charges lines)
+            const unsigned long long ab = act ? (unsigned long long)(acc + ((size_t)e * gs + mem) * 4) : 0ull;
+#define XM_PAIR(CTRL) { const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)ab, CTRL, 0xf, 0xf, true);            \
+                        const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(ab >> 32), CTRL, 0xf, 0xf, true);      \
+                        double *z = (double *)(((unsigned long long)hi_ << 32) | lo_);                                               \
+                        if (z) { z[(lane & 1) * 2] = 0.0; z[(lane & 1) * 2 + 1] = 0.0; } }
+            XM_PAIR(0xA0)       // quad_perm [0,0,2,2]: the even lane's entry
+            XM_PAIR(0xF5)       // quad_perm [1,1,3,3]: the odd lane's entry
+#undef XM_PAIR
+        }
+#endif
         // (rows of k_paths4 are indexed by end RANK; the item behind a rank -- a random 4-byte gather, a third of the pass's
         //  memory requests -- is looked up only for the candidates that pass the running threshold: ~10 ln(n / 10) per start)
         const bool q = act && key >= thr;
@@ -997,7 +1012,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                     const int s = A.src_idx[p];
                     for (long long ap = A.att_ptr[s] + lane; ap < A.att_ptr[s + 1]; ap += 64) {
                         const int xid = A.nb_id[A.att_idx[ap]];
-                        if (ONE_RANGE || (xid >= x0 && xid < x1)) body(xid, v2, m2, f2, p, ap);
+                        if (ONE_RANGE || (xid >= x0 && xid < x1)) body(true, xid, v2, m2, f2, p, ap);
                     }
                 }
             }
@@ -1088,8 +1103,8 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                     for (int u = 0; u < MID_UNROLL; u++) {
                         const int jl = jj[u] >= 0 ? jj[u] : 0;
                         const int qq = __shfl(q, jl, 64), jjo = __shfl(jo, jl, 64);      // (all lanes take part in the exchange)
-                        if (jj[u] >= 0 && (ONE_RANGE || (xi[u] >= x0 && xi[u] < x1)))
-                            body(xi[u], q_v2[qq], q_m2[qq], q_f2[qq], q_s0[qq] + jjo, ap[u]);
+                        // (every lane calls: the placement moves its records between the lanes of a quad)
+                        body(jj[u] >= 0 && (ONE_RANGE || (xi[u] >= x0 && xi[u] < x1)), xi[u], q_v2[qq], q_m2[qq], q_f2[qq], q_s0[qq] + jjo, ap[u]);
                     }
                 }
             }
@@ -1103,7 +1118,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
         if (!ONE_RANGE) __syncthreads();                // (the previous range's placement is over)
         for (int i = threadIdx.x; i < nx; i += 64 * MIDROW_WAVES) bins[i] = 0;
         __syncthreads();
-        walk(x0, x1, [&](int xid, double, double, double, long long, long long) { atomicAdd(&bins[xid - x0], 1); });
+        walk(x0, x1, [&](bool valid, int xid, double, double, double, long long, long long) { if (valid) atomicAdd(&bins[xid - x0], 1); });
         __syncthreads();
         // per thread a run of consecutive bins: (non-empty tiles << 40 | records), block-wide exclusive scan
         const int per = (nx + 64 * MIDROW_WAVES - 1) / (64 * MIDROW_WAVES);
@@ -1133,21 +1148,64 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                 }
             }
             __syncthreads();
-            walk(x0, x1, [&](int xid, double v2, double m2, double f2, long long p, long long ap) {
-                const long long pos = rbase + atomicAdd(&bins[xid - x0], 1);
-#ifdef EXP_MID_NOVAL      // (ablation: no gathers of the edge values -- wrong records, timing only)
-                const double v3 = 1.0, m3 = 1.0, f3 = 1.0, v4 = 1.0, m4 = (double)(p + ap), f4 = 1.0;
-#else
-                const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];      // edge (t, s)
-                const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
-#endif
+            walk(x0, x1, [&](bool valid, int xid, double v2, double m2, double f2, long long p, long long ap) {
+                long long pos = 0;
                 MidX r;
-                r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
-                r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
-#ifdef EXP_MID_NOSTORE    // (ablation: the records are not written -- timing only)
-                if (r.mu == -1.5) A.midX[pos] = r;
+                r.sm2 = 0.0; r.sm3 = 0.0; r.sm4 = 0.0; r.f2 = 0.0; r.f3 = 0.0; r.f4 = 0.0; r.mu = 0.0; r.xid = 0; r.pad = 0;
+                if (valid) {
+                    pos = rbase + atomicAdd(&bins[xid - x0], 1);
+#ifdef EXP_MID_NOVAL      // (ablation: no gathers of the edge values -- wrong records, timing only)
+                    const double v3 = 1.0, m3 = 1.0, f3 = 1.0, v4 = 1.0, m4 = (double)(p + ap), f4 = 1.0;
 #else
-                A.midX[pos] = r;
+                    const double v3 = A.src_val[p * 3], m3 = A.src_val[p * 3 + 1], f3 = A.src_val[p * 3 + 2];      // edge (t, s)
+                    const double v4 = A.att_val[ap * 3], m4 = A.att_val[ap * 3 + 1], f4 = A.att_val[ap * 3 + 2];  // edge (s, x)
+#endif
+                    r.sm2 = v2 * m2; r.sm3 = v3 * m3; r.sm4 = v4 * m4; r.f2 = f2; r.f3 = f3; r.f4 = f4;
+                    r.mu = (m2 + m3) + m4; r.xid = xid; r.pad = 0;
+                }
+#if defined(EXP_MID_NOSTORE)    // (ablation: the records are not written -- timing only)
+                if (valid && r.mu == -1.5) A.midX[pos] = r;
+#elif defined(EXP_MID_WALK1) || defined(EXP_MID_ST1)      // (a record per lane: four 16-byte stores over 64 lines each)
+                if (valid) A.midX[pos] = r;
+#else
+                // The four records of a QUAD of lanes leave as four store instructions of 16 lines each instead of four of 64
+                // (the CU's memory path charges a store by the lines it touches, profiles/ta_rate.hip): the 4 x 4 pieces of 16 bytes
+                // are transposed inside the quad (two DPP butterfly steps), lane q then holds piece q of each of the quad's records
+                uint4 P[4];
+                {
+                    const long long b0 = __double_as_longlong(r.sm2), b1 = __double_as_longlong(r.sm3), b2 = __double_as_longlong(r.sm4);
+                    const long long b3 = __double_as_longlong(r.f2), b4 = __double_as_longlong(r.f3), b5 = __double_as_longlong(r.f4);
+                    const long long b6 = __double_as_longlong(r.mu);
+                    P[0] = make_uint4((unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32));
+                    P[1] = make_uint4((unsigned)b2, (unsigned)(b2 >> 32), (unsigned)b3, (unsigned)(b3 >> 32));
+                    P[2] = make_uint4((unsigned)b4, (unsigned)(b4 >> 32), (unsigned)b5, (unsigned)(b5 >> 32));
+                    P[3] = make_uint4((unsigned)b6, (unsigned)(b6 >> 32), (unsigned)r.xid, (unsigned)r.pad);
+                }
+                const int ql = lane & 3;
+                const bool odd = (ql & 1) != 0, high = (ql & 2) != 0;
+#define XM_SWAP4(CTRL, V) make_uint4((unsigned)__builtin_amdgcn_update_dpp(0, (int)(V).x, CTRL, 0xf, 0xf, true), \
+                                     (unsigned)__builtin_amdgcn_update_dpp(0, (int)(V).y, CTRL, 0xf, 0xf, true), \
+                                     (unsigned)__builtin_amdgcn_update_dpp(0, (int)(V).z, CTRL, 0xf, 0xf, true), \
+                                     (unsigned)__builtin_amdgcn_update_dpp(0, (int)(V).w, CTRL, 0xf, 0xf, true))
+#pragma unroll
+                for (int m = 0; m < 2; m++) {       // lane ^ 1: the off-diagonal pieces of every 2 x 2 block
+                    const uint4 send = odd ? P[2 * m] : P[2 * m + 1];
+                    const uint4 recv = XM_SWAP4(0xB1, send);
+                    if (odd) P[2 * m] = recv; else P[2 * m + 1] = recv;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; c++) {       // lane ^ 2: the off-diagonal 2 x 2 blocks
+                    const uint4 send = high ? P[c] : P[2 + c];
+                    const uint4 recv = XM_SWAP4(0x4E, send);
+                    if (high) P[c] = recv; else P[2 + c] = recv;
+                }
+#undef XM_SWAP4
+                uint4 *out16 = reinterpret_cast<uint4 *>(A.midX);
+#define XM_QSTORE(J) { const long long pj = __double_as_longlong(quad_bcast<J>(__longlong_as_double(pos)));                       \
+                       const int vj = __builtin_amdgcn_update_dpp(0, valid ? 1 : 0, (J) | ((J) << 2) | ((J) << 4) | ((J) << 6), 0xf, 0xf, true); \
+                       if (vj) out16[pj * 4 + ql] = P[J]; }
+                XM_QSTORE(0) XM_QSTORE(1) XM_QSTORE(2) XM_QSTORE(3)
+#undef XM_QSTORE
 #endif
             });
         }
@@ -2479,33 +2537,6 @@ constexpr int MERGE_GROUP = 12;
 // (four sets of 64 entries per wave and step with all their loads in flight -- 120 VGPRs, one block per CU -- made the two
 //  kernels slower: 5.35 + 6.07 ms against 4.23 + 5.45, round 4)
 __device__ __forceinline__ void merge_row(double *acc_d, int *touched_d, int *s_nt, double *acc_s, const int *touched_s, int nt_s) {
-#ifdef Q_MRG2     // (an entry per lane PAIR: the even lane adds the (value, error) pair of the sums, the odd lane that of the weights)
-    {
-        const int lane = lane_id(), w = threadIdx.x >> 6;
-        const int half = (lane & 1) * 2;
-        for (int b0 = 32 * w; b0 < nt_s; b0 += 32 * MERGE_WAVES) {
-            const int b = b0 + (lane >> 1);
-            bool first = false;
-            int e = 0;
-            if (b < nt_s) {
-                e = touched_s[b];
-                double *s = acc_s + (size_t)e * 4 + half, *d = acc_d + (size_t)e * 4 + half;
-                double hi = d[0], lo = d[1];
-                first = half == 2 && hi == 0.0;
-                dd_add(hi, lo, s[0]); dd_add(hi, lo, s[1]);
-                d[0] = hi; d[1] = lo;
-                s[0] = 0.0; s[1] = 0.0;
-            }
-            const unsigned long long m = __ballot(first);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(s_nt, __popcll(m));
-            base = rl32(base, 0);
-            if (first) touched_d[base + __popcll(m & lanemask_lt())] = e;
-        }
-        __syncthreads();
-        return;
-    }
-#endif
     const int lane = lane_id(), w = threadIdx.x >> 6;
     for (int b0 = 64 * w; b0 < nt_s; b0 += 64 * MERGE_WAVES) {
         const int b = b0 + lane;
