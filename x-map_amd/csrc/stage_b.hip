@@ -735,12 +735,14 @@ __device__ __forceinline__ int finalize_slice(const PathArgs &A, FinBuf &F, doub
             if (full) { A.xs_end[off + b] = A.uitem ? A.uitem[e] : e; A.xs_val[off + b] = v; }
         }
 #ifdef Q_FIN3
-        {   // the entries are zeroed by lane PAIRS: both lanes of a pair write one half each of the even lane's entry, then of the
-            // odd lane's -- two store instructions over 32 lines each instead of two over 64 (the memory path charges lines)
+        {   // (-DQ_FIN3, not the default: inside the box-to-box noise, 478-501 ms either way) the entries are zeroed by lane PAIRS:
+            // both lanes of a pair write one half each of the even lane's entry, then of the odd lane's -- two store instructions
+            // over 32 lines each instead of two over 64
             const unsigned long long ab = act ? (unsigned long long)(acc + ((size_t)e * gs + mem) * 4) : 0ull;
 #define XM_PAIR(CTRL) { const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)ab, CTRL, 0xf, 0xf, true);            \
                         const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(ab >> 32), CTRL, 0xf, 0xf, true);      \
-                        double *z = (double *)(((unsigned long long)hi_ << 32) | lo_);                                               \
+                        typedef __attribute__((address_space(1))) double gf64;      /* (a GLOBAL pointer: the integer round trip loses the address space) */ \
+                        gf64 *z = (gf64 *)(((unsigned long long)hi_ << 32) | lo_);                                                   \
                         if (z) { z[(lane & 1) * 2] = 0.0; z[(lane & 1) * 2 + 1] = 0.0; } }
             XM_PAIR(0xA0)       // quad_perm [0,0,2,2]: the even lane's entry
             XM_PAIR(0xF5)       // quad_perm [1,1,3,3]: the odd lane's entry
