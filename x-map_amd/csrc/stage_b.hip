@@ -2539,6 +2539,34 @@ constexpr int MERGE_GROUP = 12;
 // (four sets of 64 entries per wave and step with all their loads in flight -- 120 VGPRs, one block per CU -- made the two
 //  kernels slower: 5.35 + 6.07 ms against 4.23 + 5.45, round 4)
 __device__ __forceinline__ void merge_row(double *acc_d, int *touched_d, int *s_nt, double *acc_s, const int *touched_s, int nt_s) {
+#ifdef Q_MRG2     // (an entry per lane PAIR: the even lane adds the (value, error) pair of the sums, the odd lane that of the weights --
+                  //  the two halves are independent, and every load / store instruction touches each line once)
+    {
+        const int lane = lane_id(), w = threadIdx.x >> 6;
+        const int half = (lane & 1) * 2;
+        for (int b0 = 32 * w; b0 < nt_s; b0 += 32 * MERGE_WAVES) {
+            const int b = b0 + (lane >> 1);
+            bool first = false;
+            int e = 0;
+            if (b < nt_s) {
+                e = touched_s[b];
+                double *s = acc_s + (size_t)e * 4 + half, *d = acc_d + (size_t)e * 4 + half;
+                double hi = d[0], lo = d[1];
+                first = half == 2 && hi == 0.0;
+                dd_add(hi, lo, s[0]); dd_add(hi, lo, s[1]);
+                d[0] = hi; d[1] = lo;
+                s[0] = 0.0; s[1] = 0.0;
+            }
+            const unsigned long long m = __ballot(first);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(s_nt, __popcll(m));
+            base = rl32(base, 0);
+            if (first) touched_d[base + __popcll(m & lanemask_lt())] = e;
+        }
+        __syncthreads();
+        return;
+    }
+#endif
     const int lane = lane_id(), w = threadIdx.x >> 6;
     for (int b0 = 64 * w; b0 < nt_s; b0 += 64 * MERGE_WAVES) {
         const int b = b0 + lane;
