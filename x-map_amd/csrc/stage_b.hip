@@ -2539,8 +2539,9 @@ constexpr int MERGE_GROUP = 12;
 // (four sets of 64 entries per wave and step with all their loads in flight -- 120 VGPRs, one block per CU -- made the two
 //  kernels slower: 5.35 + 6.07 ms against 4.23 + 5.45, round 4)
 __device__ __forceinline__ void merge_row(double *acc_d, int *touched_d, int *s_nt, double *acc_s, const int *touched_s, int nt_s) {
-#ifdef Q_MRG2     // (an entry per lane PAIR: the even lane adds the (value, error) pair of the sums, the odd lane that of the weights --
-                  //  the two halves are independent, and every load / store instruction touches each line once)
+#ifndef Q_MRG1    // An entry per lane PAIR (round 4): the even lane adds the (value, error) pair of the sums, the odd lane that of the
+                  // weights -- the two halves are independent, and every load / store instruction touches each line once:
+                  // k_merge_groups 4.07 -> 3.55 ms, k_merge 5.62 -> 5.03 ms (rocprof, profiles/tools/merge_ab.sh).  -DQ_MRG1: an entry per lane
     {
         const int lane = lane_id(), w = threadIdx.x >> 6;
         const int half = (lane & 1) * 2;
