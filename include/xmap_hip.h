@@ -333,6 +333,13 @@ int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, con
                        int32_t *rcnt /*[I]*/, int32_t row_lo, int32_t row_hi /*the rows (= targets of the lists) of this
                        call: the list of a row is built from that row alone, so a rank's share of the rows gives a
                        contiguous share of the lists; [0, I) = all*/);
+/* attach (mode 0) and rnn (mode 2) lists counted in ONE pass over the rows -- both ask the same non-bridge neighbours b of an
+ * entry, about their two lists: one class gather and one read of the matrix instead of two.  eflag (required) then serves
+ * xmap_reverse_fill of mode 0 and of mode 2 (bit 0 / bit 2). */
+int xmap_reverse_count_att_rnn(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const uint8_t *cls,
+                               const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                               const uint32_t *contains_mask, const uint8_t *flags, const void *thr, int32_t *long_rows,
+                               uint8_t *eflag, int32_t *rcnt_att /*[I]*/, int32_t *rcnt_rnn /*[I]*/, int32_t row_lo, int32_t row_hi);
 int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,
                       const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
                       const uint32_t *contains_mask, const uint8_t *flags, const int64_t *attach_ptr,

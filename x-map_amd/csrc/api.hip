@@ -92,15 +92,17 @@ static int d2h(T *host, const T *dev, size_t n, hipStream_t st) {
 
 // one reverse adjacency: count -> scan -> fill
 static int reverse_list(xmap_ctx *c, int mode, const uint8_t *bb, const int64_t *attach_ptr, const void *thr, int32_t *long_rows,
-                        uint8_t *eflag,
+                        uint8_t *eflag, int32_t *counted /*the list's counts where a fused pass left them, or NULL*/,
                         const int64_t **rptr, const int32_t **ridx, const double **rval, const uint8_t **rflag) {
     const int I = c->R.n_items, k = c->top_k;
-    int32_t *rcnt;
+    int32_t *rcnt = counted;
     int64_t *ptr;
-    XM_ALLOCZ(c->p_ext, rcnt, I);
     XM_ALLOCZ(c->p_ext, ptr, I + 1);
-    XM_TRY(xmap_reverse_count(c->st, &c->S, mode, k, bb, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->R.suffix_cls,
-                              c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, eflag, rcnt, 0, I));
+    if (!counted) {
+        XM_ALLOCZ(c->p_ext, rcnt, I);
+        XM_TRY(xmap_reverse_count(c->st, &c->S, mode, k, bb, c->T.cls, c->T.kcnt, c->T.kcol, c->T.kval, c->R.suffix_cls,
+                                  c->R.contains_mask, c->R.flags, attach_ptr, thr, long_rows, eflag, rcnt, 0, I));
+    }
     int64_t n = 0;
     XM_TRY(xmap_exclusive_scan_i32_to_i64(c->st, rcnt, ptr, I, &n));
     int32_t *idx;
@@ -388,9 +390,16 @@ int xmap_ctx_extend(xmap_ctx *c, int top_k, int64_t *n_out, int64_t *n_paths) {
     XM_ALLOC(c->p_ext, eflag, (size_t)(c->n_kept > 0 ? c->n_kept : 1));
     XM_TRY(xmap_knn_thresholds(c->st, I, k, kcnt, kcol, kval, thr));
     const uint8_t *dummy;
-    XM_TRY(reverse_list(c, 0, bb, nullptr, thr, long_rows, eflag, &T.att_ptr, &T.att_idx, &T.att_val, &dummy));
-    XM_TRY(reverse_list(c, 1, bb, T.att_ptr, thr, long_rows, eflag, &T.src_ptr, &T.src_idx, &T.src_val, &T.src_flag));
-    XM_TRY(reverse_list(c, 2, bb, nullptr, thr, long_rows, eflag, &T.rnn_ptr, &T.rnn_idx, &T.rnn_val, &dummy));
+    // attach and rnn lists: ONE count pass over the matrix for both, then their fill passes; then the src lists (whose
+    // predicate reads the attach offsets)
+    int32_t *cnt_att, *cnt_rnn;
+    XM_ALLOCZ(c->p_ext, cnt_att, I);
+    XM_ALLOCZ(c->p_ext, cnt_rnn, I);
+    XM_TRY(xmap_reverse_count_att_rnn(c->st, &c->S, k, bb, cls, kcnt, kcol, kval, c->R.suffix_cls, c->R.contains_mask, c->R.flags,
+                                      thr, long_rows, eflag, cnt_att, cnt_rnn, 0, I));
+    XM_TRY(reverse_list(c, 0, bb, nullptr, thr, long_rows, eflag, cnt_att, &T.att_ptr, &T.att_idx, &T.att_val, &dummy));
+    XM_TRY(reverse_list(c, 2, bb, nullptr, thr, long_rows, eflag, cnt_rnn, &T.rnn_ptr, &T.rnn_idx, &T.rnn_val, &dummy));
+    XM_TRY(reverse_list(c, 1, bb, T.att_ptr, thr, long_rows, eflag, nullptr, &T.src_ptr, &T.src_idx, &T.src_val, &T.src_flag));
     // exact per-start path counts -> work units
     int64_t *wtmp, *P;
     XM_ALLOCZ(c->p_ext, wtmp, (size_t)4 * I); XM_ALLOCZ(c->p_ext, P, I);

@@ -360,6 +360,7 @@ struct RevArgs {
     const uint8_t *flags;
     const long long *attach_ptr;
     int *rcnt;
+    int *rcnt2;                  // mode 3 (attach and rnn lists counted in ONE pass over the rows): the rnn counts
     const long long *rptr;
     int *ridx;
     double *rval;
@@ -408,6 +409,8 @@ __device__ __forceinline__ bool rev_entry(const RevArgs &A, int a, long long p, 
                              (in_list(A, a, 0, b, ab) || in_list(A, a, 1, b, ab));
                 fl = joint ? 1 : 0;
             }
+        } else if (A.mode == 3) {    // attach and rnn together (count pass only): ok = attach, fl bit 1 = rnn (eflag bit 2)
+            if (cb == 2) { ok = in_list(A, b, 0, a, ab); if (in_list(A, b, 1, a, ab)) fl = 2; }
         } else {                     // rnn(y = a): x = b non-bridge record with a in NB_NN(x)
             ok = (cb == 2) && in_list(A, b, 1, a, ab);
         }
@@ -432,15 +435,16 @@ __device__ __forceinline__ bool rev_test(const RevArgs &A, int a, long long p, l
     if (!A.eflag) return rev_entry(A, a, p, hi, b, sv, fl);
     if (!FILL) {
         const bool ok = rev_entry(A, a, p, hi, b, sv, fl);
-        if (p < hi) A.eflag[p - p0] = (uint8_t)((ok ? 1 : 0) | (fl << 1));
+        // (bit 0 = attach / src, bit 1 = joint (src), bit 2 = rnn: a fused count serves the fill passes of both of its lists)
+        if (p < hi) A.eflag[p - p0] = (uint8_t)((ok ? (A.mode == 2 ? 4 : 1) : 0) | (fl << 1));
         return ok;
     }
     b = 0; sv = 0.0; fl = 0;
     bool ok = false;
     if (p < hi) {
         const uint8_t e = A.eflag[p - p0];
-        ok = (e & 1) != 0;
-        fl = (uint8_t)(e >> 1);
+        ok = (e & (A.mode == 2 ? 4 : 1)) != 0;
+        fl = (uint8_t)((e >> 1) & 1);
         if (ok) { b = A.col[p]; sv = A.sim[p]; }
     }
     return ok;
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
     bool row_ok = true;
     if (A.mode == 1) row_ok = (A.flags[a] & 2) != 0;  // "T:" in t
     long long out = FILL ? A.rptr[a] : 0;
-    int total = 0;
+    int total = 0, total2 = 0;
     const long long p0 = A.eflag ? A.row_ptr[A.row_lo] : 0;
     if (row_ok)
         for (long long base = lo; base < hi; base += 64) {
@@ -473,8 +477,9 @@ __global__ __launch_bounds__(256) void k_reverse(RevArgs A) {
             int c = __popcll(m);
             out += c;
             total += c;
+            if (!FILL && A.mode == 3) total2 += __popcll(__ballot((fl & 2) != 0));
         }
-    if (!FILL && lane == 0) A.rcnt[a] = total;
+    if (!FILL && lane == 0) { A.rcnt[a] = total; if (A.mode == 3) A.rcnt2[a] = total2; }
 }
 
 __global__ __launch_bounds__(256) void k_rev_long_rows(int row_lo, int row_hi, const long long *row_ptr, int rev_long,
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(256) void k_rev_long_rows(int row_lo, int row_hi, c
 template <bool FILL>
 __global__ __launch_bounds__(64 * REV_WAVES) void k_reverse_long(RevArgs A) {
     __shared__ int s_cnt[REV_WAVES];
+    __shared__ int s_tot2;
     const int lane = lane_id(), w = threadIdx.x >> 6;
     const int n_long = A.long_rows[0];
     const long long p0 = A.eflag ? A.row_ptr[A.row_lo] : 0;
@@ -494,13 +500,15 @@ __global__ __launch_bounds__(64 * REV_WAVES) void k_reverse_long(RevArgs A) {
         const long long lo = A.row_ptr[a], hi = A.row_ptr[a + 1];
         const bool row_ok = (A.mode != 1) || ((A.flags[a] & 2) != 0);
         long long out = FILL ? A.rptr[a] : 0;
-        int total = 0;
+        int total = 0, total2 = 0;
+        if (!FILL && A.mode == 3) { if (threadIdx.x == 0) s_tot2 = 0; __syncthreads(); }
         if (row_ok)
             for (long long base = lo; base < hi; base += 64 * REV_WAVES) {
                 const long long p = base + threadIdx.x;
                 int b; double sv; uint8_t fl;
                 const bool ok = rev_test<FILL>(A, a, p, hi, p0, b, sv, fl);
                 const unsigned long long m = __ballot(ok);
+                if (!FILL && A.mode == 3) total2 += __popcll(__ballot((fl & 2) != 0));      // (this wave's rnn entries)
                 if (lane == 0) s_cnt[w] = __popcll(m);
                 __syncthreads();
                 int before = 0, all = 0;
@@ -510,6 +518,12 @@ __global__ __launch_bounds__(64 * REV_WAVES) void k_reverse_long(RevArgs A) {
                 total += all;
                 __syncthreads();
             }
+        if (!FILL && A.mode == 3) {
+            if (lane == 0) atomicAdd(&s_tot2, total2);
+            __syncthreads();
+            if (threadIdx.x == 0) A.rcnt2[a] = s_tot2;
+            __syncthreads();
+        }
         if (!FILL && threadIdx.x == 0) A.rcnt[a] = total;
     }
 }
@@ -2763,9 +2777,10 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
                           const uint8_t *cls, const int32_t *kcnt, const int32_t *kcol, const double *kval,
                           const int32_t *suffix_cls, const uint32_t *contains_mask, const uint8_t *flags,
                           const int64_t *attach_ptr, const void *thr, int32_t *long_rows, uint8_t *eflag, int32_t *rcnt,
-                          const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo, int32_t row_hi) {
+                          const int64_t *rptr, int32_t *ridx, double *rval, uint8_t *rflag, int32_t row_lo, int32_t row_hi,
+                          int32_t *rcnt2 = nullptr) {
     XM_ARG(S && bb && cls && kcnt && kcol && kval && suffix_cls && contains_mask && flags);
-    XM_ARG(mode >= 0 && mode <= 2);
+    XM_ARG((mode >= 0 && mode <= 2) || (mode == 3 && !fill && rcnt2 && eflag));
     XM_ARG(mode != 1 || attach_ptr);
     XM_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= S->n_items);
     if (row_hi == row_lo) return XMAP_OK;
@@ -2778,6 +2793,7 @@ static int reverse_common(void *stream, bool fill, const xmap_sim *S, int mode, 
     A.info = S->info; A.frac = S->frac; A.bb = bb; A.cls = cls; A.kcnt = kcnt; A.kcol = kcol; A.kval = kval;
     A.suffix_cls = suffix_cls; A.contains_mask = contains_mask; A.flags = flags;
     A.attach_ptr = (const long long *)attach_ptr;
+    A.rcnt2 = rcnt2;
     A.rcnt = rcnt; A.rptr = (const long long *)rptr; A.ridx = ridx; A.rval = rval; A.rflag = rflag;
     const int n_rows = row_hi - row_lo;
     dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
@@ -2817,6 +2833,15 @@ int xmap_reverse_count(void *stream, const xmap_sim *S, int mode, int top_k, con
     XM_ARG(rcnt);
     return reverse_common(stream, false, S, mode, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags,
                           attach_ptr, thr, long_rows, eflag, rcnt, nullptr, nullptr, nullptr, nullptr, row_lo, row_hi);
+}
+
+int xmap_reverse_count_att_rnn(void *stream, const xmap_sim *S, int top_k, const uint8_t *bb, const uint8_t *cls,
+                               const int32_t *kcnt, const int32_t *kcol, const double *kval, const int32_t *suffix_cls,
+                               const uint32_t *contains_mask, const uint8_t *flags, const void *thr, int32_t *long_rows,
+                               uint8_t *eflag, int32_t *rcnt_att, int32_t *rcnt_rnn, int32_t row_lo, int32_t row_hi) {
+    XM_ARG(rcnt_att && rcnt_rnn && eflag);
+    return reverse_common(stream, false, S, 3, top_k, bb, cls, kcnt, kcol, kval, suffix_cls, contains_mask, flags, nullptr, thr,
+                          long_rows, eflag, rcnt_att, nullptr, nullptr, nullptr, nullptr, row_lo, row_hi, rcnt_rnn);
 }
 
 int xmap_reverse_fill(void *stream, const xmap_sim *S, int mode, int top_k, const uint8_t *bb, const uint8_t *cls,

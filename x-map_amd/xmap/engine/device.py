@@ -820,6 +820,30 @@ class Engine(object):
         check(lib.xmap_reverse_count(_stream(self.dev), *st8.args, vp(st8.rcnt), i32(st8.rows[0]), i32(st8.rows[1])))
         return st8
 
+    def reverse_count_pair(self, S, E, rows):
+        """the count passes of the attach (mode 0) and rnn (mode 2) lists as ONE pass over the rows (both ask the non-bridge
+        neighbours of an entry, about their two lists): two handles like reverse_count's, sharing the per-entry bytes"""
+        R = self.R
+        I = R.n_items
+        lo, hi = (0, I) if rows is None else (int(rows[0]), int(rows[1]))
+        eflag = self._empty(max(int(S.col.numel()), 1), torch.uint8)
+        sts = []
+        for mode in (0, 2):
+            st8 = ExtResult()
+            st8.S, st8.E, st8.mode, st8.rows = S, E, mode, (lo, hi)
+            st8.rcnt = self._zeros(max(I, 1), torch.int32)
+            st8.eflag = eflag
+            st8.args = (C.byref(S.c), mode, E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol), vp(E.kval),
+                        vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(None), vp(E.thr),
+                        vp(getattr(E, "long_rows", None)), vp(eflag))
+            st8.keep = None
+            sts.append(st8)
+        check(lib.xmap_reverse_count_att_rnn(_stream(self.dev), C.byref(S.c), E.k, vp(E.bb), vp(E.cls), vp(E.kcnt), vp(E.kcol),
+                                             vp(E.kval), vp(R.suffix_cls), vp(R.contains_mask), vp(R.flags), vp(E.thr),
+                                             vp(getattr(E, "long_rows", None)), vp(eflag), vp(sts[0].rcnt), vp(sts[1].rcnt),
+                                             i32(lo), i32(hi)))
+        return sts
+
     def reverse_gather_counts(self, sts, comm):
         """collective: every rank's counts of its rows -> the counts of all rows (of several lists in one exchange)"""
         I = self.R.n_items
@@ -1128,9 +1152,15 @@ class Engine(object):
         run the three in row shares: xmap.engine.sharded._stage_b)"""
         with self.timed("reverse"):
             self.ext_thresholds(E)
-            E.att = self._reverse(S, E, 0, None)
+            if getattr(E, "thr", None) is not None and os.environ.get("XMAP_REV_SEPARATE") != "1":
+                st_att, st_rnn = self.reverse_count_pair(S, E, None)      # attach + rnn: one count pass for both
+                self.reverse_fill(st_att)
+                self.reverse_fill(st_rnn)
+                E.att, E.rnn = st_att.out, st_rnn.out
+            else:
+                E.att = self._reverse(S, E, 0, None)
+                E.rnn = self._reverse(S, E, 2, None)
             E.src = self._reverse(S, E, 1, E.att[0])
-            E.rnn = self._reverse(S, E, 2, None)
         return E
 
     def ext_tables_from_knn(self, top_k, cls, kcnt, kcol, kval):

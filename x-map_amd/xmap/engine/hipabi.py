@@ -70,7 +70,7 @@ EXPORTS = [
     "xmap_build_csc", "xmap_user_stats", "xmap_item_stats", 
     "xmap_sim2_layout", "xmap_sim2_plan", "xmap_sim2_units",
     "xmap_sim2_pairs", "xmap_sim2_scatter", "xmap_sim3_layout", "xmap_sim3_plan", "xmap_sim3_mircount", "xmap_sim3_mirror", "xmap_item_partials", "xmap_item_merge", "xmap_sim2_pack_partials",
-    "xmap_sim2_sort_partials", "xmap_sim2_merge_partials", "xmap_sim2_pack_pairs", "xmap_sim2_unpack_pairs", "xmap_bridge_flags", "xmap_knn_classify", "xmap_knn_thresholds", "xmap_reverse_count",
+    "xmap_sim2_sort_partials", "xmap_sim2_merge_partials", "xmap_sim2_pack_pairs", "xmap_sim2_unpack_pairs", "xmap_bridge_flags", "xmap_knn_classify", "xmap_knn_thresholds", "xmap_reverse_count", "xmap_reverse_count_att_rnn",
     "xmap_reverse_fill", "xmap_topc_from_lists", "xmap_path_weights", "xmap_extend_paths", 
     "xmap_mid_rows_count", "xmap_mid_rows_place", "xmap_edge_ranges", "xmap_end_universe", "xmap_extend_cols", "xmap_extend_cols_slots", "xmap_nb_index", "xmap_path_plan", "xmap_end_order", "xmap_dense_normalize", "xmap_dense_layout", "xmap_dense_topk", "xmap_rec_select", "xmap_predict", "xmap_select_map", "xmap_alterego_count", "xmap_alterego_fill",
     "xmap_feed_text", "xmap_feed_texts", "xmap_feed_merge", "xmap_feed_sizes", "xmap_feed_arrays", "xmap_feed_ids", "xmap_feed_free",

@@ -464,8 +464,11 @@ def _stage_b(eng, comm, coo, rowcnt, info, L, k, rank, world, n_local):
             for group in (((0, "att"), (2, "rnn")), ((1, "src"),)):
                 err, sts = None, []
                 try:
-                    for mode, _ in group:
-                        sts.append(eng.reverse_count(S, E, mode, E.att[0] if mode == 1 else None, rows))
+                    if len(group) == 2:
+                        sts = eng.reverse_count_pair(S, E, rows)          # (attach + rnn: one pass over the rows for both)
+                    else:
+                        for mode, _ in group:
+                            sts.append(eng.reverse_count(S, E, mode, E.att[0] if mode == 1 else None, rows))
                 except Exception as e:
                     err = e
                 comm.agree(err, "stage B (reverse lists: count)")
