@@ -6,9 +6,17 @@
 //   k_knn_classify  : per row, chunked bitonic sort in LDS by (|sim| desc, col asc) and the two
 //                     filtered top-k lists of find_knn_items                              (HBM-bound, one pass over D')
 //   k_reverse       : reverse adjacencies (attach / src / rnn) built in row order with an O(1)
-//                     membership test against the k-th entry of the neighbour's list       (HBM-bound, one pass over D')
-//   k_paths         : streamed path enumeration, one wave per start item, fp64 (s_p, c_p) in
-//                     registers, per-start accumulators, fused top-10                      (ALU / latency bound)
+//                     membership test against the k-th entry of the neighbour's list; count pass (attach + rnn together)
+//                     leaves a byte per entry, the fill passes read it                    (bound by the CU's gather rate)
+//   k_joint_list, k_att_columns, k_mid_rows<count|place>
+//                   : middle lists -- per non-bridge x' the (t, s, x) records of its joint paths, grouped by column x
+//                     (tile directory + 64-byte records); one block per x', tile counters in LDS, flat walk
+//   k_col_home, k_col_ends, k_paths4 (heads_Q), finalize_*, k_merge_groups, k_merge
+//                   : the path enumeration (default): start-major, heads merged by column, one row update per column,
+//                     rows indexed by end rank, exact (value, error) sums, fused top-10     (random HBM row updates)
+//   k_w_*           : exact per-start path counts (scheduling weights)
+//   k_paths         : per-path enumeration, one wave per start (fallback beyond the middle-list budget; cross-check)
+//   under XMAP_CROSSCHECK (libxmap_hip_xcheck.so only): k_mid_build / k_mid_dir (dense-table middle lists), k_paths2
 #include "common.h"
 #include <stdlib.h>
 
