@@ -358,6 +358,31 @@ def test_partitioned_count_on_random_shapes(dev):
         os.environ.pop("XMAP_COUNT_PART_MIN", None)
 
 
+def test_reverse_lists_fused_count_equals_separate_passes(dev, monkeypatch):
+    """attach and rnn lists are counted in ONE pass over the matrix (xmap_reverse_count_att_rnn; its byte per entry serves both
+    fill passes); XMAP_REV_SEPARATE=1 counts them in a pass each as rounds 1-4a did (mode 2 then writes its own bit): the
+    three reverse adjacencies come out identical, also with every row walked by the 16-wave kernel of the long rows"""
+    from xmap.engine import synth
+    r = synth.make_two_domain(23, 3000, 700, 700, overlap=0.15)
+    eng = _engine(dev, r.user_ptr, r.item, r.rating, r.time, r.n_items, r.item_attrs())
+    S = eng.item_sim("adjust_cosine", CAP)
+
+    def lists():
+        E = eng.ext_tables(S, 10)
+        return [t.cpu().numpy() for name in ("att", "src", "rnn") for t in getattr(E, name)[:4]]
+    fused = lists()
+    monkeypatch.setenv("XMAP_REV_SEPARATE", "1")
+    separate = lists()
+    monkeypatch.setenv("XMAP_REV_LONG", "8")           # (rows of more than 8 entries: k_reverse_long)
+    separate_long = lists()
+    monkeypatch.delenv("XMAP_REV_SEPARATE")
+    fused_long = lists()
+    assert sum(len(x) for x in fused) > 1000
+    for other in (separate, separate_long, fused_long):
+        for x, y in zip(fused, other):
+            assert np.array_equal(x, y)
+
+
 def test_middle_lists_in_column_ranges(dev, monkeypatch):
     """k_mid_rows keeps the tile counters of XMAP_MID_ROWS_SPAN columns in LDS and builds wider rows range by range: with a
     span of 37 columns (several ranges per row here) the extension equals the one-range build and the oracle, bit for bit."""
