@@ -902,6 +902,7 @@ struct MidArgs {
     int n_nb; const int *nb_list; const int *nb_id;
     const long long *jptr; const int *joff;     // joint (t, s) of every t, compacted: offsets into src(t) (k_joint_list; k_mid_rows)
     const int *axid;                            // column of every attach entry (k_att_columns)
+    const long long *xoff; int *xl;             // rows wider than the LDS span: the columns of a row's records in walk order, [xoff[x'], xoff[x'+1])
     int *tile_cnt;                 // [n_nb * n_nb] tally, then placement cursor
     const long long *tile_off;     // [n_nb * n_nb + 1]
     MidX *midX;
@@ -1003,6 +1004,38 @@ __global__ __launch_bounds__(256) void k_att_columns(long long bound, int I, con
     if (ap < bound && ap < att_ptr[I]) axid[ap] = nb_id[att_idx[ap]];
 }
 
+// records behind every t: sum of the attach-list lengths over its joint (t, s) -- and per row x' over its neighbours t: the
+// exact record count of a row BEFORE it is built (rows wider than the LDS span keep their records' columns in a scratch list)
+__global__ __launch_bounds__(256) void k_joint_records(int I, const long long *jptr, const int *joff, const long long *src_ptr,
+                                                       const int *src_idx, const long long *att_ptr, long long *jrec) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= I) return;
+    const int lane = lane_id();
+    const long long j0 = jptr[t], j1 = jptr[t + 1], s0 = src_ptr[t];
+    long long sum = 0;
+    for (long long j = j0 + lane; j < j1; j += 64) {
+        const int sx = src_idx[s0 + joff[j]];
+        sum += att_ptr[sx + 1] - att_ptr[sx];
+    }
+    sum = wave_sum_ll(sum);
+    if (lane == 0) jrec[t] = sum;
+}
+__global__ __launch_bounds__(256) void k_row_records(int n_nb, int k, const int *nb_list, const int *kcnt, const int *kcol,
+                                                     const uint8_t *flags, const long long *jrec, long long *rowrec) {
+    const int xpid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xpid >= n_nb) return;
+    const int lane = lane_id();
+    const int xp = nb_list[xpid];
+    const int nq = kcnt[(size_t)xp * 2];
+    long long sum = 0;
+    for (int q = lane; q < nq; q += 64) {
+        const int t = kcol[((size_t)xp * 2) * k + q];
+        if (flags[t] & 2) sum += jrec[t];
+    }
+    sum = wave_sum_ll(sum);
+    if (lane == 0) rowrec[xpid] = sum;
+}
+
 constexpr int MIDROW_WAVES = 16;
 template <int PHASE, bool ONE_RANGE>
 __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mid_rows(MidArgs A, int span, int *ng, long long *nrec, const long long *dir_ptr,
@@ -1036,7 +1069,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                     const int s = A.src_idx[p];
                     for (long long ap = A.att_ptr[s] + lane; ap < A.att_ptr[s + 1]; ap += 64) {
                         const int xid = A.nb_id[A.att_idx[ap]];
-                        if (ONE_RANGE || (xid >= x0 && xid < x1)) body(true, xid, v2, m2, f2, p, ap);
+                        if (ONE_RANGE || (xid >= x0 && xid < x1)) body(true, xid, v2, m2, f2, p, ap, 0ll);
                     }
                 }
             }
@@ -1062,6 +1095,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
     __shared__ int s_off[MIDROW_WAVES][64];          // (what else a record needs of its joint comes from the joint's LANE by
     volatile int *w_off = s_off[w];                  //  ds_bpermute: with 64.5 KB of counters at configs[1], two blocks per CU need the rest small)
     auto walk = [&](int x0, int x1, auto &&body) {
+        long long cbase = 0;                            // records of the chunks in front: a record's index in the row's walk order
         for (int qb = 0; qb < nq; qb += 64) {
             __syncthreads();                            // (nobody reads the previous table any more)
             if (w == 0) {
@@ -1104,16 +1138,19 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                 for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
                 const int T = rl32(incl, 63);
                 if (T == 0) continue;
+                const long long cb = cbase;
+                cbase += T;
                 __builtin_amdgcn_wave_barrier();
                 w_off[lane] = incl - len;                // first record of the lane's joint (lanes without records: their successor's)
                 __builtin_amdgcn_wave_barrier();
                 const int a0_lo = (int)(a0 & 0xffffffffll), a0_hi = (int)(a0 >> 32);
                 for (int r0 = 64 * w; r0 < T; r0 += 64 * MIDROW_WAVES * MID_UNROLL) {
-                    int jj[MID_UNROLL], xi[MID_UNROLL];
+                    int jj[MID_UNROLL], xi[MID_UNROLL], rr[MID_UNROLL];
                     long long ap[MID_UNROLL];
 #pragma unroll
                     for (int u = 0; u < MID_UNROLL; u++) {
                         const int r = r0 + u * 64 * MIDROW_WAVES + lane;
+                        rr[u] = r;
                         int j = 0;                       // the last lane whose joint starts at or before record r
 #pragma unroll
                         for (int st = 32; st >= 1; st >>= 1) if (w_off[j + st] <= r) j += st;
@@ -1128,7 +1165,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                         const int jl = jj[u] >= 0 ? jj[u] : 0;
                         const int qq = __shfl(q, jl, 64), jjo = __shfl(jo, jl, 64);      // (all lanes take part in the exchange)
                         // (every lane calls: the placement moves its records between the lanes of a quad)
-                        body(jj[u] >= 0 && (ONE_RANGE || (xi[u] >= x0 && xi[u] < x1)), xi[u], q_v2[qq], q_m2[qq], q_f2[qq], q_s0[qq] + jjo, ap[u]);
+                        body(jj[u] >= 0 && (ONE_RANGE || (xi[u] >= x0 && xi[u] < x1)), xi[u], q_v2[qq], q_m2[qq], q_f2[qq], q_s0[qq] + jjo, ap[u], cb + rr[u]);
                     }
                 }
             }
@@ -1137,12 +1174,34 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
 #endif
     unsigned long long done = 0;                        // (non-empty tiles << 40 | records) of the ranges before this one
     const long long rbase = PHASE ? rec_ptr[xpid] : 0, dbase = PHASE ? dir_ptr[xpid] : 0;
+#ifndef EXP_MID_WALK1
+    // A row wider than the LDS span is built range by range, and every range needs the tally of ITS columns.  The first form
+    // walked the row again for every tally (27 walks per row at the S1 shape: nine ranges, count + tally + placement); now ONE
+    // walk leaves the column of every record in a scratch list (the walk order is deterministic and the rows' record counts
+    // are known beforehand: k_joint_records / k_row_records), and the ranges' tallies stream it.
+    int *stash = nullptr;
+    long long n_stash = 0;
+    if (!ONE_RANGE) {
+        stash = A.xl + A.xoff[xpid];
+        n_stash = A.xoff[xpid + 1] - A.xoff[xpid];
+        walk(0, n_nb, [&](bool valid, int xid, double, double, double, long long, long long, long long ridx) { if (valid && ridx < n_stash) stash[ridx] = xid; });
+        __syncthreads();
+    }
+#endif
     for (int x0 = 0; x0 < n_nb; x0 += ONE_RANGE ? n_nb : span) {
         const int x1 = (ONE_RANGE || (x0 + span) >= n_nb) ? n_nb : (x0 + span), nx = x1 - x0;
         if (!ONE_RANGE) __syncthreads();                // (the previous range's placement is over)
         for (int i = threadIdx.x; i < nx; i += 64 * MIDROW_WAVES) bins[i] = 0;
         __syncthreads();
-        walk(x0, x1, [&](bool valid, int xid, double, double, double, long long, long long) { if (valid) atomicAdd(&bins[xid - x0], 1); });
+#ifndef EXP_MID_WALK1
+        if (!ONE_RANGE) {
+            for (long long i = threadIdx.x; i < n_stash; i += 64 * MIDROW_WAVES) {
+                const int xid = stash[i];
+                if (xid >= x0 && xid < x1) atomicAdd(&bins[xid - x0], 1);
+            }
+        } else
+#endif
+        walk(x0, x1, [&](bool valid, int xid, double, double, double, long long, long long, long long) { if (valid) atomicAdd(&bins[xid - x0], 1); });
         __syncthreads();
         // per thread a run of consecutive bins: (non-empty tiles << 40 | records), block-wide exclusive scan
         const int per = (nx + 64 * MIDROW_WAVES - 1) / (64 * MIDROW_WAVES);
@@ -1172,7 +1231,7 @@ __global__ __launch_bounds__(64 * MIDROW_WAVES) __attribute__((amdgpu_waves_per_
                 }
             }
             __syncthreads();
-            walk(x0, x1, [&](bool valid, int xid, double v2, double m2, double f2, long long p, long long ap) {
+            walk(x0, x1, [&](bool valid, int xid, double v2, double m2, double f2, long long p, long long ap, long long) {
                 long long pos = 0;
                 MidX r;
                 r.sm2 = 0.0; r.sm3 = 0.0; r.sm4 = 0.0; r.f2 = 0.0; r.f3 = 0.0; r.f4 = 0.0; r.mu = 0.0; r.xid = 0; r.pad = 0;
@@ -3007,7 +3066,7 @@ static MidArgs mid_args(int32_t n_items, int top_k, const uint8_t *cls, const in
 static_assert((size_t)XMAP_MID_ROWS_SPAN * 4 + (size_t)MIDROW_WAVES * 64 * 4 + 3072 + 256 <= 160 * 1024,
               "k_mid_rows: tile counters + the neighbour table + the waves' walk state must fit the LDS of a gfx950 CU");
 // the compacted joint lists of one call (temporaries of the caller's scope)
-static int mid_joints(hipStream_t st, MidArgs &A) {
+static int mid_joints(hipStream_t st, MidArgs &A, bool ranges) {
     int *jcnt = nullptr, *joff = nullptr;
     long long *jptr = nullptr;
     const int I = A.I;
@@ -3035,6 +3094,22 @@ static int mid_joints(hipStream_t st, MidArgs &A) {
             XM_LAUNCH_CHECK();
         }
         A.axid = axid;
+    }
+    if (ranges && A.n_nb > 0) {      // rows wider than the LDS span: where the columns of a row's records are kept between its ranges
+        long long *jrec = nullptr, *rowrec = nullptr, *xoff = nullptr;
+        int *xl = nullptr;
+        XM_HIP(xm_malloc_async((void **)&jrec, sizeof(long long) * (size_t)(I > 0 ? I : 1), st));
+        XM_HIP(xm_malloc_async((void **)&rowrec, sizeof(long long) * (size_t)A.n_nb, st));
+        XM_HIP(xm_malloc_async((void **)&xoff, sizeof(long long) * ((size_t)A.n_nb + 1), st));
+        k_joint_records<<<dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st>>>(I, jptr, joff, A.src_ptr, A.src_idx, A.att_ptr, jrec);
+        XM_LAUNCH_CHECK();
+        k_row_records<<<dim3((unsigned)((A.n_nb + 3) / 4)), dim3(256), 0, st>>>(A.n_nb, A.k, A.nb_list, A.kcnt, A.kcol, A.flags, jrec, rowrec);
+        XM_LAUNCH_CHECK();
+        int64_t total = 0;
+        rc = xmap_exclusive_scan_i64(st, (const int64_t *)rowrec, (int64_t *)xoff, A.n_nb, &total);
+        if (rc) return rc;
+        XM_HIP(xm_malloc_async((void **)&xl, sizeof(int) * (size_t)(total > 0 ? total : 1), st));
+        A.xoff = xoff; A.xl = xl;
     }
     return XMAP_OK;
 }
@@ -3064,7 +3139,7 @@ int xmap_mid_rows_count(void *stream, int32_t n_items, int top_k, const uint8_t 
                          src_flag, n_nb, nb_list, nb_id);
     XM_ARG(src_flag);
     XM_SCOPE(stream);
-    rc = mid_joints((hipStream_t)stream, A);
+    rc = mid_joints((hipStream_t)stream, A, span < n_nb);
     if (rc) return rc;
     if (span >= n_nb) {
         XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3096,7 +3171,7 @@ int xmap_mid_rows_place(void *stream, int32_t n_items, int top_k, const uint8_t 
     A.midX = (MidX *)midX;
     XM_ARG(src_flag);
     XM_SCOPE(stream);
-    rc = mid_joints((hipStream_t)stream, A);
+    rc = mid_joints((hipStream_t)stream, A, span < n_nb);
     if (rc) return rc;
     if (span >= n_nb) {
         XM_HIP(hipFuncSetAttribute((const void *)k_mid_rows<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
